@@ -1,0 +1,110 @@
+/*
+ * vslam_c.h -- C ABI of libvslam_hip.so: the MI355X (gfx950) implementation of the PTAM
+ * tracking + local bundle-adjustment hot path of ahcorde/visualSLAM_Android.
+ *
+ * The only C ABI the reference has is its JNI surface (jni/jni_part.cpp:84-145):
+ *   native_createTest / native_disposeTest / native_touchScreen / native_update(gray, rgba).
+ * vslam_create / vslam_destroy / vslam_touch / vslam_update replace those one for one
+ * (INTEGRATION.md shows the JNI stub that binds them).  The remaining entry points expose the
+ * stages behind Tracker::TrackFrame (jni/Tracker.cc:76-146) and MapMaker::AddKeyFrame
+ * (jni/MapMaker.cc:470-478) individually for parity tests and benchmarks; each cites the
+ * reference function it replaces.
+ *
+ * Conventions: plain pointers and sizes only; every call returns 0 on success or a negative
+ * VSLAM_E_* code (never aborts; the reference has no error convention, jni_part.cpp:144
+ * returns constant 0).  One vslam_system holds n_streams independent sequences that are
+ * processed in lock-step by batched kernels on one HIP stream; calls on one system must be
+ * serialised by the caller, different systems are independent.  Inputs are borrowed for the
+ * duration of the call; outputs go to caller-provided buffers.
+ */
+#ifndef VSLAM_C_H
+#define VSLAM_C_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSLAM_LEVELS 4 /* jni/KeyFrame.h:33 */
+
+#define VSLAM_OK 0
+#define VSLAM_E_INVALID (-1)  /* bad argument */
+#define VSLAM_E_HIP (-2)      /* HIP runtime error, see vslam_last_error() */
+#define VSLAM_E_CAPACITY (-3) /* a fixed-capacity device buffer overflowed */
+#define VSLAM_E_STATE (-4)    /* call not valid in the current state */
+
+/* reference-quirk switches. Default 0 = PTAM-intended semantics. */
+#define VSLAM_Q_CAM_INT_RADIUS 1         /* jni/ATANCamera.cc:70-82  */
+#define VSLAM_Q_POSE_INT_RESIDUAL 2      /* jni/Tracker.cc:766-767   */
+#define VSLAM_Q_NONMAX_RIGHT_NEIGHBOUR 4 /* jni/vision/cvfast.cpp:9282-9285 */
+
+typedef struct vslam_system vslam_system;
+
+/* Every tunable the reference hard-codes on the hot path. */
+typedef struct vslam_params {
+  int width, height;               /* jni/jni_part.cpp:41 (800x480 there) */
+  int n_streams;                   /* independent sequences batched on this GPU */
+  int fast_threshold[VSLAM_LEVELS];/* jni/KeyFrame.cc:32-39: 10,15,15,10 */
+  int nonmax_barrier;              /* jni/KeyFrame.cc:63: 10 */
+  int patch_size;                  /* jni/PatchFinder.h:48: 11 (BASELINE configs: 8) */
+  int max_corners[VSLAM_LEVELS];   /* device capacity per stream and level */
+  int max_points;                  /* map-point capacity per stream */
+  int max_keyframes;               /* keyframe capacity per stream */
+  int max_patches_per_frame;       /* jni/Tracker.cc:518: 1000 */
+  int coarse_min, coarse_max;      /* jni/Tracker.cc:405-406: 20, 60 */
+  int coarse_range;                /* jni/Tracker.cc:407: 30 */
+  int coarse_subpix_its;           /* jni/Tracker.cc:408: 8 */
+  int coarse_disabled;             /* jni/Tracker.cc:409: 0 */
+  double coarse_min_vel;           /* jni/Tracker.cc:410: 0.006 */
+  int fine_subpix_its;             /* jni/Tracker.cc:505: 8 (level 3 only) */
+  double wls_prior;                /* jni/Tracker.cc:734: 100 */
+  int use_sbi;                     /* jni/Tracker.cc:88 gvnUseSBI: reference 1; 0 here (SBI is a "next" row) */
+  int min_frames_between_kf;       /* jni/Tracker.cc:128: 20 */
+  double max_kf_dist_wiggle_mult;  /* jni/MapMaker.cc:768: 0.2 */
+  double wiggle_scale;             /* jni/MapMaker.cc:57: 0.1 */
+  int ba_max_iterations;           /* jni/Bundle.cc:65: 20 */
+  double ba_convergence_limit;     /* jni/Bundle.cc:66: 1e-6 */
+  double ba_min_tukey_sigma;       /* jni/Bundle.cc:224: 0.4 */
+  int ba_window;                   /* jni/MapMaker.cc:812-820: newest + 4 nearest = 5 */
+  int ba_min_keyframes;            /* jni/MapMaker.cc:803: 8 */
+  double cam[5];                   /* jni/ATANCamera.cc:20-24 normalised fx fy cx cy w */
+  int quirks;                      /* VSLAM_Q_* bit set */
+  int device;                      /* HIP device ordinal */
+} vslam_params;
+
+const char* vslam_last_error(void);
+int vslam_default_params(vslam_params* p, int width, int height, int n_streams);
+
+/* native_createTest / native_disposeTest (jni/jni_part.cpp:109-118) */
+int vslam_create(const vslam_params* p, vslam_system** out);
+int vslam_destroy(vslam_system* sys);
+int vslam_synchronize(vslam_system* sys);
+
+/* ---- frame front-end ------------------------------------------------------------------- */
+
+/* KeyFrame::MakeKeyFrame_Lite (jni/KeyFrame.cc:5-51) for all n_streams frames at once:
+ * 4-level pyramid, FAST-10 per level, raster-ordered corner lists and row LUTs, all on device.
+ * gray: n_streams images, image s at gray + s*stream_stride, rows row_stride bytes apart;
+ * on_device != 0 means gray is device memory (borrowed until the next front-end call).
+ * Asynchronous on the system's stream. */
+int vslam_make_keyframe_lite(vslam_system* sys, const uint8_t* gray, size_t row_stride,
+                             size_t stream_stride, int on_device);
+
+/* fast_nonmax (jni/vision/cvfast.cpp:9395-9400) on the current frame of every stream, all
+ * levels: compute_fast_score_old + nonmax_suppression -> vMaxCorners. */
+int vslam_fast_nonmax(vslam_system* sys);
+
+/* read-back of the current frame (synchronises) */
+int vslam_read_level_image(vslam_system* sys, int stream, int level, uint8_t* dst, size_t dst_stride);
+int vslam_read_corners(vslam_system* sys, int stream, int level, uint32_t* corners /* x | y<<16 */,
+                       int cap, int* n);
+int vslam_read_row_lut(vslam_system* sys, int stream, int level, int* lut /* height>>level ints */);
+int vslam_read_max_corners(vslam_system* sys, int stream, int level, uint32_t* corners, int* scores,
+                           int cap, int* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,32 @@
+"""CPU test: libvslam_hip.so loads and exports every symbol include/vslam_c.h declares."""
+import ctypes
+import os
+import re
+
+from visualslam_android_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "vslam_c.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vslam_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    syms = declared_symbols()
+    assert "vslam_create" in syms and "vslam_make_keyframe_lite" in syms
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), "libvslam_hip.so does not export %s" % s
+    # and the Python mirror binds exactly that set
+    assert sorted(capi.SYMBOLS) == syms
+
+
+def test_params_struct_defaults():
+    p = capi.default_params(640, 480, 3)
+    assert (p.width, p.height, p.n_streams) == (640, 480, 3)
+    assert list(p.fast_threshold) == [10, 15, 15, 10]          # jni/KeyFrame.cc:32-39
+    assert p.patch_size == 11 and p.max_patches_per_frame == 1000
+    assert abs(p.cam[0] - 0.841906) < 1e-12 and abs(p.cam[4] + 0.0133843) < 1e-12

@@ -1,0 +1,85 @@
+"""GPU parity: HIP front-end (through the C ABI) vs the oracle -- bit-exact images, corners, LUTs."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import synth_image
+from visualslam_android_amd import capi
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def run_gpu(frames, **kw):
+    S, h, w = frames.shape
+    sys_ = capi.System(capi.default_params(w, h, S, **kw))
+    sys_.make_keyframe_lite(frames)
+    return sys_
+
+
+@pytest.mark.parametrize("w,h,S", [(640, 480, 3), (160, 120, 2), (800, 480, 1), (1280, 720, 1), (200, 136, 2)])
+def test_keyframe_lite_bit_exact(oracle, w, h, S):
+    frames = np.stack([synth_image(100 + s, w, h) for s in range(S)])
+    g = run_gpu(frames)
+    for s in range(S):
+        want = oracle.make_keyframe_lite(frames[s])
+        for l in range(4):
+            img, corners, lut = want[l]
+            assert np.array_equal(g.read_level_image(s, l), img), (s, l)
+            assert np.array_equal(g.read_corners(s, l), corners), (s, l)
+            assert np.array_equal(g.read_row_lut(s, l), lut), (s, l)
+    g.close()
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "fast10_tree_*.npz"))))
+def test_fast10_against_reference_tree_vectors(path):
+    gv = np.load(path)
+    img = gv["image"]
+    thr = int(gv["threshold"])
+    g = run_gpu(img[None], fast_threshold=[thr] * 4)
+    assert np.array_equal(g.read_corners(0, 0), gv["corners"])
+    g.close()
+
+
+def test_edge_cases(oracle):
+    flat = np.full((1, 120, 160), 77, np.uint8)
+    g = run_gpu(flat)
+    assert all(len(g.read_corners(0, l)) == 0 for l in range(4))
+    assert np.all(g.read_row_lut(0, 0) == 0)
+    g.close()
+    # same system reused across frames: stale masks/counts must not leak
+    a = synth_image(1, 160, 120)[None]
+    g = run_gpu(a)
+    n1 = len(g.read_corners(0, 0))
+    g.make_keyframe_lite(flat)
+    assert len(g.read_corners(0, 0)) == 0
+    g.make_keyframe_lite(a)
+    assert len(g.read_corners(0, 0)) == n1 > 0
+    g.close()
+
+
+def test_capacity_overflow_is_reported():
+    noisy = np.random.default_rng(3).integers(0, 256, size=(1, 120, 160)).astype(np.uint8)
+    g = run_gpu(noisy, max_corners=[64, 64, 64, 64])
+    with pytest.raises(capi.VslamError):
+        g.read_corners(0, 0)
+    g.close()
+
+
+@pytest.mark.parametrize("quirk", [0, capi.Q_NONMAX_RIGHT_NEIGHBOUR])
+def test_fast_nonmax_bit_exact(oracle, quirk):
+    frames = np.stack([synth_image(300 + s, 320, 240) for s in range(2)])
+    g = run_gpu(frames, quirks=quirk)
+    g.fast_nonmax()
+    for s in range(2):
+        want = oracle.make_keyframe_lite(frames[s])
+        for l in range(4):
+            img, corners, _ = want[l]
+            sc = oracle.fast_score(img, corners, 10)
+            keep = oracle.nonmax(corners, sc, quirk=bool(quirk))
+            got, gsc = g.read_max_corners(s, l)
+            assert np.array_equal(gsc[:len(corners)], sc), (s, l)
+            assert np.array_equal(got, keep), (s, l)
+    g.close()

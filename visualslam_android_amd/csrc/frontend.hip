@@ -1,0 +1,383 @@
+// Frame front-end on gfx950: KeyFrame::MakeKeyFrame_Lite (jni/KeyFrame.cc:5-51) and fast_nonmax
+// (jni/vision/cvfast.cpp:9243-9400) for all streams of a system at once.
+//
+// Kernels (all HBM-bound byte/integer work; one pass over each level image):
+//   k_pyr_fast0   one workgroup per 16-row band of level 0: the band (+3-row halo) is staged in LDS
+//                 with 16-B coalesced loads, levels 1..3 of the band are produced from LDS
+//                 ((a+b+c+d+2)>>2) and written, and FAST-10 runs on the staged rows; one wave tests 64
+//                 consecutive pixels, __ballot gives the 64-bit corner-mask word and the row count.
+//   k_fast_lvl    the same FAST band sweep for levels 1..3 (their rows come back from L2/MALL).
+//   k_compact     per (stream, level): exclusive scan of the row counts = the reference's row LUT
+//                 (jni/KeyFrame.cc:43-49); each wave expands mask words into the raster-ordered corner
+//                 list at lut[y] + popcount prefix -> bit-exact order without ordered atomics.
+//   k_score / k_nonmax   compute_fast_score_old + nonmax_suppression, one lane per corner.
+#include "vslam_internal.h"
+
+#define BAND 16          // level-0 rows per workgroup (multiple of 8: three halvings stay inside a band)
+#define HALO 3           // FAST ring radius (cvfast.cpp:6094-6111)
+#define FE_THREADS 256
+
+struct FeArgs {
+  const uint8_t* in; size_t in_sstride; int in_pitch;
+  uint8_t* lvl[NLEV]; size_t lvl_sstride[NLEV]; int lvl_pitch[NLEV];
+  int w[NLEV], h[NLEV], nchunk[NLEV], thr[NLEV], cap[NLEV];
+  unsigned long long* cmask[NLEV];
+  int* rowcnt[NLEV];
+  int* rowlut[NLEV];
+  uint32_t* corners[NLEV];
+  int* ncorners;
+  int* overflow;
+  int band_first[NLEV];   // k_fast_lvl: first blockIdx.x of each level
+};
+
+__device__ __forceinline__ bool ring_run10(unsigned m16) {
+  unsigned m = m16 | (m16 << 16);
+  unsigned r2 = m & (m >> 1);
+  unsigned r4 = r2 & (r2 >> 2);
+  unsigned r8 = r4 & (r4 >> 4);
+  unsigned r10 = r8 & (r2 >> 8);
+  return (r10 & 0xFFFFu) != 0;
+}
+
+// FAST-10 segment test at LDS pixel p (row pitch lp): >=10 contiguous ring pixels all > c+t or all < c-t
+// (cvfast.cpp:6088-9241; equivalence with the decision tree is pinned in tests/golden/fast10_tree_pin.json).
+__device__ __forceinline__ bool fast10_at(const uint8_t* p, int lp, int t) {
+  const int c = p[0], cb = c + t, c_b = c - t;
+  const int p0 = p[3 * lp], p8 = p[-3 * lp];
+  if (!(p0 > cb || p0 < c_b || p8 > cb || p8 < c_b)) return false;   // an arc of 10 holds one of each opposite pair
+  const int p4 = p[3], p12 = p[-3];
+  if (!(p4 > cb || p4 < c_b || p12 > cb || p12 < c_b)) return false;
+  unsigned mb = 0, md = 0;
+#define RINGPIX(k, dx, dy) { const int v = p[(dx) + (dy) * lp]; mb |= (unsigned)(v > cb) << (k); md |= (unsigned)(v < c_b) << (k); }
+  RINGPIX(0, 0, 3) RINGPIX(1, 1, 3) RINGPIX(2, 2, 2) RINGPIX(3, 3, 1) RINGPIX(4, 3, 0) RINGPIX(5, 3, -1)
+  RINGPIX(6, 2, -2) RINGPIX(7, 1, -3) RINGPIX(8, 0, -3) RINGPIX(9, -1, -3) RINGPIX(10, -2, -2)
+  RINGPIX(11, -3, -1) RINGPIX(12, -3, 0) RINGPIX(13, -3, 1) RINGPIX(14, -2, 2) RINGPIX(15, -1, 3)
+#undef RINGPIX
+  return ring_run10(mb) || ring_run10(md);
+}
+
+// Stage rows [gy0, gy0+nrows) of an image into LDS (row pitch lp, 16-B aligned). Rows outside the image are skipped.
+__device__ __forceinline__ void stage_rows(uint8_t* tile, int lp, const uint8_t* img, int pitch, int w, int h,
+                                           int gy0, int nrows) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
+  for (int r = wave; r < nrows; r += nwave) {
+    const int gy = gy0 + r;
+    if (gy < 0 || gy >= h) continue;
+    const uint8_t* src = img + (size_t)gy * pitch;
+    uint8_t* dst = tile + r * lp;
+    int done = 0;
+    if ((((uintptr_t)src) & 15) == 0) {
+      const int nvec = w >> 4;
+      for (int v = lane; v < nvec; v += 64) ((uint4*)dst)[v] = ((const uint4*)src)[v];
+      done = nvec << 4;
+    }
+    for (int i = done + lane; i < w; i += 64) dst[i] = src[i];
+  }
+}
+
+// FAST over nrows image rows starting at y0; tile row 0 holds image row y0 - HALO.
+__device__ __forceinline__ void fast_band(const uint8_t* tile, int lp, int y0, int nrows, int w, int h, int thr,
+                                          int nchunk, unsigned long long* cmask /* [h][nchunk] */,
+                                          int* rowcnt /* [h] */, int* cnt_lds /* [BAND] */) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
+  if (threadIdx.x < BAND) cnt_lds[threadIdx.x] = 0;
+  __syncthreads();
+  const int items = nrows * nchunk;
+  for (int it = wave; it < items; it += nwave) {
+    const int r = it / nchunk, c = it - r * nchunk;
+    const int y = y0 + r, x = (c << 6) + lane;
+    bool flag = false;
+    if (y >= HALO && y < h - HALO && x >= HALO && x < w - HALO)      // cvfast.cpp:6113-6117
+      flag = fast10_at(tile + (r + HALO) * lp + x, lp, thr);
+    const unsigned long long m = __ballot(flag);
+    if (lane == 0) {
+      cmask[(size_t)y * nchunk + c] = m;
+      if (m) atomicAdd(&cnt_lds[r], __popcll(m));
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nrows) rowcnt[y0 + threadIdx.x] = cnt_lds[threadIdx.x];
+}
+
+// 2x2 box mean of nrows_out output rows: src rows (2j, 2j+1) of an LDS tile -> LDS tile + global.
+__device__ __forceinline__ void halve_rows(const uint8_t* src, int slp, uint8_t* dst, int dlp, int wout, int nrows_out,
+                                           uint8_t* gdst, int gpitch) {
+  const int q = wout >> 2;
+  for (int it = threadIdx.x; it < nrows_out * q; it += blockDim.x) {
+    const int j = it / q, xq = it - j * q;
+    const uint2 a = *(const uint2*)(src + (2 * j) * slp + 8 * xq);
+    const uint2 b = *(const uint2*)(src + (2 * j + 1) * slp + 8 * xq);
+    uint32_t o = 0;
+#define HQ(k, wa, wb, sh) { const unsigned s = ((wa >> sh) & 255u) + ((wa >> (sh + 8)) & 255u) + ((wb >> sh) & 255u) + ((wb >> (sh + 8)) & 255u) + 2u; o |= (s >> 2) << (8 * k); }
+    HQ(0, a.x, b.x, 0) HQ(1, a.x, b.x, 16) HQ(2, a.y, b.y, 0) HQ(3, a.y, b.y, 16)
+#undef HQ
+    if (dst) *(uint32_t*)(dst + j * dlp + 4 * xq) = o;
+    *(uint32_t*)(gdst + (size_t)j * gpitch + 4 * xq) = o;
+  }
+  const int rem = wout - (q << 2);
+  for (int it = threadIdx.x; it < nrows_out * rem; it += blockDim.x) {
+    const int j = it / rem, x = (q << 2) + (it - j * rem);
+    const uint8_t* r0 = src + (2 * j) * slp + 2 * x;
+    const uint8_t* r1 = r0 + slp;
+    const uint8_t o = (uint8_t)((r0[0] + r0[1] + r1[0] + r1[1] + 2) >> 2);
+    if (dst) dst[j * dlp + x] = o;
+    gdst[(size_t)j * gpitch + x] = o;
+  }
+}
+
+__global__ __launch_bounds__(FE_THREADS) void k_pyr_fast0(FeArgs a, int lp0, int lp1, int lp2) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  uint8_t* t0 = lds;                               // (BAND + 2*HALO) rows of level 0
+  uint8_t* t1 = t0 + (BAND + 2 * HALO) * lp0;      // BAND/2 rows of level 1
+  uint8_t* t2 = t1 + (BAND / 2) * lp1;             // BAND/4 rows of level 2
+  int* cnt = (int*)(t2 + (BAND / 4) * lp2);
+  const int b = blockIdx.x, s = blockIdx.y;
+  const uint8_t* in = a.in + (size_t)s * a.in_sstride;
+  const int y0 = b * BAND;
+  stage_rows(t0, lp0, in, a.in_pitch, a.w[0], a.h[0], y0 - HALO, BAND + 2 * HALO);
+  __syncthreads();
+  // pyramid rows owned by this band (jni/KeyFrame.cc:19-23; 2:1 area filter)
+  int n1 = min(BAND / 2, a.h[1] - y0 / 2); n1 = max(n1, 0);
+  halve_rows(t0 + HALO * lp0, lp0, t1, lp1, a.w[1], n1, a.lvl[1] + (size_t)s * a.lvl_sstride[1] + (size_t)(y0 / 2) * a.lvl_pitch[1], a.lvl_pitch[1]);
+  __syncthreads();
+  int n2 = min(BAND / 4, a.h[2] - y0 / 4); n2 = max(n2, 0);
+  halve_rows(t1, lp1, t2, lp2, a.w[2], n2, a.lvl[2] + (size_t)s * a.lvl_sstride[2] + (size_t)(y0 / 4) * a.lvl_pitch[2], a.lvl_pitch[2]);
+  __syncthreads();
+  int n3 = min(BAND / 8, a.h[3] - y0 / 8); n3 = max(n3, 0);
+  halve_rows(t2, lp2, nullptr, 0, a.w[3], n3, a.lvl[3] + (size_t)s * a.lvl_sstride[3] + (size_t)(y0 / 8) * a.lvl_pitch[3], a.lvl_pitch[3]);
+  // FAST-10 on the level-0 rows of the band
+  const int nrows = min(BAND, a.h[0] - y0);
+  fast_band(t0, lp0, y0, nrows, a.w[0], a.h[0], a.thr[0], a.nchunk[0],
+            a.cmask[0] + (size_t)s * a.h[0] * a.nchunk[0], a.rowcnt[0] + (size_t)s * a.h[0], cnt);
+}
+
+__global__ __launch_bounds__(FE_THREADS) void k_fast_lvl(FeArgs a) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  int l = 1;
+  if ((int)blockIdx.x >= a.band_first[2]) l = 2;
+  if ((int)blockIdx.x >= a.band_first[3]) l = 3;
+  const int b = blockIdx.x - a.band_first[l], s = blockIdx.y;
+  const int lp = (a.w[l] + 15) & ~15;
+  uint8_t* t = lds;
+  int* cnt = (int*)(t + (BAND + 2 * HALO) * lp);
+  const int y0 = b * BAND;
+  stage_rows(t, lp, a.lvl[l] + (size_t)s * a.lvl_sstride[l], a.lvl_pitch[l], a.w[l], a.h[l], y0 - HALO, BAND + 2 * HALO);
+  __syncthreads();
+  const int nrows = min(BAND, a.h[l] - y0);
+  fast_band(t, lp, y0, nrows, a.w[l], a.h[l], a.thr[l], a.nchunk[l],
+            a.cmask[l] + (size_t)s * a.h[l] * a.nchunk[l], a.rowcnt[l] + (size_t)s * a.h[l], cnt);
+}
+
+// Block-wide exclusive scan of n ints (n <= 16*256) from global into LDS out[0..n]; out[n] = total.
+__device__ __forceinline__ void block_exscan(const int* in, int n, int* out, int* wsum /* [8] */) {
+  const int per = (n + FE_THREADS - 1) / FE_THREADS;
+  const int lo = min((int)threadIdx.x * per, n), hi = min(lo + per, n);
+  int sum = 0;
+  for (int i = lo; i < hi; i++) sum += in[i];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = sum;
+  for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(inc, d); if (lane >= d) inc += v; }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; w++) base += wsum[w];
+  int run = base + inc - sum;
+  for (int i = lo; i < hi; i++) { out[i] = run; run += in[i]; }
+  if (threadIdx.x == FE_THREADS - 1) out[n] = run;
+  __syncthreads();
+}
+
+#define COMPACT_RB 8   // workgroups per (stream, level)
+__global__ __launch_bounds__(FE_THREADS) void k_compact(FeArgs a) {
+  __shared__ int lut[4096 + 1];
+  __shared__ int wsum[8];
+  const int l = blockIdx.y, s = blockIdx.z;
+  const int h = a.h[l], nchunk = a.nchunk[l], cap = a.cap[l];
+  const int* rowcnt = a.rowcnt[l] + (size_t)s * h;
+  block_exscan(rowcnt, h, lut, wsum);
+  if (blockIdx.x == 0) {
+    int* glut = a.rowlut[l] + (size_t)s * (h + 1);
+    for (int i = threadIdx.x; i <= h; i += FE_THREADS) glut[i] = min(lut[i], cap);
+    if (threadIdx.x == 0) {
+      a.ncorners[s * NLEV + l] = min(lut[h], cap);
+      if (lut[h] > cap) *a.overflow = 1;
+    }
+  }
+  const unsigned long long* cm = a.cmask[l] + (size_t)s * h * nchunk;
+  uint32_t* out = a.corners[l] + (size_t)s * cap;
+  const int lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * (FE_THREADS / 64) + (threadIdx.x >> 6), ngw = gridDim.x * (FE_THREADS / 64);
+  for (int y = gw; y < h; y += ngw) {
+    int base = lut[y];
+    if (lut[y + 1] == base) continue;
+    const unsigned long long mine = lane < nchunk ? cm[(size_t)y * nchunk + lane] : 0ull;
+    for (int c = 0; c < nchunk; c++) {
+      const unsigned long long m = __shfl(mine, c);
+      if (!m) continue;
+      if ((m >> lane) & 1ull) {
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < cap) out[pos] = (uint32_t)((c << 6) + lane) | ((uint32_t)y << 16);
+      }
+      base += __popcll(m);
+    }
+  }
+}
+
+// ---- MakeKeyFrame_Rest: FAST score + non-max (jni/KeyFrame.cc:53-63) ---------------------------------------------
+struct NmArgs {
+  const uint8_t* img[NLEV]; size_t img_sstride[NLEV]; int img_pitch[NLEV];
+  int h[NLEV], cap[NLEV];
+  const uint32_t* corners[NLEV]; const int* rowlut[NLEV]; const int* ncorners;
+  int* scores[NLEV]; uint32_t* maxcorners[NLEV]; int* nmax;
+  int barrier, quirk;
+};
+
+// compute_fast_score_old (cvfast.cpp:9337-9393): one lane per corner.
+__global__ __launch_bounds__(FE_THREADS) void k_score(NmArgs a) {
+  const int l = blockIdx.y, s = blockIdx.z;
+  const int n = a.ncorners[s * NLEV + l];
+  const int i = blockIdx.x * FE_THREADS + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t cxy = a.corners[l][(size_t)s * a.cap[l] + i];
+  const int x = cxy & 0xFFFF, y = cxy >> 16, lp = a.img_pitch[l];
+  const uint8_t* p = a.img[l] + (size_t)s * a.img_sstride[l] + (size_t)y * lp + x;
+  const int cb = p[0] + a.barrier, c_b = p[0] - a.barrier;
+  int sp = 0, sn = 0;
+#define SC(dx, dy) { const int v = p[(dx) + (dy) * lp]; if (v > cb) sp += v - cb; else if (v < c_b) sn += c_b - v; }
+  SC(0, 3) SC(1, 3) SC(2, 2) SC(3, 1) SC(3, 0) SC(3, -1) SC(2, -2) SC(1, -3)
+  SC(0, -3) SC(-1, -3) SC(-2, -2) SC(-3, -1) SC(-3, 0) SC(-3, 1) SC(-2, 2) SC(-1, 3)
+#undef SC
+  a.scores[l][(size_t)s * a.cap[l] + i] = sp > sn ? sp : sn;
+}
+
+// nonmax_suppression (cvfast.cpp:9243-9335): a corner survives unless a corner among its 8 neighbours
+// has a strictly greater score; rows above/below are found through the row LUT.  One workgroup per
+// (stream, level) keeps the output in raster order with a block scan of the keep flags.
+__global__ __launch_bounds__(FE_THREADS) void k_nonmax(NmArgs a) {
+  __shared__ int wsum[8];
+  __shared__ int carry;
+  const int l = blockIdx.x, s = blockIdx.y;
+  const int n = a.ncorners[s * NLEV + l], cap = a.cap[l], h = a.h[l];
+  const uint32_t* cs = a.corners[l] + (size_t)s * cap;
+  const int* sc = a.scores[l] + (size_t)s * cap;
+  const int* lut = a.rowlut[l] + (size_t)s * (h + 1);
+  uint32_t* out = a.maxcorners[l] + (size_t)s * cap;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i0 = 0; i0 < n; i0 += FE_THREADS) {
+    const int i = i0 + threadIdx.x;
+    int keep = 0;
+    uint32_t me = 0;
+    if (i < n) {
+      me = cs[i];
+      const int x = me & 0xFFFF, y = me >> 16, score = sc[i];
+      keep = 1;
+      if (i > 0) {                                                     // check left  :9276-9279
+        const uint32_t c = cs[i - 1];
+        if ((int)(c & 0xFFFF) == x - 1 && (int)(c >> 16) == y && sc[i - 1] > score) keep = 0;
+      }
+      if (keep && i < n - 1) {                                         // check right :9281-9285
+        const uint32_t c = cs[i + 1];
+        if (a.quirk) {  // reference tests corners[i-1](1) == pos(1); i == 0 reads out of bounds there -> no match
+          if (i > 0 && (int)(c & 0xFFFF) == x + 1 && (int)(cs[i - 1] >> 16) == y && sc[i + 1] > score) keep = 0;
+        } else {
+          if ((int)(c & 0xFFFF) == x + 1 && (int)(c >> 16) == y && sc[i + 1] > score) keep = 0;
+        }
+      }
+      if (keep && y > 0) {                                             // check above :9287-9306
+        for (int j = lut[y - 1]; j < lut[y]; j++) {
+          const int xx = cs[j] & 0xFFFF;
+          if (xx > x + 1) break;
+          if (xx >= x - 1 && sc[j] > score) { keep = 0; break; }
+        }
+      }
+      if (keep && y + 1 < h) {                                         // check below :9308-9326
+        for (int j = lut[y + 1]; j < lut[y + 2 > h ? h : y + 2]; j++) {
+          const int xx = cs[j] & 0xFFFF;
+          if (xx > x + 1) break;
+          if (xx >= x - 1 && sc[j] > score) { keep = 0; break; }
+        }
+      }
+    }
+    int inc = keep;
+    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(inc, d); if (lane >= d) inc += v; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int base = carry;
+    for (int w = 0; w < wave; w++) base += wsum[w];
+    if (keep) out[base + inc - 1] = me;
+    __syncthreads();
+    if (threadIdx.x == FE_THREADS - 1) carry = base + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) a.nmax[s * NLEV + l] = carry;
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------
+static void fill_fe_args(vslam_system* sys, FeArgs& a) {
+  for (int l = 0; l < NLEV; l++) {
+    a.lvl[l] = sys->d_lvl[l];
+    a.lvl_sstride[l] = (size_t)sys->geom[l].pitch * sys->geom[l].h;
+    a.lvl_pitch[l] = sys->geom[l].pitch;
+    a.w[l] = sys->geom[l].w; a.h[l] = sys->geom[l].h; a.nchunk[l] = sys->geom[l].nchunk;
+    a.thr[l] = sys->geom[l].thr; a.cap[l] = sys->geom[l].cap;
+    a.cmask[l] = sys->fr.cmask[l]; a.rowcnt[l] = sys->fr.rowcnt[l]; a.rowlut[l] = sys->fr.rowlut[l];
+    a.corners[l] = sys->fr.corners[l];
+  }
+  a.ncorners = sys->fr.ncorners;
+  a.overflow = sys->fr.overflow;
+}
+
+int fe_make_keyframe_lite(vslam_system* sys, const uint8_t* gray, size_t row_stride, size_t stream_stride,
+                          int on_device) {
+  const LevelGeom* g = sys->geom;
+  if (!gray || (int)row_stride < g[0].w) { vslam_set_error("make_keyframe_lite: bad image arguments"); return VSLAM_E_INVALID; }
+  FeArgs a;
+  fill_fe_args(sys, a);
+  if (on_device) {
+    a.in = gray; a.in_sstride = stream_stride; a.in_pitch = (int)row_stride;
+  } else {
+    // host input: copy into the owned level-0 image (TrackFrame copies its input too, jni/KeyFrame.cc:12)
+    for (int s = 0; s < sys->S; s++)
+      HIPCHK(hipMemcpy2DAsync(sys->d_lvl[0] + (size_t)s * a.lvl_sstride[0], g[0].pitch, gray + (size_t)s * stream_stride,
+                              row_stride, g[0].w, g[0].h, hipMemcpyHostToDevice, sys->stream));
+    a.in = sys->d_lvl[0]; a.in_sstride = a.lvl_sstride[0]; a.in_pitch = g[0].pitch;
+  }
+  sys->fr.img[0] = a.in; sys->fr.img_sstride[0] = a.in_sstride; sys->fr.img_pitch[0] = a.in_pitch;
+  for (int l = 1; l < NLEV; l++) { sys->fr.img[l] = a.lvl[l]; sys->fr.img_sstride[l] = a.lvl_sstride[l]; sys->fr.img_pitch[l] = a.lvl_pitch[l]; }
+
+  const int lp0 = (g[0].w + 15) & ~15, lp1 = (g[1].w + 15) & ~15, lp2 = (g[2].w + 15) & ~15;
+  const size_t lds0 = (size_t)(BAND + 2 * HALO) * lp0 + (BAND / 2) * lp1 + (BAND / 4) * lp2 + BAND * sizeof(int);
+  const int nb0 = (g[0].h + BAND - 1) / BAND;
+  hipLaunchKernelGGL(k_pyr_fast0, dim3(nb0, sys->S), dim3(FE_THREADS), lds0, sys->stream, a, lp0, lp1, lp2);
+  int nb = 0;
+  a.band_first[0] = 0;
+  for (int l = 1; l < NLEV; l++) { a.band_first[l] = nb; nb += (g[l].h + BAND - 1) / BAND; }
+  const size_t lds1 = (size_t)(BAND + 2 * HALO) * lp1 + BAND * sizeof(int);
+  hipLaunchKernelGGL(k_fast_lvl, dim3(nb, sys->S), dim3(FE_THREADS), lds1, sys->stream, a);
+  hipLaunchKernelGGL(k_compact, dim3(COMPACT_RB, NLEV, sys->S), dim3(FE_THREADS), 0, sys->stream, a);
+  HIPCHK(hipGetLastError());
+  sys->have_frame = true;
+  return VSLAM_OK;
+}
+
+int fe_fast_nonmax(vslam_system* sys) {
+  if (!sys->have_frame) { vslam_set_error("fast_nonmax: no current frame"); return VSLAM_E_STATE; }
+  NmArgs a;
+  int maxcap = 0;
+  for (int l = 0; l < NLEV; l++) {
+    a.img[l] = sys->fr.img[l]; a.img_sstride[l] = sys->fr.img_sstride[l]; a.img_pitch[l] = sys->fr.img_pitch[l];
+    a.h[l] = sys->geom[l].h; a.cap[l] = sys->geom[l].cap;
+    a.corners[l] = sys->fr.corners[l]; a.rowlut[l] = sys->fr.rowlut[l];
+    a.scores[l] = sys->fr.scores[l]; a.maxcorners[l] = sys->fr.maxcorners[l];
+    if (a.cap[l] > maxcap) maxcap = a.cap[l];
+  }
+  a.ncorners = sys->fr.ncorners; a.nmax = sys->fr.nmax;
+  a.barrier = sys->p.nonmax_barrier;
+  a.quirk = (sys->p.quirks & VSLAM_Q_NONMAX_RIGHT_NEIGHBOUR) ? 1 : 0;
+  hipLaunchKernelGGL(k_score, dim3((maxcap + FE_THREADS - 1) / FE_THREADS, NLEV, sys->S), dim3(FE_THREADS), 0, sys->stream, a);
+  hipLaunchKernelGGL(k_nonmax, dim3(NLEV, sys->S), dim3(FE_THREADS), 0, sys->stream, a);
+  HIPCHK(hipGetLastError());
+  return VSLAM_OK;
+}

@@ -1,0 +1,198 @@
+// vslam_system lifetime, parameters and read-back entry points of the C ABI (include/vslam_c.h).
+#include "vslam_internal.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void vslam_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* vslam_last_error(void) { return g_err; }
+
+extern "C" int vslam_default_params(vslam_params* p, int width, int height, int n_streams) {
+  if (!p || width < 64 || height < 64 || n_streams < 1) { vslam_set_error("default_params: bad size"); return VSLAM_E_INVALID; }
+  memset(p, 0, sizeof(*p));
+  p->width = width; p->height = height; p->n_streams = n_streams;
+  p->fast_threshold[0] = 10; p->fast_threshold[1] = 15; p->fast_threshold[2] = 15; p->fast_threshold[3] = 10;
+  p->nonmax_barrier = 10;
+  p->patch_size = 11;
+  for (int l = 0; l < NLEV; l++) {
+    const int n = ((width >> l) * (height >> l)) / 8;
+    p->max_corners[l] = n < 256 ? 256 : n;
+  }
+  p->max_points = 4096;
+  p->max_keyframes = 32;
+  p->max_patches_per_frame = 1000;
+  p->coarse_min = 20; p->coarse_max = 60; p->coarse_range = 30; p->coarse_subpix_its = 8;
+  p->coarse_disabled = 0; p->coarse_min_vel = 0.006;
+  p->fine_subpix_its = 8;
+  p->wls_prior = 100.0;
+  p->use_sbi = 0;
+  p->min_frames_between_kf = 20;
+  p->max_kf_dist_wiggle_mult = 0.2;
+  p->wiggle_scale = 0.1;
+  p->ba_max_iterations = 20;
+  p->ba_convergence_limit = 1e-6;
+  p->ba_min_tukey_sigma = 0.4;
+  p->ba_window = 5;
+  p->ba_min_keyframes = 8;
+  p->cam[0] = 0.841906; p->cam[1] = 1.10893; p->cam[2] = 0.505171; p->cam[3] = 0.470265; p->cam[4] = -0.0133843;
+  p->quirks = 0;
+  p->device = 0;
+  return VSLAM_OK;
+}
+
+template <class T>
+static int dev_alloc(vslam_system* sys, T** out, size_t count) {
+  void* ptr = nullptr;
+  HIPCHK(hipMalloc(&ptr, count * sizeof(T) + 64));
+  HIPCHK(hipMemsetAsync(ptr, 0, count * sizeof(T) + 64, sys->stream));
+  sys->allocs.push_back(ptr);
+  *out = (T*)ptr;
+  return VSLAM_OK;
+}
+#define ALLOC(ptr, count) do { int _r = dev_alloc(sys, &(ptr), (count)); if (_r) { vslam_destroy(sys); return _r; } } while (0)
+
+extern "C" int vslam_create(const vslam_params* p, vslam_system** out) {
+  if (!p || !out) { vslam_set_error("create: null argument"); return VSLAM_E_INVALID; }
+  if (p->width < 64 || p->height < 64 || p->width > 4096 || p->height > 4096 || p->n_streams < 1 ||
+      (p->patch_size != 8 && p->patch_size != 11)) {
+    vslam_set_error("create: unsupported size %dx%d streams %d patch %d", p->width, p->height, p->n_streams, p->patch_size);
+    return VSLAM_E_INVALID;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+    vslam_set_error("create: no HIP device visible (the MI355X path has no CPU fallback)");
+    return VSLAM_E_HIP;
+  }
+  HIPCHK(hipSetDevice(p->device));
+  vslam_system* sys = new vslam_system();
+  sys->p = *p;
+  sys->S = p->n_streams;
+  sys->have_frame = false;
+  sys->stream = nullptr;
+  if (hipStreamCreateWithFlags(&sys->stream, hipStreamNonBlocking) != hipSuccess) {
+    vslam_set_error("create: hipStreamCreate failed"); delete sys; return VSLAM_E_HIP;
+  }
+  const int S = sys->S;
+  for (int l = 0; l < NLEV; l++) {
+    LevelGeom& g = sys->geom[l];
+    g.w = p->width >> l; g.h = p->height >> l;
+    g.pitch = (g.w + 63) & ~63;
+    g.nchunk = (g.w + 63) >> 6;
+    g.cap = p->max_corners[l];
+    g.thr = p->fast_threshold[l];
+    ALLOC(sys->d_lvl[l], (size_t)S * g.pitch * g.h);
+    ALLOC(sys->fr.cmask[l], (size_t)S * g.h * g.nchunk);
+    ALLOC(sys->fr.rowcnt[l], (size_t)S * g.h);
+    ALLOC(sys->fr.rowlut[l], (size_t)S * (g.h + 1));
+    ALLOC(sys->fr.corners[l], (size_t)S * g.cap);
+    ALLOC(sys->fr.scores[l], (size_t)S * g.cap);
+    ALLOC(sys->fr.maxcorners[l], (size_t)S * g.cap);
+    sys->fr.img[l] = sys->d_lvl[l];
+    sys->fr.img_sstride[l] = (size_t)g.pitch * g.h;
+    sys->fr.img_pitch[l] = g.pitch;
+  }
+  ALLOC(sys->fr.ncorners, (size_t)S * NLEV);
+  ALLOC(sys->fr.nmax, (size_t)S * NLEV);
+  ALLOC(sys->fr.overflow, 1);
+  if (hipStreamSynchronize(sys->stream) != hipSuccess) { vslam_set_error("create: sync failed"); vslam_destroy(sys); return VSLAM_E_HIP; }
+  *out = sys;
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_destroy(vslam_system* sys) {
+  if (!sys) return VSLAM_OK;
+  if (sys->stream) (void)hipStreamSynchronize(sys->stream);
+  for (void* p : sys->allocs) (void)hipFree(p);
+  if (sys->stream) (void)hipStreamDestroy(sys->stream);
+  delete sys;
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_synchronize(vslam_system* sys) {
+  if (!sys) return VSLAM_E_INVALID;
+  HIPCHK(hipStreamSynchronize(sys->stream));
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_make_keyframe_lite(vslam_system* sys, const uint8_t* gray, size_t row_stride, size_t stream_stride,
+                                        int on_device) {
+  if (!sys) return VSLAM_E_INVALID;
+  return fe_make_keyframe_lite(sys, gray, row_stride, stream_stride, on_device);
+}
+
+extern "C" int vslam_fast_nonmax(vslam_system* sys) {
+  if (!sys) return VSLAM_E_INVALID;
+  return fe_fast_nonmax(sys);
+}
+
+static int check_sl(vslam_system* sys, int stream, int level) {
+  if (!sys || stream < 0 || stream >= sys->S || level < 0 || level >= NLEV) { vslam_set_error("bad stream/level"); return VSLAM_E_INVALID; }
+  if (!sys->have_frame) { vslam_set_error("no current frame"); return VSLAM_E_STATE; }
+  return VSLAM_OK;
+}
+
+static int check_overflow(vslam_system* sys) {
+  int ov = 0;
+  HIPCHK(hipMemcpyAsync(&ov, sys->fr.overflow, sizeof(int), hipMemcpyDeviceToHost, sys->stream));
+  HIPCHK(hipStreamSynchronize(sys->stream));
+  if (ov) { vslam_set_error("corner capacity exceeded (raise vslam_params.max_corners)"); return VSLAM_E_CAPACITY; }
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_read_level_image(vslam_system* sys, int stream, int level, uint8_t* dst, size_t dst_stride) {
+  int r = check_sl(sys, stream, level); if (r) return r;
+  const LevelGeom& g = sys->geom[level];
+  HIPCHK(hipMemcpy2DAsync(dst, dst_stride, sys->fr.img[level] + (size_t)stream * sys->fr.img_sstride[level],
+                          sys->fr.img_pitch[level], g.w, g.h, hipMemcpyDeviceToHost, sys->stream));
+  HIPCHK(hipStreamSynchronize(sys->stream));
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_read_corners(vslam_system* sys, int stream, int level, uint32_t* corners, int cap, int* n) {
+  int r = check_sl(sys, stream, level); if (r) return r;
+  r = check_overflow(sys); if (r) return r;
+  int cnt = 0;
+  HIPCHK(hipMemcpyAsync(&cnt, sys->fr.ncorners + stream * NLEV + level, sizeof(int), hipMemcpyDeviceToHost, sys->stream));
+  HIPCHK(hipStreamSynchronize(sys->stream));
+  if (n) *n = cnt;
+  const int m = cnt < cap ? cnt : cap;
+  if (corners && m > 0) {
+    HIPCHK(hipMemcpyAsync(corners, sys->fr.corners[level] + (size_t)stream * sys->geom[level].cap, (size_t)m * 4,
+                          hipMemcpyDeviceToHost, sys->stream));
+    HIPCHK(hipStreamSynchronize(sys->stream));
+  }
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_read_row_lut(vslam_system* sys, int stream, int level, int* lut) {
+  int r = check_sl(sys, stream, level); if (r) return r;
+  const int h = sys->geom[level].h;
+  HIPCHK(hipMemcpyAsync(lut, sys->fr.rowlut[level] + (size_t)stream * (h + 1), (size_t)h * 4, hipMemcpyDeviceToHost, sys->stream));
+  HIPCHK(hipStreamSynchronize(sys->stream));
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_read_max_corners(vslam_system* sys, int stream, int level, uint32_t* corners, int* scores, int cap,
+                                      int* n) {
+  int r = check_sl(sys, stream, level); if (r) return r;
+  int cnt = 0, nc = 0;
+  HIPCHK(hipMemcpyAsync(&cnt, sys->fr.nmax + stream * NLEV + level, sizeof(int), hipMemcpyDeviceToHost, sys->stream));
+  HIPCHK(hipMemcpyAsync(&nc, sys->fr.ncorners + stream * NLEV + level, sizeof(int), hipMemcpyDeviceToHost, sys->stream));
+  HIPCHK(hipStreamSynchronize(sys->stream));
+  if (n) *n = cnt;
+  const size_t off = (size_t)stream * sys->geom[level].cap;
+  if (corners && cnt > 0)
+    HIPCHK(hipMemcpyAsync(corners, sys->fr.maxcorners[level] + off, (size_t)(cnt < cap ? cnt : cap) * 4, hipMemcpyDeviceToHost, sys->stream));
+  if (scores && nc > 0)  // scores of ALL corners of the level (same order as vslam_read_corners)
+    HIPCHK(hipMemcpyAsync(scores, sys->fr.scores[level] + off, (size_t)(nc < cap ? nc : cap) * 4, hipMemcpyDeviceToHost, sys->stream));
+  HIPCHK(hipStreamSynchronize(sys->stream));
+  return VSLAM_OK;
+}
