@@ -16,14 +16,14 @@ void vslam_set_error(const char* fmt, ...) {
 extern "C" const char* vslam_last_error(void) { return g_err; }
 
 extern "C" int vslam_default_params(vslam_params* p, int width, int height, int n_streams) {
-  if (!p || width < 64 || height < 64 || n_streams < 1) { vslam_set_error("default_params: bad size"); return VSLAM_E_INVALID; }
+  if (!p || width < 48 || height < 48 || n_streams < 1) { vslam_set_error("default_params: bad size"); return VSLAM_E_INVALID; }
   memset(p, 0, sizeof(*p));
   p->width = width; p->height = height; p->n_streams = n_streams;
   p->fast_threshold[0] = 10; p->fast_threshold[1] = 15; p->fast_threshold[2] = 15; p->fast_threshold[3] = 10;
   p->nonmax_barrier = 10;
   p->patch_size = 11;
   for (int l = 0; l < NLEV; l++) {
-    const int n = ((width >> l) * (height >> l)) / 8;
+    const int n = ((width >> l) * (height >> l)) / 2;
     p->max_corners[l] = n < 256 ? 256 : n;
   }
   p->max_points = 4096;
@@ -61,7 +61,7 @@ static int dev_alloc(vslam_system* sys, T** out, size_t count) {
 
 extern "C" int vslam_create(const vslam_params* p, vslam_system** out) {
   if (!p || !out) { vslam_set_error("create: null argument"); return VSLAM_E_INVALID; }
-  if (p->width < 64 || p->height < 64 || p->width > 4096 || p->height > 4096 || p->n_streams < 1 ||
+  if (p->width < 48 || p->height < 48 || p->width > 4096 || p->height > 4096 || p->n_streams < 1 ||
       (p->patch_size != 8 && p->patch_size != 11)) {
     vslam_set_error("create: unsupported size %dx%d streams %d patch %d", p->width, p->height, p->n_streams, p->patch_size);
     return VSLAM_E_INVALID;
