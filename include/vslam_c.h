@@ -104,6 +104,90 @@ int vslam_read_row_lut(vslam_system* sys, int stream, int level, int* lut /* hei
 int vslam_read_max_corners(vslam_system* sys, int stream, int level, uint32_t* corners, int* scores,
                            int cap, int* n);
 
+/* ---- map (jni/Map.h:21-34) ---------------------------------------------------------------- */
+/* The reference fills its map through InitFromStereo / AddPointEpipolar (bootstrap and map growth: out of
+ * scope / "next" rows); the feeder supplies a ground-truth map through these instead. */
+
+/* KeyFrame (jni/KeyFrame.h:73-97): pose12 = R row-major (9) + t (3), camera-from-world; gray is host memory.
+ * Builds the keyframe's pyramid on device.  Returns the keyframe index (>= 0) or a negative error. */
+int vslam_map_add_keyframe(vslam_system* sys, int stream, const double pose12[12], int fixed, const uint8_t* gray,
+                           size_t row_stride, double depth_mean, double depth_sigma);
+/* MapPoint (jni/MapPoint.h:22-69). Returns the point index or a negative error. */
+int vslam_map_add_point(vslam_system* sys, int stream, const double pos[3], int src_keyframe, int src_level,
+                        int ir_x, int ir_y, const double pixel_right_w[3], const double pixel_down_w[3]);
+/* Measurement (jni/KeyFrame.h:46-51): source 0 TRACKER 1 REFIND 2 ROOT 3 TRAIL 4 EPIPOLAR */
+int vslam_map_add_measurement(vslam_system* sys, int stream, int keyframe, int point, int level,
+                              const double root_pos[2], int subpix, int source);
+/* the same for n measurements at once (arrays of n; root_pos 2n doubles) */
+int vslam_map_add_measurements(vslam_system* sys, int stream, int n, const int* keyframe, const int* point,
+                               const int* level, const double* root_pos, const int* subpix, const int* source);
+int vslam_map_set_good(vslam_system* sys, int stream);           /* Map::bGood (jni/Map.h:33) */
+int vslam_set_pose(vslam_system* sys, int stream, const double pose12[12]);
+int vslam_set_velocity(vslam_system* sys, int stream, const double v6[6]);
+
+/* ---- tracking ------------------------------------------------------------------------------ */
+
+typedef struct vslam_track_state {
+  double pose[12];                 /* Tracker::GetCurrentPose, jni/Tracker.h:58 */
+  double velocity[6];              /* mv6CameraVelocity */
+  double msd_velocity, depth_mean, depth_sigma;
+  int attempted[VSLAM_LEVELS], found[VSLAM_LEVELS];   /* manMeasAttempted / manMeasFound */
+  int quality;                     /* 0 BAD, 1 DODGY, 2 GOOD (jni/Tracker.h:123) */
+  int lost_frames, frame, did_coarse;
+  int kf_added, n_keyframes, n_points, ba_accepted;
+  long long n_zmssd, n_ba_trials;  /* counters: ZMSSD evaluations, LM trials */
+} vslam_track_state;
+
+/* Tracker::TrackFrame (jni/Tracker.cc:76-146) for one frame of every stream: MakeKeyFrame_Lite, motion
+ * model, TrackMap, quality assessment, and -- when the tracker asks for a keyframe -- MapMaker::AddKeyFrame
+ * (jni/MapMaker.cc:470-506) followed by one BundleAdjustRecent (jni/MapMaker.cc:801-851), all on device.
+ * Same image arguments as vslam_make_keyframe_lite.  Asynchronous. */
+int vslam_track_frame(vslam_system* sys, const uint8_t* gray, size_t row_stride, size_t stream_stride,
+                      int on_device);
+/* the JNI-equivalent per-frame entry: native_update (jni/jni_part.cpp:132-145): host gray image of stream 0..n-1,
+ * synchronous; native_touchScreen (:120-124) has no effect once a map exists and is accepted for ABI parity. */
+int vslam_update(vslam_system* sys, const uint8_t* gray, size_t row_stride, size_t stream_stride);
+int vslam_touch(vslam_system* sys);
+
+int vslam_get_state(vslam_system* sys, int stream, vslam_track_state* out);
+/* Tracker::GetMessageForUser (jni/Tracker.cc:880-883): "Tracking Map, quality good. Found: a/b ... Map: nP, nKF" */
+int vslam_get_message(vslam_system* sys, int stream, char* buf, size_t cap);
+/* per map point of a stream (arrays of n_points): TrackerData::bFound/bSearched/nSearchLevel/bDidSubPix,
+ * v2Found (L0), v2Image.  Any pointer may be NULL. Returns n_points. */
+int vslam_get_point_tracks(vslam_system* sys, int stream, int* found, int* searched, int* level, int* subpix,
+                           double* vfound, double* image, int cap);
+int vslam_get_points(vslam_system* sys, int stream, double* pos3, int* bad, int* n_inlier, int* n_outlier, int cap);
+int vslam_get_keyframe_pose(vslam_system* sys, int stream, int keyframe, double pose12[12]);
+int vslam_get_keyframe_measurements(vslam_system* sys, int stream, int keyframe, int* point, int* level,
+                                    double* root_pos, int* source, int cap);
+int vslam_get_template(vslam_system* sys, int stream, int point, uint8_t* tmpl /* P*P */, int* sum, int* sumsq,
+                       int* bad);
+
+/* ---- mapping ------------------------------------------------------------------------------- */
+/* MapMaker::BundleAdjustRecent / BundleAdjustAll (jni/MapMaker.cc:801-851, 776-798) on every stream, followed by
+ * HandleBadPoints (:140-164); what the reference's map-maker thread loop (:80-123) would run next. */
+int vslam_bundle_adjust_recent(vslam_system* sys);
+int vslam_bundle_adjust_all(vslam_system* sys);
+
+/* ---- stand-alone Bundle (jni/Bundle.h:111-121), batched: n_problems independent problems ---- */
+typedef struct vslam_bundle vslam_bundle;
+int vslam_bundle_create(const vslam_params* p, int n_problems, int max_cameras, int max_points, int max_meas,
+                        vslam_bundle** out);
+int vslam_bundle_destroy(vslam_bundle* b);
+int vslam_bundle_add_camera(vslam_bundle* b, int problem, const double pose12[12], int fixed);   /* Bundle::AddCamera */
+int vslam_bundle_add_point(vslam_bundle* b, int problem, const double pos[3]);                   /* Bundle::AddPoint  */
+int vslam_bundle_add_meas(vslam_bundle* b, int problem, int cam, int point, const double pos[2],
+                          double sigma_squared);                                                  /* Bundle::AddMeas   */
+/* Bundle::Compute for every problem (one launch); asynchronous. accepted[problem] read by _get_result. */
+int vslam_bundle_compute(vslam_bundle* b);
+int vslam_bundle_synchronize(vslam_bundle* b);
+int vslam_bundle_get_result(vslam_bundle* b, int problem, int* accepted, int* converged, double* sigma_squared,
+                            double* lambda, long long* trials);
+int vslam_bundle_get_camera(vslam_bundle* b, int problem, int n, double pose12[12]);             /* Bundle::GetCamera */
+int vslam_bundle_get_point(vslam_bundle* b, int problem, int n, double pos[3]);                  /* Bundle::GetPoint  */
+int vslam_bundle_get_outlier_meas(vslam_bundle* b, int problem, int* pc_pairs, int cap);         /* GetOutlierMeasurements */
+int vslam_bundle_get_outlier_points(vslam_bundle* b, int problem, int* idx, int cap);            /* GetOutliers */
+
 #ifdef __cplusplus
 }
 #endif

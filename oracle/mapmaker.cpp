@@ -1,0 +1,122 @@
+// ORACLE (test infrastructure only).  BA-driver part of jni/MapMaker.cc restated
+// (AddKeyFrame :470-506, KeyFrameLinearDist/NClosest/Closest :705-758, NeedNewKeyFrame :761-773,
+//  BundleAdjustAll :776-798, BundleAdjustRecent :801-851, BundleAdjust :854-960).
+// The reference orders its std::set<KeyFrame*> / std::map<MapPoint*,...> by heap address; the build defines the
+// order as insertion index.  The map-maker runs synchronously (the reference's thread is disabled,
+// jni/MapMaker.cc:56).  Map growth (ReFind*, AddSomeMapPoints) is a "next" row and not run here.
+#include "ptam_system.hpp"
+
+namespace orc {
+
+double System::KeyFrameLinearDist(const SE3& a, const SE3& b) {
+  // :705-712
+  const SE3 ia = inverse(a), ib = inverse(b);
+  const double d[3] = {ib.t[0] - ia.t[0], ib.t[1] - ia.t[1], ib.t[2] - ia.t[2]};
+  return sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+}
+
+bool System::NeedNewKeyFrame() {
+  // :761-773 with ClosestKeyFrame :737-758
+  double best = 9999999999.9;
+  for (auto k : kfs) { const double d = KeyFrameLinearDist(cur.pose, k->pose); if (d < best) best = d; }
+  double dDist = best;
+  dDist *= (1.0 / cur.depth_mean);
+  return dDist > p.max_kf_dist_wiggle_mult * wiggle_depth_norm;
+}
+
+void System::AddKeyFrame() {
+  // MapMaker::AddKeyFrame :470-478 (deep copy) + AddKeyFrameFromTopOfQueue :481-506 run inline
+  KeyFrame* pK = new KeyFrame(cur);
+  make_keyframe_rest_nonmax(*pK, p.nonmax_barrier, (p.quirks & ORC_Q_NONMAX_RIGHT_NEIGHBOUR) != 0);   // :488
+  kfs.push_back(pK);
+  const int kidx = (int)kfs.size() - 1;
+  for (auto& it : pK->meas) { pts[it.first]->meas_kfs.insert(kidx); it.second.source = SRC_TRACKER; }   // :491-494
+  // ReFindInSingleKeyFrame / AddSomeMapPoints: "next" rows
+  ba_converged_full = false; ba_converged_recent = false;                                                   // :504-505
+  // MapMaker::run :98-99: local bundle adjustment takes priority once the queue is empty
+  last_ba_accepted = BundleAdjustRecent();
+  HandleBadPoints();                                                                                          // run() :117
+}
+
+void System::HandleBadPoints() {
+  // :140-164.  Bad points stay in the arrays flagged `bad` (the reference moves them to a trash list, jni/Map.cc:16-27).
+  for (auto q : pts) if (q->n_outlier > 20 && q->n_outlier > q->n_inlier) q->bad = true;
+  for (size_t i = 0; i < pts.size(); i++) if (pts[i]->bad) for (auto k : kfs) k->meas.erase((int)i);
+}
+
+int System::BundleAdjustAll() {
+  // :776-798
+  std::vector<int> adj, fixed, points;
+  for (size_t i = 0; i < kfs.size(); i++) (kfs[i]->fixed ? fixed : adj).push_back((int)i);
+  for (size_t i = 0; i < pts.size(); i++) if (!pts[i]->bad) points.push_back((int)i);
+  return BundleAdjust(adj, fixed, points, false);
+}
+
+int System::BundleAdjustRecent() {
+  // :801-851
+  if ((int)kfs.size() < p.ba_min_keyframes) { ba_converged_recent = true; return -2; }
+  std::set<int> sAdjust;
+  const int newest = (int)kfs.size() - 1;
+  sAdjust.insert(newest);
+  std::vector<std::pair<double, int>> v;                                  // NClosestKeyFrames :714-735
+  for (int i = 0; i < (int)kfs.size(); i++) if (i != newest) v.push_back(std::make_pair(KeyFrameLinearDist(kfs[newest]->pose, kfs[i]->pose), i));
+  unsigned N = p.ba_window - 1;
+  if (N > v.size()) N = v.size();
+  std::partial_sort(v.begin(), v.begin() + N, v.end());
+  for (unsigned i = 0; i < N; i++) if (!kfs[v[i].second]->fixed) sAdjust.insert(v[i].second);
+  std::set<int> sPoints;
+  for (int k : sAdjust) for (auto& it : kfs[k]->meas) sPoints.insert(it.first);
+  std::vector<int> fixed;
+  for (int i = 0; i < (int)kfs.size(); i++) {
+    if (sAdjust.count(i)) continue;
+    bool inc = false;
+    for (auto& it : kfs[i]->meas) if (sPoints.count(it.first)) { inc = true; break; }
+    if (inc) fixed.push_back(i);
+  }
+  return BundleAdjust(std::vector<int>(sAdjust.begin(), sAdjust.end()), fixed, std::vector<int>(sPoints.begin(), sPoints.end()), true);
+}
+
+int System::BundleAdjust(const std::vector<int>& adj, const std::vector<int>& fixed, const std::vector<int>& points, bool recent) {
+  // :854-960
+  Bundle b;
+  b.camera = camera;
+  b.max_iterations = p.ba_max_iterations; b.convergence_limit = p.ba_convergence_limit; b.min_sigma = p.ba_min_tukey_sigma;
+  std::map<int, int> view_id, point_id;
+  std::vector<int> id_view, id_point;
+  for (int k : adj) { view_id[k] = b.AddCamera(kfs[k]->pose, kfs[k]->fixed); id_view.push_back(k); }
+  for (int k : fixed) { view_id[k] = b.AddCamera(kfs[k]->pose, true); id_view.push_back(k); }
+  for (int q : points) { point_id[q] = b.AddPoint(pts[q]->pos); id_point.push_back(q); }
+  for (int k = 0; k < (int)kfs.size(); k++) {                                                      // :888-902
+    if (!view_id.count(k)) continue;
+    for (auto& it : kfs[k]->meas) {
+      if (!point_id.count(it.first)) continue;
+      const int s = level_scale(it.second.level);
+      b.AddMeas(view_id[k], point_id[it.first], it.second.root, (double)(s * s));
+    }
+  }
+  abort_flag = false;
+  const int nAccepted = b.Compute(&abort_flag);
+  n_ba_trials += b.n_trials;
+  if (nAccepted < 0) return nAccepted;   // reference: mbResetRequested (:913); here surfaced to the caller
+  if (nAccepted > 0) {                   // :918-929
+    for (auto& it : point_id) pts[it.first]->pos = b.pts[it.second].pos;
+    for (auto& it : view_id) kfs[it.first]->pose = b.cams[it.second].pose;
+    if (recent) ba_converged_recent = false;
+    ba_converged_full = false;
+  }
+  if (b.converged) { ba_converged_recent = true; if (!recent) ba_converged_full = true; }   // :931-935
+  for (auto& pc : b.outlier_meas) {                                                                 // :941-959
+    const int pp = id_point[pc.first], pk = id_view[pc.second];
+    Measurement& m = kfs[pk]->meas[pp];
+    if ((int)pts[pp]->meas_kfs.size() <= 2 || m.source == SRC_ROOT) pts[pp]->bad = true;
+    else {
+      if (m.source == SRC_TRACKER || m.source == SRC_EPIPOLAR) failure_queue.push_back(std::make_pair(pk, pp));
+      else pts[pp]->never_retry.insert(pk);
+      kfs[pk]->meas.erase(pp);
+      pts[pp]->meas_kfs.erase(pk);
+    }
+  }
+  return nAccepted;
+}
+
+}  // namespace orc

@@ -1,0 +1,341 @@
+// ORACLE (test infrastructure only -- see ptam_oracle.h).  Math substrate restatement:
+// SO3/SE3 (jni/RT.h), ATAN/FOV camera (jni/ATANCamera.{h,cc}), M-estimators (jni/MEstimator.h),
+// WLS accumulator (jni/myWLS.h), small dense linear algebra standing in for Eigen
+// (Eigen 3 is an un-vendored dependency of the reference: linear-solve round-off is "parity unpinned").
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace orc {
+
+struct V2 { double x, y; };
+struct V3 { double v[3]; double& operator[](int i) { return v[i]; } double operator[](int i) const { return v[i]; } };
+
+inline V3 v3(double a, double b, double c) { V3 r; r.v[0] = a; r.v[1] = b; r.v[2] = c; return r; }
+inline V3 operator+(const V3& a, const V3& b) { return v3(a[0] + b[0], a[1] + b[1], a[2] + b[2]); }
+inline V3 operator-(const V3& a, const V3& b) { return v3(a[0] - b[0], a[1] - b[1], a[2] - b[2]); }
+inline V3 operator*(const V3& a, double s) { return v3(a[0] * s, a[1] * s, a[2] * s); }
+inline double dot(const V3& a, const V3& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+inline V3 cross(const V3& a, const V3& b) {
+  return v3(a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]);
+}
+
+// ---- SE3: R row-major 3x3, t ------------------------------------------------------------------
+struct SE3 {
+  double R[9];
+  double t[3];
+  SE3() { for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0 : 0.0; t[0] = t[1] = t[2] = 0; }
+};
+
+inline V3 rot(const SE3& T, const V3& p) {
+  return v3(T.R[0] * p[0] + T.R[1] * p[1] + T.R[2] * p[2], T.R[3] * p[0] + T.R[4] * p[1] + T.R[5] * p[2],
+            T.R[6] * p[0] + T.R[7] * p[1] + T.R[8] * p[2]);
+}
+inline V3 rot_inv(const SE3& T, const V3& p) {  // R^T p
+  return v3(T.R[0] * p[0] + T.R[3] * p[1] + T.R[6] * p[2], T.R[1] * p[0] + T.R[4] * p[1] + T.R[7] * p[2],
+            T.R[2] * p[0] + T.R[5] * p[1] + T.R[8] * p[2]);
+}
+// jni/RT.h:492-499: lhs * v = t + R v
+inline V3 xform(const SE3& T, const V3& p) { V3 r = rot(T, p); return v3(T.t[0] + r[0], T.t[1] + r[1], T.t[2] + r[2]); }
+
+// jni/RT.h:286-295
+inline SE3 mul(const SE3& a, const SE3& b) {
+  SE3 r;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      r.R[i * 3 + j] = a.R[i * 3 + 0] * b.R[0 * 3 + j] + a.R[i * 3 + 1] * b.R[1 * 3 + j] + a.R[i * 3 + 2] * b.R[2 * 3 + j];
+  V3 rt = rot(a, v3(b.t[0], b.t[1], b.t[2]));
+  for (int i = 0; i < 3; i++) r.t[i] = a.t[i] + rt[i];
+  return r;
+}
+// jni/RT.h:274-282
+inline SE3 inverse(const SE3& a) {
+  SE3 r;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.R[i * 3 + j] = a.R[j * 3 + i];
+  V3 rt = rot(r, v3(a.t[0], a.t[1], a.t[2]));
+  for (int i = 0; i < 3; i++) r.t[i] = -rt[i];
+  return r;
+}
+
+// jni/RT.h:98-129 rodrigues_so3_exp
+inline void rodrigues(const double w[3], double A, double B, double R[9]) {
+  const double wx2 = w[0] * w[0], wy2 = w[1] * w[1], wz2 = w[2] * w[2];
+  R[0] = 1.0 - B * (wy2 + wz2); R[4] = 1.0 - B * (wx2 + wz2); R[8] = 1.0 - B * (wx2 + wy2);
+  { const double a = A * w[2], b = B * (w[0] * w[1]); R[1] = b - a; R[3] = b + a; }
+  { const double a = A * w[1], b = B * (w[0] * w[2]); R[2] = b + a; R[6] = b - a; }
+  { const double a = A * w[0], b = B * (w[1] * w[2]); R[5] = b - a; R[7] = b + a; }
+}
+
+// jni/RT.h:134-165 mySO3::exp
+inline void so3_exp(const double w[3], double R[9]) {
+  const double one_6th = 1.0 / 6.0, one_20th = 1.0 / 20.0;
+  const double theta_sq = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  const double theta = sqrt(theta_sq);
+  double A, B;
+  if (theta_sq < 1e-8) { A = 1.0 - one_6th * theta_sq; B = 0.5; }
+  else if (theta_sq < 1e-6) { B = 0.5 - 0.25 * one_6th * theta_sq; A = 1.0 - theta_sq * one_6th * (1.0 - one_20th * theta_sq); }
+  else { const double inv_theta = 1.0 / theta; A = sin(theta) * inv_theta; B = (1 - cos(theta)) * (inv_theta * inv_theta); }
+  rodrigues(w, A, B, R);
+}
+
+// jni/RT.h:167-214 mySO3::ln
+inline V3 so3_ln(const double M[9]) {
+  V3 result;
+  const double cos_angle = (M[0] + M[4] + M[8] - 1.0) * 0.5;
+  result[0] = (M[7] - M[5]) / 2; result[1] = (M[2] - M[6]) / 2; result[2] = (M[3] - M[1]) / 2;
+  double sin_angle_abs = sqrt(dot(result, result));
+  if (cos_angle > M_SQRT1_2) {
+    if (sin_angle_abs > 0) result = result * (asin(sin_angle_abs) / sin_angle_abs);
+  } else if (cos_angle > -M_SQRT1_2) {
+    const double angle = acos(cos_angle);
+    result = result * (angle / sin_angle_abs);
+  } else {
+    const double angle = M_PI - asin(sin_angle_abs);
+    const double d0 = M[0] - cos_angle, d1 = M[4] - cos_angle, d2 = M[8] - cos_angle;
+    V3 r2;
+    if (d0 * d0 > d1 * d1 && d0 * d0 > d2 * d2) { r2[0] = d0; r2[1] = (M[3] + M[1]) / 2; r2[2] = (M[2] + M[6]) / 2; }
+    else if (d1 * d1 > d2 * d2) { r2[0] = (M[3] + M[1]) / 2; r2[1] = d1; r2[2] = (M[7] + M[5]) / 2; }
+    else { r2[0] = (M[2] + M[6]) / 2; r2[1] = (M[7] + M[5]) / 2; r2[2] = d2; }
+    if (dot(r2, result) < 0) r2 = r2 * -1.0;
+    const double nrm = sqrt(dot(r2, r2));
+    r2 = r2 * (1.0 / nrm);   // Eigen normalize(): v /= norm
+    result = r2 * angle;
+  }
+  return result;
+}
+
+// jni/RT.h:318-352 mySE3::exp, mu = (translation[3], rotation[3])
+inline SE3 se3_exp(const double mu[6]) {
+  const double one_6th = 1.0 / 6.0, one_20th = 1.0 / 20.0;
+  SE3 result;
+  const double w[3] = {mu[3], mu[4], mu[5]};
+  const double theta_sq = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  const double theta = sqrt(theta_sq);
+  double A, B;
+  const V3 W = v3(w[0], w[1], w[2]), U = v3(mu[0], mu[1], mu[2]);
+  const V3 cr = cross(W, U);
+  if (theta_sq < 1e-8) {
+    A = 1.0 - one_6th * theta_sq; B = 0.5;
+    for (int i = 0; i < 3; i++) result.t[i] = U[i] + 0.5 * cr[i];
+  } else {
+    double C;
+    if (theta_sq < 1e-6) { C = one_6th * (1.0 - one_20th * theta_sq); A = 1.0 - theta_sq * C; B = 0.5 - 0.25 * one_6th * theta_sq; }
+    else { const double inv_theta = 1.0 / theta; A = sin(theta) * inv_theta; B = (1 - cos(theta)) * (inv_theta * inv_theta); C = (1 - A) * (inv_theta * inv_theta); }
+    const V3 wc = cross(W, cr);
+    for (int i = 0; i < 3; i++) result.t[i] = U[i] + B * cr[i] + C * wc[i];
+  }
+  rodrigues(w, A, B, result.R);
+  return result;
+}
+
+// jni/RT.h:354-383 mySE3::ln
+inline void se3_ln(const SE3& T, double out[6]) {
+  V3 rotv = so3_ln(T.R);
+  const double theta = sqrt(dot(rotv, rotv));
+  double shtot = 0.5;
+  if (theta > 0.00001) shtot = sin(theta / 2) / theta;
+  const double half[3] = {rotv[0] * -0.5, rotv[1] * -0.5, rotv[2] * -0.5};
+  SE3 hr; so3_exp(half, hr.R);
+  const V3 tr = v3(T.t[0], T.t[1], T.t[2]);
+  V3 rottrans = rot(hr, tr);
+  if (theta > 0.001) rottrans = rottrans - rotv * ((dot(tr, rotv)) * (1 - 2 * shtot) / (dot(rotv, rotv)));
+  else rottrans = rottrans - rotv * ((dot(tr, rotv)) / 24);
+  rottrans = rottrans * (1.0 / (2 * shtot));   // Eigen 3.0-3.2 "v /= s" multiplies by 1/s
+  out[0] = rottrans[0]; out[1] = rottrans[1]; out[2] = rottrans[2];
+  out[3] = rotv[0]; out[4] = rotv[1]; out[5] = rotv[2];
+}
+
+// jni/RT.h:297-308 generator_field(i, pos) with pos = (x, y, z, 1)
+inline void generator_field(int i, const double pos[4], double out[4]) {
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (i < 3) { out[i] = pos[3]; return; }
+  out[(i + 1) % 3] = -pos[(i + 2) % 3];
+  out[(i + 2) % 3] = pos[(i + 1) % 3];
+}
+
+// ---- ATAN / FOV camera ---------------------------------------------------------------------------
+// Pure-function restatement of the stateful jni/ATANCamera.{h,cc}: project() returns everything
+// GetProjectionDerivs_Eigen would read from the cached members.
+struct Camera {
+  double params[5];
+  double size[2];
+  double focal[2], center[2], inv_focal[2];
+  double w, winv, two_tan, one_over_2tan, distortion_enabled;
+  double largest_radius, max_r;
+
+  // jni/ATANCamera.h:145-150
+  double invrtrans(double r) const { if (w == 0.0) return r; return tan(r * w) * one_over_2tan; }
+  // jni/ATANCamera.h:136-142
+  double rtrans_factor(double r) const { if (r < 0.001 || w == 0.0) return 1.0; return winv * atan(r * two_tan) / r; }
+
+  // jni/ATANCamera.cc:6-29 + SetImageSize :31-35 + RefreshParams :37-82
+  void init(const double p[5], double width, double height, bool quirk_int_radius) {
+    for (int i = 0; i < 5; i++) params[i] = p[i];
+    size[0] = width; size[1] = height;
+    focal[0] = size[0] * params[0]; focal[1] = size[1] * params[1];
+    center[0] = size[0] * params[2] - 0.5; center[1] = size[1] * params[3] - 0.5;
+    inv_focal[0] = 1.0 / focal[0]; inv_focal[1] = 1.0 / focal[1];
+    w = params[4];
+    if (w != 0.0) { two_tan = 2.0 * tan(w / 2.0); one_over_2tan = 1.0 / two_tan; winv = 1.0 / w; distortion_enabled = 1.0; }
+    else { winv = 0.0; two_tan = 0.0; one_over_2tan = 0.0; distortion_enabled = 0.0; }
+    double v2[2];
+    if (quirk_int_radius) {  // :70-78 stores the operands in int -> both 0 (quirk #5)
+      int m1 = (int)params[2]; int m2 = (int)(1.0 - params[2]);
+      v2[0] = std::max(m1, m2) / params[0];
+      m1 = (int)params[3]; m2 = (int)(1.0 - params[3]);
+      v2[1] = std::max(m1, m2) / params[1];
+    } else {                 // PTAM-intended
+      v2[0] = std::max(params[2], 1.0 - params[2]) / params[0];
+      v2[1] = std::max(params[3], 1.0 - params[3]) / params[1];
+    }
+    largest_radius = invrtrans(sqrt(v2[0] * v2[0] + v2[1] * v2[1]));
+    max_r = 1.5 * largest_radius;  // :82
+  }
+
+  struct Proj { double im[2]; double cam[2]; double r; double factor; bool invalid; };
+
+  // jni/ATANCamera.cc:133-145 Project
+  Proj project(double cx, double cy) const {
+    Proj p;
+    p.cam[0] = cx; p.cam[1] = cy;
+    p.r = sqrt(cx * cx + cy * cy);
+    p.invalid = (p.r > max_r);
+    p.factor = rtrans_factor(p.r);
+    p.im[0] = center[0] + focal[0] * (cx * p.factor);
+    p.im[1] = center[1] + focal[1] * (cy * p.factor);
+    return p;
+  }
+
+  // jni/ATANCamera.cc:198-231 GetProjectionDerivs_Eigen; d = [d00 d01; d10 d11] row-major
+  void derivs(const Proj& p, double d[4]) const {
+    double dFracBydx, dFracBydy;
+    const double k = two_tan, x = p.cam[0], y = p.cam[1];
+    const double r = p.r * distortion_enabled;
+    if (r < 0.01) { dFracBydx = 0.0; dFracBydy = 0.0; }
+    else {
+      dFracBydx = winv * (k * x) / (r * r * (1 + k * k * r * r)) - x * p.factor / (r * r);
+      dFracBydy = winv * (k * y) / (r * r * (1 + k * k * r * r)) - y * p.factor / (r * r);
+    }
+    d[0] = focal[0] * (dFracBydx * x + p.factor);
+    d[2] = focal[1] * (dFracBydx * y);
+    d[1] = focal[0] * (dFracBydy * x);
+    d[3] = focal[1] * (dFracBydy * y + p.factor);
+  }
+
+  // jni/ATANCamera.cc:149-164 UnProject
+  void unproject(double ix, double iy, double out[2]) const {
+    const double dx = (ix - center[0]) * inv_focal[0], dy = (iy - center[1]) * inv_focal[1];
+    const double dist_r = sqrt(dx * dx + dy * dy);
+    const double r = invrtrans(dist_r);
+    double f;
+    if (dist_r > 0.01) f = r / dist_r; else f = 1.0;
+    out[0] = dx * f; out[1] = dy * f;
+  }
+};
+
+// ---- M-estimators (jni/MEstimator.h) -----------------------------------------------------------------
+enum { EST_TUKEY = 0, EST_CAUCHY = 1, EST_HUBER = 2, EST_LSQ = 3 };
+
+inline double find_sigma_squared(int est, std::vector<double>& v) {  // sorts in place like the reference (:67-77)
+  if (est == EST_LSQ) {
+    if (v.empty()) return 0.0;
+    double s = 0; for (double x : v) s += x; return s / v.size();
+  }
+  std::sort(v.begin(), v.end());
+  const double med = v[v.size() / 2];
+  double sigma = 1.4826 * (1 + 5.0 / (v.size() * 2 - 6)) * sqrt(med);   // size_t arithmetic as in the reference
+  sigma = (est == EST_HUBER ? 1.345 : 4.6851) * sigma;
+  return sigma * sigma;
+}
+inline double sqrt_weight(int est, double e2, double s2) {
+  switch (est) {
+    case EST_TUKEY: return e2 > s2 ? 0.0 : 1.0 - (e2 / s2);
+    case EST_CAUCHY: return sqrt(1.0 / (1.0 + e2 / s2));
+    case EST_HUBER: return sqrt(e2 < s2 ? 1.0 : sqrt(s2 / e2));
+    default: return 1.0;
+  }
+}
+inline double weight(int est, double e2, double s2) {
+  switch (est) {
+    case EST_TUKEY: { const double d = sqrt_weight(est, e2, s2); return d * d; }
+    case EST_CAUCHY: return 1.0 / (1.0 + e2 / s2);
+    case EST_HUBER: return e2 < s2 ? 1.0 : sqrt(s2 / e2);
+    default: return 1.0;
+  }
+}
+inline double objective(int est, double e2, double s2) {
+  switch (est) {
+    case EST_TUKEY: { if (e2 > s2) return 1.0; const double d = 1.0 - e2 / s2; return 1.0 - d * d * d; }
+    case EST_CAUCHY: return log(1.0 + e2 / s2);
+    case EST_HUBER: { if (e2 < s2) return 0.5 * e2; const double s = sqrt(s2), e = sqrt(e2); return s * (e - 0.5 * s); }
+    default: return e2;
+  }
+}
+
+// ---- dense solve standing in for Eigen's  A.inverse() * b  (PartialPivLU) -----------------------------
+// In-place Gaussian elimination with partial pivoting; A is n x n row-major (destroyed), b -> x.
+inline bool lu_solve(double* A, double* b, int n) {
+  for (int k = 0; k < n; k++) {
+    int piv = k; double best = fabs(A[k * n + k]);
+    for (int r = k + 1; r < n; r++) if (fabs(A[r * n + k]) > best) { best = fabs(A[r * n + k]); piv = r; }
+    if (best == 0.0) return false;
+    if (piv != k) { for (int c = 0; c < n; c++) std::swap(A[k * n + c], A[piv * n + c]); std::swap(b[k], b[piv]); }
+    const double inv = 1.0 / A[k * n + k];
+    for (int r = k + 1; r < n; r++) {
+      const double f = A[r * n + k] * inv;
+      if (f == 0.0) continue;
+      for (int c = k + 1; c < n; c++) A[r * n + c] -= f * A[k * n + c];
+      b[r] -= f * b[k];
+    }
+  }
+  for (int k = n - 1; k >= 0; k--) {
+    double s = b[k];
+    for (int c = k + 1; c < n; c++) s -= A[k * n + c] * b[c];
+    b[k] = s / A[k * n + k];
+  }
+  return true;
+}
+
+// 3x3 inverse by cofactors (Eigen's fixed-size 3x3 inverse); m row-major
+inline void inv3(const double m[9], double o[9]) {
+  const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+  const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+  const double id = 1.0 / det;
+  o[0] = c00 * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+  o[3] = c01 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+  o[6] = c02 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+inline void inv2(const double m[4], double o[4]) {
+  const double id = 1.0 / (m[0] * m[3] - m[1] * m[2]);
+  o[0] = m[3] * id; o[1] = -m[1] * id; o[2] = -m[2] * id; o[3] = m[0] * id;
+}
+
+// ---- myWLS<6> (jni/myWLS.h) ------------------------------------------------------------------------------
+struct WLS6 {
+  double C[36]; double v[6];
+  WLS6() { memset(C, 0, sizeof(C)); memset(v, 0, sizeof(v)); }
+  void add_prior(double val) { for (int i = 0; i < 6; i++) C[i * 6 + i] += val; }          // :33-37
+  void add_mJ(double m, const double J[6], double weight) {                                // :39-50
+    for (int r = 0; r < 6; r++) {
+      const double Jw = weight * J[r];
+      v[r] += m * Jw;
+      for (int c = r; c < 6; c++) C[r * 6 + c] += Jw * J[c];
+    }
+  }
+  void compute(double mu[6]) {                                                             // :54-62
+    for (int r = 1; r < 6; r++) for (int c = 0; c < r; c++) C[r * 6 + c] = C[c * 6 + r];
+    double A[36], b[6];
+    memcpy(A, C, sizeof(A)); memcpy(b, v, sizeof(b));
+    if (!lu_solve(A, b, 6)) memset(b, 0, sizeof(b));
+    memcpy(mu, b, sizeof(b));
+  }
+};
+
+// jni/LevelHelpers.h
+inline int level_scale(int l) { return 1 << l; }
+inline double level_zero_pos(double p, int l) { return (p + 0.5) * level_scale(l) - 0.5; }
+inline double level_n_pos(double p, int l) { return (p + 0.5) / level_scale(l) - 0.5; }
+
+}  // namespace orc

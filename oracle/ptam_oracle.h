@@ -68,6 +68,73 @@ int orc_make_keyframe_lite(const uint8_t* gray, int w, int h, int stride, const 
                            uint8_t* const lvl_img[ORC_LEVELS], uint32_t* const corners[ORC_LEVELS],
                            int cap, int ncorners[ORC_LEVELS], int* const lut[ORC_LEVELS]);
 
+/* ---- whole-path oracle: one sequence (stream) ------------------------------------------------ */
+
+typedef struct orc_params {           /* mirrors the hot-path fields of vslam_params */
+  int width, height, patch_size;
+  int thr[4]; int nonmax_barrier;
+  int max_patches; int coarse_min, coarse_max, coarse_range, coarse_subpix_its, coarse_disabled;
+  double coarse_min_vel; int fine_subpix_its; double wls_prior;
+  int min_frames_between_kf; double max_kf_dist_wiggle_mult, wiggle_scale;
+  int ba_max_iterations; double ba_convergence_limit, ba_min_tukey_sigma; int ba_window, ba_min_keyframes;
+  double cam[5]; int quirks;
+} orc_params;
+
+typedef struct orc_track_state {      /* same fields as vslam_track_state */
+  double pose[12];                    /* R row-major (9) + t (3): camera-from-world, jni/Tracker.h:58 */
+  double velocity[6];
+  double msd_velocity, depth_mean, depth_sigma;
+  int attempted[4], found[4];         /* manMeasAttempted/Found, jni/Tracker.h:121-122 */
+  int quality, lost_frames, frame, did_coarse;
+  int kf_added, n_keyframes, n_points, ba_accepted;
+  long long n_zmssd, n_ba_trials;
+} orc_track_state;
+
+void* orc_sys_create(const orc_params* p);
+void orc_sys_destroy(void* sys);
+int orc_sys_add_keyframe(void* sys, const double pose12[12], int fixed, const uint8_t* gray, int stride, double dmean, double dsigma);
+int orc_sys_add_point(void* sys, const double pos[3], int src_kf, int src_level, int irx, int iry, const double right[3], const double down[3]);
+void orc_sys_add_meas(void* sys, int kf, int pt, int level, const double root[2], int subpix, int source);
+void orc_sys_set_map_good(void* sys);
+void orc_sys_set_pose(void* sys, const double pose12[12]);
+void orc_sys_set_velocity(void* sys, const double v6[6]);
+void orc_sys_track_frame(void* sys, const uint8_t* gray, int stride);   /* Tracker::TrackFrame, jni/Tracker.cc:76-146 */
+void orc_sys_get_state(void* sys, orc_track_state* out);
+/* per map point: found flag, searched flag, search level, did-subpix, found position (L0), projected position */
+int orc_sys_get_point_tracks(void* sys, int* found, int* searched, int* level, int* subpix, double* vfound, double* image, int cap);
+int orc_sys_get_points(void* sys, double* pos3, int* bad, int* n_in, int* n_out, int cap);
+void orc_sys_get_keyframe_pose(void* sys, int kf, double pose12[12]);
+int orc_sys_get_keyframe_meas(void* sys, int kf, int* pt, int* level, double* root, int* source, int cap);
+int orc_sys_get_template(void* sys, int pt, uint8_t* tmpl, int* sum, int* sumsq, int* bad);
+int orc_sys_bundle_adjust_recent(void* sys);   /* MapMaker::BundleAdjustRecent, jni/MapMaker.cc:801-851 */
+int orc_sys_bundle_adjust_all(void* sys);      /* MapMaker::BundleAdjustAll,    jni/MapMaker.cc:776-798 */
+
+/* ---- stand-alone Bundle (jni/Bundle.h:111-121) --------------------------------------------------- */
+void* orc_ba_create(const double cam5[5], int width, int height, int quirks, int max_iterations, double convergence_limit, double min_sigma);
+void orc_ba_destroy(void* ba);
+int orc_ba_add_camera(void* ba, const double pose12[12], int fixed);
+int orc_ba_add_point(void* ba, const double pos[3]);
+void orc_ba_add_meas(void* ba, int cam, int point, const double pos[2], double sigma_squared);
+int orc_ba_compute(void* ba);                  /* Bundle::Compute: accepted iterations or <0 */
+void orc_ba_get_camera(void* ba, int n, double pose12[12]);
+void orc_ba_get_point(void* ba, int n, double pos[3]);
+int orc_ba_converged(void* ba);
+int orc_ba_get_outlier_meas(void* ba, int* pc_pairs, int cap);   /* (p, c) pairs */
+int orc_ba_get_outlier_points(void* ba, int* idx, int cap);
+void orc_ba_get_stats(void* ba, double* sigma2, double* lambda, long long* trials);
+
+/* ---- substrate unit functions -------------------------------------------------------------------- */
+void orc_se3_exp(const double mu[6], double pose12[12]);
+void orc_se3_ln(const double pose12[12], double mu[6]);
+void orc_cam_project(const double cam5[5], int w, int h, int quirks, double cx, double cy, double im[2], double derivs[4], int* invalid, double* largest_radius);
+void orc_cam_unproject(const double cam5[5], int w, int h, double ix, double iy, double out[2]);
+double orc_find_sigma_squared(int est, const double* v, int n);
+double orc_weight(int est, double e2, double s2);
+double orc_sqrt_weight(int est, double e2, double s2);
+double orc_objective(int est, double e2, double s2);
+int orc_transform_image(const uint8_t* in, int iw, int ih, int istride, uint8_t* out, int P, const double M[4], const double inOrig[2], const double outOrig[2]);
+int orc_zmssd(const uint8_t* tmpl, int P, const uint8_t* img, int w, int h, int stride, int icol, int irow);
+
 #ifdef __cplusplus
 }
 #endif

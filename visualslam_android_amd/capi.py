@@ -33,26 +33,65 @@ class Params(C.Structure):
     ]
 
 
+class TrackState(C.Structure):
+    """Mirror of struct vslam_track_state."""
+    _fields_ = [("pose", C.c_double * 12), ("velocity", C.c_double * 6), ("msd_velocity", C.c_double),
+                ("depth_mean", C.c_double), ("depth_sigma", C.c_double), ("attempted", C.c_int * 4), ("found", C.c_int * 4),
+                ("quality", C.c_int), ("lost_frames", C.c_int), ("frame", C.c_int), ("did_coarse", C.c_int),
+                ("kf_added", C.c_int), ("n_keyframes", C.c_int), ("n_points", C.c_int), ("ba_accepted", C.c_int),
+                ("n_zmssd", C.c_longlong), ("n_ba_trials", C.c_longlong)]
+
+
 _lib = None
 
 # name -> (restype, argtypes); every symbol include/vslam_c.h declares
-_u8p = C.POINTER(C.c_uint8)
-_u32p = C.POINTER(C.c_uint32)
 _ip = C.POINTER(C.c_int)
-_dp = C.POINTER(C.c_double)
 _sys = C.c_void_p
+_vp = C.c_void_p
+_i, _d, _sz = C.c_int, C.c_double, C.c_size_t
 SYMBOLS = {
     "vslam_last_error": (C.c_char_p, []),
-    "vslam_default_params": (C.c_int, [C.POINTER(Params), C.c_int, C.c_int, C.c_int]),
-    "vslam_create": (C.c_int, [C.POINTER(Params), C.POINTER(_sys)]),
-    "vslam_destroy": (C.c_int, [_sys]),
-    "vslam_synchronize": (C.c_int, [_sys]),
-    "vslam_make_keyframe_lite": (C.c_int, [_sys, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]),
-    "vslam_fast_nonmax": (C.c_int, [_sys]),
-    "vslam_read_level_image": (C.c_int, [_sys, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
-    "vslam_read_corners": (C.c_int, [_sys, C.c_int, C.c_int, C.c_void_p, C.c_int, _ip]),
-    "vslam_read_row_lut": (C.c_int, [_sys, C.c_int, C.c_int, C.c_void_p]),
-    "vslam_read_max_corners": (C.c_int, [_sys, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, _ip]),
+    "vslam_default_params": (_i, [C.POINTER(Params), _i, _i, _i]),
+    "vslam_create": (_i, [C.POINTER(Params), C.POINTER(_sys)]),
+    "vslam_destroy": (_i, [_sys]),
+    "vslam_synchronize": (_i, [_sys]),
+    "vslam_make_keyframe_lite": (_i, [_sys, _vp, _sz, _sz, _i]),
+    "vslam_fast_nonmax": (_i, [_sys]),
+    "vslam_read_level_image": (_i, [_sys, _i, _i, _vp, _sz]),
+    "vslam_read_corners": (_i, [_sys, _i, _i, _vp, _i, _ip]),
+    "vslam_read_row_lut": (_i, [_sys, _i, _i, _vp]),
+    "vslam_read_max_corners": (_i, [_sys, _i, _i, _vp, _vp, _i, _ip]),
+    "vslam_map_add_keyframe": (_i, [_sys, _i, _vp, _i, _vp, _sz, _d, _d]),
+    "vslam_map_add_point": (_i, [_sys, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "vslam_map_add_measurement": (_i, [_sys, _i, _i, _i, _i, _vp, _i, _i]),
+    "vslam_map_add_measurements": (_i, [_sys, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vslam_map_set_good": (_i, [_sys, _i]),
+    "vslam_set_pose": (_i, [_sys, _i, _vp]),
+    "vslam_set_velocity": (_i, [_sys, _i, _vp]),
+    "vslam_track_frame": (_i, [_sys, _vp, _sz, _sz, _i]),
+    "vslam_update": (_i, [_sys, _vp, _sz, _sz]),
+    "vslam_touch": (_i, [_sys]),
+    "vslam_get_state": (_i, [_sys, _i, C.POINTER(TrackState)]),
+    "vslam_get_message": (_i, [_sys, _i, C.c_char_p, _sz]),
+    "vslam_get_point_tracks": (_i, [_sys, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
+    "vslam_get_points": (_i, [_sys, _i, _vp, _vp, _vp, _vp, _i]),
+    "vslam_get_keyframe_pose": (_i, [_sys, _i, _i, _vp]),
+    "vslam_get_keyframe_measurements": (_i, [_sys, _i, _i, _vp, _vp, _vp, _vp, _i]),
+    "vslam_get_template": (_i, [_sys, _i, _i, _vp, _ip, _ip, _ip]),
+    "vslam_bundle_adjust_recent": (_i, [_sys]),
+    "vslam_bundle_adjust_all": (_i, [_sys]),
+    "vslam_bundle_create": (_i, [C.POINTER(Params), _i, _i, _i, _i, C.POINTER(_vp)]),
+    "vslam_bundle_destroy": (_i, [_vp]),
+    "vslam_bundle_add_camera": (_i, [_vp, _i, _vp, _i]),
+    "vslam_bundle_add_point": (_i, [_vp, _i, _vp]),
+    "vslam_bundle_add_meas": (_i, [_vp, _i, _i, _i, _vp, _d]),
+    "vslam_bundle_compute": (_i, [_vp]),
+    "vslam_bundle_synchronize": (_i, [_vp]),
+    "vslam_bundle_get_result": (_i, [_vp, _i, _ip, _ip, C.POINTER(_d), C.POINTER(_d), C.POINTER(C.c_longlong)]),
+    "vslam_bundle_get_camera": (_i, [_vp, _i, _i, _vp]),
+    "vslam_bundle_get_point": (_i, [_vp, _i, _i, _vp]),
+    "vslam_bundle_get_outlier_meas": (_i, [_vp, _i, _vp, _i]),
+    "vslam_bundle_get_outlier_points": (_i, [_vp, _i, _vp, _i]),
 }
 
 
@@ -75,8 +114,9 @@ def load_library(path=None):
 
 
 def _check(rc):
-    if rc != 0:
+    if rc < 0:
         raise VslamError("vslam error %d: %s" % (rc, load_library().vslam_last_error().decode()))
+    return rc
 
 
 def default_params(width, height, n_streams=1, **overrides):
@@ -90,6 +130,10 @@ def default_params(width, height, n_streams=1, **overrides):
         else:
             setattr(p, k, v)
     return p
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, np.float64)
 
 
 class System:
@@ -120,12 +164,16 @@ class System:
         return self.params.height >> level, self.params.width >> level
 
     # ---- front-end ---------------------------------------------------------------------------
-    def make_keyframe_lite(self, gray):
-        """gray: uint8 array [S, H, W] (host).  KeyFrame::MakeKeyFrame_Lite for all streams."""
+    def _frames(self, gray):
         g = np.ascontiguousarray(gray, dtype=np.uint8)
         if g.ndim == 2:
             g = g[None]
         assert g.shape == (self.S, self.params.height, self.params.width), g.shape
+        return g
+
+    def make_keyframe_lite(self, gray):
+        """gray: uint8 array [S, H, W] (host).  KeyFrame::MakeKeyFrame_Lite for all streams."""
+        g = self._frames(gray)
         _check(self.lib.vslam_make_keyframe_lite(self.h, g.ctypes.data, g.shape[2], g.shape[1] * g.shape[2], 0))
         self.synchronize()  # the host buffer is only borrowed for the call
 
@@ -161,3 +209,162 @@ class System:
         n = C.c_int(0)
         _check(self.lib.vslam_read_max_corners(self.h, stream, level, out.ctypes.data, sc.ctypes.data, cap, C.byref(n)))
         return out[:n.value].copy(), sc
+
+    # ---- map ---------------------------------------------------------------------------------
+    def add_keyframe(self, stream, pose12, fixed, gray, dmean, dsigma):
+        g = np.ascontiguousarray(gray, np.uint8)
+        return _check(self.lib.vslam_map_add_keyframe(self.h, stream, _f64(pose12).ctypes.data, int(fixed), g.ctypes.data, g.shape[1], dmean, dsigma))
+
+    def add_point(self, stream, pos, src_kf, level, irx, iry, right, down):
+        return _check(self.lib.vslam_map_add_point(self.h, stream, _f64(pos).ctypes.data, src_kf, level, irx, iry,
+                                                   _f64(right).ctypes.data, _f64(down).ctypes.data))
+
+    def load_map(self, stream, m):
+        """m: dict from visualslam_android_amd.feeder.build_map"""
+        for k in m["keyframes"]:
+            self.add_keyframe(stream, k["pose"], k["fixed"], k["image"], k["depth_mean"], k["depth_sigma"])
+        for q in m["points"]:
+            self.add_point(stream, q["pos"], q["src_kf"], q["level"], q["irx"], q["iry"], q["right"], q["down"])
+        ms = m["meas"]
+        n = len(ms)
+        kf = np.array([x[0] for x in ms], np.int32); pt = np.array([x[1] for x in ms], np.int32)
+        lv = np.array([x[2] for x in ms], np.int32); root = np.array([[x[3], x[4]] for x in ms], np.float64)
+        sp = np.array([x[5] for x in ms], np.int32); src = np.array([x[6] for x in ms], np.int32)
+        _check(self.lib.vslam_map_add_measurements(self.h, stream, n, kf.ctypes.data, pt.ctypes.data, lv.ctypes.data,
+                                                   root.ctypes.data, sp.ctypes.data, src.ctypes.data))
+        _check(self.lib.vslam_map_set_good(self.h, stream))
+
+    def set_pose(self, stream, pose12):
+        _check(self.lib.vslam_set_pose(self.h, stream, _f64(pose12).ctypes.data))
+
+    def set_velocity(self, stream, v6):
+        _check(self.lib.vslam_set_velocity(self.h, stream, _f64(v6).ctypes.data))
+
+    # ---- tracking ----------------------------------------------------------------------------
+    def track_frame(self, gray):
+        """Tracker::TrackFrame on host frames [S, H, W]; synchronous (vslam_update)."""
+        g = self._frames(gray)
+        _check(self.lib.vslam_update(self.h, g.ctypes.data, g.shape[2], g.shape[1] * g.shape[2]))
+
+    def track_frame_device(self, dev_ptr, row_stride, stream_stride):
+        _check(self.lib.vslam_track_frame(self.h, dev_ptr, row_stride, stream_stride, 1))
+
+    def state(self, stream):
+        s = TrackState()
+        _check(self.lib.vslam_get_state(self.h, stream, C.byref(s)))
+        return s
+
+    def message(self, stream):
+        buf = C.create_string_buffer(512)
+        _check(self.lib.vslam_get_message(self.h, stream, buf, 512))
+        return buf.value.decode()
+
+    def point_tracks(self, stream):
+        n = self.state(stream).n_points
+        found, searched, level, subpix = (np.zeros(n, np.int32) for _ in range(4))
+        vfound, image = np.zeros((n, 2)), np.zeros((n, 2))
+        _check(self.lib.vslam_get_point_tracks(self.h, stream, found.ctypes.data, searched.ctypes.data, level.ctypes.data,
+                                               subpix.ctypes.data, vfound.ctypes.data, image.ctypes.data, n))
+        return {"found": found, "searched": searched, "level": level, "subpix": subpix, "vfound": vfound, "image": image}
+
+    def points(self, stream):
+        n = self.state(stream).n_points
+        pos = np.zeros((n, 3)); bad, nin, nout = (np.zeros(n, np.int32) for _ in range(3))
+        _check(self.lib.vslam_get_points(self.h, stream, pos.ctypes.data, bad.ctypes.data, nin.ctypes.data, nout.ctypes.data, n))
+        return {"pos": pos, "bad": bad, "n_in": nin, "n_out": nout}
+
+    def keyframe_pose(self, stream, kf):
+        p = np.zeros(12)
+        _check(self.lib.vslam_get_keyframe_pose(self.h, stream, kf, p.ctypes.data))
+        return p
+
+    def keyframe_meas(self, stream, kf, cap=8192):
+        pt, level, source = (np.zeros(cap, np.int32) for _ in range(3))
+        root = np.zeros((cap, 2))
+        n = _check(self.lib.vslam_get_keyframe_measurements(self.h, stream, kf, pt.ctypes.data, level.ctypes.data, root.ctypes.data, source.ctypes.data, cap))
+        return {"pt": pt[:n], "level": level[:n], "root": root[:n], "source": source[:n]}
+
+    def template(self, stream, pt):
+        P = self.params.patch_size
+        t = np.zeros(P * P, np.uint8)
+        s, sq, bad = C.c_int(0), C.c_int(0), C.c_int(0)
+        have = _check(self.lib.vslam_get_template(self.h, stream, pt, t.ctypes.data, C.byref(s), C.byref(sq), C.byref(bad)))
+        return {"tmpl": t.reshape(P, P), "sum": s.value, "sumsq": sq.value, "bad": bad.value, "have": have}
+
+    def bundle_adjust_recent(self):
+        _check(self.lib.vslam_bundle_adjust_recent(self.h))
+        self.synchronize()
+
+    def bundle_adjust_all(self):
+        _check(self.lib.vslam_bundle_adjust_all(self.h))
+        self.synchronize()
+
+
+class Bundle:
+    """Batched stand-alone Bundle (jni/Bundle.h:111-121): n_problems independent problems, one launch."""
+
+    def __init__(self, params, n_problems=1, max_cameras=16, max_points=2048, max_meas=32768):
+        self.lib = load_library()
+        self.h = _vp()
+        _check(self.lib.vslam_bundle_create(C.byref(params), n_problems, max_cameras, max_points, max_meas, C.byref(self.h)))
+        self.n = n_problems
+        self.ncam = [0] * n_problems
+        self.npt = [0] * n_problems
+
+    def close(self):
+        if self.h:
+            self.lib.vslam_bundle_destroy(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_camera(self, pose12, fixed, problem=0):
+        self.ncam[problem] += 1
+        return _check(self.lib.vslam_bundle_add_camera(self.h, problem, _f64(pose12).ctypes.data, int(fixed)))
+
+    def add_point(self, pos, problem=0):
+        self.npt[problem] += 1
+        return _check(self.lib.vslam_bundle_add_point(self.h, problem, _f64(pos).ctypes.data))
+
+    def add_meas(self, cam, pt, pos2, sigma2, problem=0):
+        _check(self.lib.vslam_bundle_add_meas(self.h, problem, cam, pt, _f64(pos2).ctypes.data, float(sigma2)))
+
+    def compute(self, sync=True):
+        _check(self.lib.vslam_bundle_compute(self.h))
+        if sync:
+            _check(self.lib.vslam_bundle_synchronize(self.h))
+
+    def synchronize(self):
+        _check(self.lib.vslam_bundle_synchronize(self.h))
+
+    def result(self, problem=0):
+        acc, conv = C.c_int(0), C.c_int(0)
+        s2, lam, tr = C.c_double(0), C.c_double(0), C.c_longlong(0)
+        _check(self.lib.vslam_bundle_get_result(self.h, problem, C.byref(acc), C.byref(conv), C.byref(s2), C.byref(lam), C.byref(tr)))
+        return {"accepted": acc.value, "converged": bool(conv.value), "sigma2": s2.value, "lambda": lam.value, "trials": tr.value}
+
+    def cameras(self, problem=0):
+        out = np.zeros((self.ncam[problem], 12))
+        for i in range(self.ncam[problem]):
+            _check(self.lib.vslam_bundle_get_camera(self.h, problem, i, out[i].ctypes.data))
+        return out
+
+    def points(self, problem=0):
+        out = np.zeros((self.npt[problem], 3))
+        for i in range(self.npt[problem]):
+            _check(self.lib.vslam_bundle_get_point(self.h, problem, i, out[i].ctypes.data))
+        return out
+
+    def outlier_meas(self, problem=0, cap=65536):
+        a = np.zeros((cap, 2), np.int32)
+        n = _check(self.lib.vslam_bundle_get_outlier_meas(self.h, problem, a.ctypes.data, cap))
+        return a[:n]
+
+    def outlier_points(self, problem=0, cap=65536):
+        a = np.zeros(cap, np.int32)
+        n = _check(self.lib.vslam_bundle_get_outlier_points(self.h, problem, a.ctypes.data, cap))
+        return a[:n]

@@ -1,0 +1,511 @@
+// Mapping side of the hot path on device:
+//   * vslam_bundle_*  : stand-alone, batched Bundle (jni/Bundle.h:111-121), one persistent workgroup per problem
+//   * MapMaker::AddKeyFrame (jni/MapMaker.cc:470-506) + BundleAdjustRecent/All (:776-851) + BundleAdjust (:854-960)
+//     + HandleBadPoints (:140-164) for every stream of a system, driven by the tracker's device-side decision
+//     (kf_pending) -- no host synchronisation between TrackFrame and the local bundle adjustment.
+#include "vslam_internal.h"
+#include "ba_device.h"
+#include <string.h>
+
+struct BaPool {            // device arrays for N problems
+  int N, max_cams, max_pts, max_meas, max_free;
+  BaResult* res;
+  Pose* cam_pose; Pose* cam_new; int* cam_fixed; int* cam_row; double* cam_U; double* cam_ea;
+  double* pt_pos; double* pt_new; double* pt_V; double* pt_eb; double* pt_Vinv; int* pt_nmeas; int* pt_nout;
+  int* ms_p; int* ms_c; int* ms_state; double* ms_found; double* ms_sin; double* ms_cam; double* ms_eps; double* ms_err2;
+  double* ms_derivs; double* ms_A; double* ms_B; double* ms_W;
+  int* lut; double* S; double* E; double* cam_up; double* map_up; double* scratch; int* outl; int* free_cams;
+  int* id_view; int* id_point;   // BundleAdjust translation tables (:861-864)
+};
+
+__host__ __device__ inline BaView ba_view(const BaPool& b, int n) {
+  BaView v;
+  const size_t C = b.max_cams, P = b.max_pts, M = b.max_meas, F = (size_t)b.max_free * 6;
+  v.max_cams = b.max_cams; v.max_pts = b.max_pts; v.max_meas = b.max_meas;
+  v.res = b.res + n;
+  v.cam_pose = b.cam_pose + n * C; v.cam_new = b.cam_new + n * C; v.cam_fixed = b.cam_fixed + n * C; v.cam_row = b.cam_row + n * C;
+  v.cam_U = b.cam_U + n * C * 36; v.cam_ea = b.cam_ea + n * C * 6;
+  v.pt_pos = b.pt_pos + n * P * 3; v.pt_new = b.pt_new + n * P * 3; v.pt_V = b.pt_V + n * P * 9; v.pt_eb = b.pt_eb + n * P * 3;
+  v.pt_Vinv = b.pt_Vinv + n * P * 9; v.pt_nmeas = b.pt_nmeas + n * P; v.pt_nout = b.pt_nout + n * P;
+  v.ms_p = b.ms_p + n * M; v.ms_c = b.ms_c + n * M; v.ms_state = b.ms_state + n * M; v.ms_found = b.ms_found + n * M * 2;
+  v.ms_sin = b.ms_sin + n * M; v.ms_cam = b.ms_cam + n * M * 3; v.ms_eps = b.ms_eps + n * M * 2; v.ms_err2 = b.ms_err2 + n * M;
+  v.ms_derivs = b.ms_derivs + n * M * 4; v.ms_A = b.ms_A + n * M * 12; v.ms_B = b.ms_B + n * M * 6; v.ms_W = b.ms_W + n * M * 18;
+  v.lut = b.lut + n * C * P; v.S = b.S + n * F * F; v.E = b.E + n * F; v.cam_up = b.cam_up + n * F; v.map_up = b.map_up + n * P * 3;
+  v.scratch = b.scratch + n * M; v.outl = b.outl + n * M * 2; v.free_cams = b.free_cams + n * C;
+  return v;
+}
+
+__global__ __launch_bounds__(BA_THREADS) void k_ba_compute(BaPool pool, BaConfig cfg) {
+  const BaView v = ba_view(pool, blockIdx.x);
+  if (!v.res->active) return;
+  ba_compute(v, cfg);
+}
+
+template <class T>
+static int pool_alloc(std::vector<void*>& allocs, hipStream_t st, T** out, size_t count) {
+  void* ptr = nullptr;
+  HIPCHK(hipMalloc(&ptr, count * sizeof(T) + 64));
+  HIPCHK(hipMemsetAsync(ptr, 0, count * sizeof(T) + 64, st));
+  allocs.push_back(ptr);
+  *out = (T*)ptr;
+  return VSLAM_OK;
+}
+#define PALLOC(field, count) do { int _r = pool_alloc(allocs, st, &b.field, (count)); if (_r) return _r; } while (0)
+
+static int pool_create(BaPool& b, std::vector<void*>& allocs, hipStream_t st, int N, int max_cams, int max_pts, int max_meas) {
+  b.N = N; b.max_cams = max_cams; b.max_pts = max_pts; b.max_meas = max_meas; b.max_free = max_cams;
+  const size_t n = N, C = max_cams, P = max_pts, M = max_meas, F = (size_t)max_cams * 6;
+  PALLOC(res, n);
+  PALLOC(cam_pose, n * C); PALLOC(cam_new, n * C); PALLOC(cam_fixed, n * C); PALLOC(cam_row, n * C); PALLOC(cam_U, n * C * 36); PALLOC(cam_ea, n * C * 6);
+  PALLOC(pt_pos, n * P * 3); PALLOC(pt_new, n * P * 3); PALLOC(pt_V, n * P * 9); PALLOC(pt_eb, n * P * 3); PALLOC(pt_Vinv, n * P * 9);
+  PALLOC(pt_nmeas, n * P); PALLOC(pt_nout, n * P);
+  PALLOC(ms_p, n * M); PALLOC(ms_c, n * M); PALLOC(ms_state, n * M); PALLOC(ms_found, n * M * 2); PALLOC(ms_sin, n * M); PALLOC(ms_cam, n * M * 3);
+  PALLOC(ms_eps, n * M * 2); PALLOC(ms_err2, n * M); PALLOC(ms_derivs, n * M * 4); PALLOC(ms_A, n * M * 12); PALLOC(ms_B, n * M * 6); PALLOC(ms_W, n * M * 18);
+  PALLOC(lut, n * C * P); PALLOC(S, n * F * F); PALLOC(E, n * F); PALLOC(cam_up, n * F); PALLOC(map_up, n * P * 3);
+  PALLOC(scratch, n * M); PALLOC(outl, n * M * 2); PALLOC(free_cams, n * C); PALLOC(id_view, n * C); PALLOC(id_point, n * P);
+  return VSLAM_OK;
+}
+
+static BaConfig make_cfg(const TrackParams& tp) {
+  BaConfig c; c.cam = tp.cam; c.max_iterations = tp.ba_max_iterations; c.convergence_limit = tp.ba_convergence_limit; c.min_sigma2 = tp.ba_min_sigma2;
+  return c;
+}
+
+// =================================================================================================================
+// stand-alone batched Bundle
+// =================================================================================================================
+struct HostProblem { std::vector<Pose> cams; std::vector<int> fixed; std::vector<double> pts; std::vector<int> mp, mc; std::vector<double> mfound, msin; };
+
+struct vslam_bundle {
+  BaPool pool; std::vector<void*> allocs; hipStream_t stream; BaConfig cfg; TrackParams tp;
+  std::vector<HostProblem> host; bool uploaded;
+};
+
+
+
+extern "C" int vslam_bundle_create(const vslam_params* p, int n_problems, int max_cameras, int max_points, int max_meas, vslam_bundle** out) {
+  if (!p || !out || n_problems < 1 || max_cameras < 1 || max_points < 1 || max_meas < 1) { vslam_set_error("bundle_create: bad argument"); return VSLAM_E_INVALID; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { vslam_set_error("bundle_create: no HIP device visible (no CPU fallback)"); return VSLAM_E_HIP; }
+  HIPCHK(hipSetDevice(p->device));
+  vslam_bundle* b = new vslam_bundle();
+  b->uploaded = false;
+  HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  trk_fill_params(*p, b->tp);
+  b->cfg = make_cfg(b->tp);
+  int r = pool_create(b->pool, b->allocs, b->stream, n_problems, max_cameras, max_points, max_meas);
+  if (r) { vslam_bundle_destroy(b); return r; }
+  b->host.resize(n_problems);
+  HIPCHK(hipStreamSynchronize(b->stream));
+  *out = b;
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_bundle_destroy(vslam_bundle* b) {
+  if (!b) return VSLAM_OK;
+  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  for (void* p : b->allocs) (void)hipFree(p);
+  if (b->stream) (void)hipStreamDestroy(b->stream);
+  delete b;
+  return VSLAM_OK;
+}
+
+#define BCHECK(cond, msg) do { if (!(cond)) { vslam_set_error("bundle: %s", msg); return VSLAM_E_INVALID; } } while (0)
+
+extern "C" int vslam_bundle_add_camera(vslam_bundle* b, int n, const double pose12[12], int fixed) {
+  BCHECK(b && n >= 0 && n < b->pool.N && pose12, "bad camera argument");
+  HostProblem& h = b->host[n];
+  if ((int)h.cams.size() >= b->pool.max_cams) { vslam_set_error("bundle: camera capacity"); return VSLAM_E_CAPACITY; }
+  Pose p; for (int i = 0; i < 9; i++) p.R[i] = pose12[i]; for (int i = 0; i < 3; i++) p.t[i] = pose12[9 + i];
+  h.cams.push_back(p); h.fixed.push_back(fixed ? 1 : 0);
+  return (int)h.cams.size() - 1;
+}
+
+extern "C" int vslam_bundle_add_point(vslam_bundle* b, int n, const double pos[3]) {
+  BCHECK(b && n >= 0 && n < b->pool.N && pos, "bad point argument");
+  HostProblem& h = b->host[n];
+  if ((int)h.pts.size() / 3 >= b->pool.max_pts) { vslam_set_error("bundle: point capacity"); return VSLAM_E_CAPACITY; }
+  double q[3] = {pos[0], pos[1], pos[2]};
+  if (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] != q[0] * q[0] + q[1] * q[1] + q[2] * q[2]) q[0] = q[1] = q[2] = 0;   // NaN guard, jni/Bundle.cc:93-96
+  h.pts.insert(h.pts.end(), q, q + 3);
+  return (int)h.pts.size() / 3 - 1;
+}
+
+extern "C" int vslam_bundle_add_meas(vslam_bundle* b, int n, int cam, int point, const double pos[2], double sigma_squared) {
+  BCHECK(b && n >= 0 && n < b->pool.N && pos, "bad measurement argument");
+  HostProblem& h = b->host[n];
+  BCHECK(cam >= 0 && cam < (int)h.cams.size() && point >= 0 && point < (int)h.pts.size() / 3, "measurement refers to an unknown camera/point");   // asserts :107-108
+  if ((int)h.mp.size() >= b->pool.max_meas) { vslam_set_error("bundle: measurement capacity"); return VSLAM_E_CAPACITY; }
+  h.mp.push_back(point); h.mc.push_back(cam); h.mfound.push_back(pos[0]); h.mfound.push_back(pos[1]);
+  h.msin.push_back(sqrt(1.0 / sigma_squared));   // :115
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_bundle_compute(vslam_bundle* b) {
+  BCHECK(b, "null");
+  const BaPool& P = b->pool;
+  for (int n = 0; n < P.N; n++) {
+    const HostProblem& h = b->host[n];
+    BaView v = ba_view(P, n);
+    BaResult r; memset(&r, 0, sizeof(r));
+    r.n_cams = (int)h.cams.size(); r.n_pts = (int)h.pts.size() / 3; r.n_meas = (int)h.mp.size();
+    r.active = r.n_cams > 0 && r.n_pts > 0 && r.n_meas > 0;
+    HIPCHK(hipMemcpyAsync(v.res, &r, sizeof(r), hipMemcpyHostToDevice, b->stream));
+    if (!r.active) continue;
+    HIPCHK(hipMemcpyAsync(v.cam_pose, h.cams.data(), sizeof(Pose) * r.n_cams, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(v.cam_fixed, h.fixed.data(), sizeof(int) * r.n_cams, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(v.pt_pos, h.pts.data(), sizeof(double) * 3 * r.n_pts, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(v.ms_p, h.mp.data(), sizeof(int) * r.n_meas, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(v.ms_c, h.mc.data(), sizeof(int) * r.n_meas, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(v.ms_found, h.mfound.data(), sizeof(double) * 2 * r.n_meas, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(v.ms_sin, h.msin.data(), sizeof(double) * r.n_meas, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemsetAsync(v.ms_state, 0, sizeof(int) * r.n_meas, b->stream));
+    HIPCHK(hipMemsetAsync(v.pt_nout, 0, sizeof(int) * r.n_pts, b->stream));
+    std::vector<int> lut((size_t)P.max_cams * P.max_pts, -1), nmeas(r.n_pts, 0);
+    for (int i = 0; i < r.n_meas; i++) { lut[(size_t)h.mc[i] * P.max_pts + h.mp[i]] = i; nmeas[h.mp[i]]++; }   // GenerateMeasLUTs
+    HIPCHK(hipMemcpyAsync(v.lut, lut.data(), sizeof(int) * lut.size(), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(v.pt_nmeas, nmeas.data(), sizeof(int) * r.n_pts, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));   // host vectors go out of scope
+  }
+  b->uploaded = true;
+  hipLaunchKernelGGL(k_ba_compute, dim3(P.N), dim3(BA_THREADS), 0, b->stream, b->pool, b->cfg);
+  HIPCHK(hipGetLastError());
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_bundle_synchronize(vslam_bundle* b) { BCHECK(b, "null"); HIPCHK(hipStreamSynchronize(b->stream)); return VSLAM_OK; }
+
+static int bundle_result(vslam_bundle* b, int n, BaResult* r) {
+  BCHECK(b && n >= 0 && n < b->pool.N, "bad problem index");
+  if (!b->uploaded) { vslam_set_error("bundle: compute has not run"); return VSLAM_E_STATE; }
+  HIPCHK(hipMemcpyAsync(r, ba_view(b->pool, n).res, sizeof(BaResult), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_bundle_get_result(vslam_bundle* b, int n, int* accepted, int* converged, double* sigma_squared, double* lambda, long long* trials) {
+  BaResult r; int rc = bundle_result(b, n, &r); if (rc) return rc;
+  if (accepted) *accepted = r.accepted; if (converged) *converged = r.converged; if (sigma_squared) *sigma_squared = r.sigma2;
+  if (lambda) *lambda = r.lambda; if (trials) *trials = r.trials;
+  return VSLAM_OK;
+}
+extern "C" int vslam_bundle_get_camera(vslam_bundle* b, int n, int i, double pose12[12]) {
+  BaResult r; int rc = bundle_result(b, n, &r); if (rc) return rc;
+  BCHECK(i >= 0 && i < r.n_cams, "camera index");
+  Pose p;
+  HIPCHK(hipMemcpy(&p, ba_view(b->pool, n).cam_pose + i, sizeof(Pose), hipMemcpyDeviceToHost));
+  for (int k = 0; k < 9; k++) pose12[k] = p.R[k]; for (int k = 0; k < 3; k++) pose12[9 + k] = p.t[k];
+  return VSLAM_OK;
+}
+extern "C" int vslam_bundle_get_point(vslam_bundle* b, int n, int i, double pos[3]) {
+  BaResult r; int rc = bundle_result(b, n, &r); if (rc) return rc;
+  BCHECK(i >= 0 && i < r.n_pts, "point index");
+  HIPCHK(hipMemcpy(pos, ba_view(b->pool, n).pt_pos + 3 * i, sizeof(double) * 3, hipMemcpyDeviceToHost));
+  return VSLAM_OK;
+}
+extern "C" int vslam_bundle_get_outlier_meas(vslam_bundle* b, int n, int* pc, int cap) {
+  BaResult r; int rc = bundle_result(b, n, &r); if (rc) return rc;
+  const int m = r.n_outlier_meas < cap ? r.n_outlier_meas : cap;
+  if (pc && m > 0) HIPCHK(hipMemcpy(pc, ba_view(b->pool, n).outl, sizeof(int) * 2 * m, hipMemcpyDeviceToHost));
+  return r.n_outlier_meas;
+}
+extern "C" int vslam_bundle_get_outlier_points(vslam_bundle* b, int n, int* idx, int cap) {
+  BaResult r; int rc = bundle_result(b, n, &r); if (rc) return rc;
+  std::vector<int> nm(r.n_pts), no(r.n_pts);
+  if (r.n_pts) {
+    HIPCHK(hipMemcpy(nm.data(), ba_view(b->pool, n).pt_nmeas, sizeof(int) * r.n_pts, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(no.data(), ba_view(b->pool, n).pt_nout, sizeof(int) * r.n_pts, hipMemcpyDeviceToHost));
+  }
+  int cnt = 0;
+  for (int i = 0; i < r.n_pts; i++) if (nm[i] > 0 && nm[i] == no[i]) { if (idx && cnt < cap) idx[cnt] = i; cnt++; }   // GetOutliers :628-637
+  return cnt;
+}
+
+// =================================================================================================================
+// in-system mapping: AddKeyFrame + BundleAdjust on the streams' maps
+// =================================================================================================================
+struct KfCopyArgs {
+  const uint8_t* src[NLEV]; size_t src_sstride[NLEV]; int src_pitch[NLEV];
+  int w[NLEV], h[NLEV], kf_pitch[NLEV]; size_t kf_stride[NLEV];
+};
+
+// MapMaker::AddKeyFrame (:470-478): deep copy of the tracker's current keyframe into the next map slot.
+__global__ __launch_bounds__(256) void k_add_keyframe(MapDev m, TrackParams tp, KfCopyArgs a) {
+  const int s = blockIdx.y;
+  TrackerState* st = &m.st[s];
+  if (!st->kf_pending) return;
+  const int slot = st->n_kf;                         // n_kf is advanced by k_ba_assemble (next launch)
+  const int nth = gridDim.x * blockDim.x, tid = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int l = 0; l < NLEV; l++) {                   // Level::operator= copies pixels (jni/KeyFrame.cc:104-112)
+    const uint8_t* src = a.src[l] + (size_t)s * a.src_sstride[l];
+    uint8_t* dst = m.kf_img[l] + ((size_t)s * tp.max_keyframes + slot) * a.kf_stride[l];
+    const int w4 = a.w[l] >> 2;
+    if ((a.src_pitch[l] & 3) == 0 && (((uintptr_t)src) & 3) == 0) {
+      for (int t = tid; t < a.h[l] * w4; t += nth) {
+        const int y = t / w4, x = t - y * w4;
+        ((uint32_t*)(dst + (size_t)y * a.kf_pitch[l]))[x] = ((const uint32_t*)(src + (size_t)y * a.src_pitch[l]))[x];
+      }
+      const int rem = a.w[l] - (w4 << 2);
+      for (int t = tid; t < a.h[l] * rem; t += nth) { const int y = t / rem, x = (w4 << 2) + t % rem; dst[(size_t)y * a.kf_pitch[l] + x] = src[(size_t)y * a.src_pitch[l] + x]; }
+    } else {
+      for (int t = tid; t < a.h[l] * a.w[l]; t += nth) { const int y = t / a.w[l], x = t - y * a.w[l]; dst[(size_t)y * a.kf_pitch[l] + x] = src[(size_t)y * a.src_pitch[l] + x]; }
+    }
+  }
+  MeasDev* km = m.kf_meas + ((size_t)s * tp.max_keyframes + slot) * tp.max_points;
+  const MeasDev* cm = m.cur_meas + (size_t)s * tp.max_points;
+  MapPointDev* pts = m.pts + (size_t)s * tp.max_points;
+  for (int i = tid; i < st->n_points; i += nth) {    // mMeasurements copy + :491-494
+    MeasDev mm = cm[i];
+    if (mm.valid) { mm.source = 0; pts[i].n_meas_kfs++; }
+    km[i] = mm;
+  }
+  if (tid == 0) {
+    m.kf_pose[(size_t)s * tp.max_keyframes + slot] = st->pose_final;
+    m.kf_fixed[(size_t)s * tp.max_keyframes + slot] = 0;
+    m.kf_depth[((size_t)s * tp.max_keyframes + slot) * 2] = st->depth_mean;
+    m.kf_depth[((size_t)s * tp.max_keyframes + slot) * 2 + 1] = st->depth_sigma;
+  }
+}
+
+DEVFN double kfdist(const Pose& a, const Pose& b) {   // KeyFrameLinearDist :705-712
+  const Pose ia = pose_inverse(a), ib = pose_inverse(b);
+  const double d0 = ib.t[0] - ia.t[0], d1 = ib.t[1] - ia.t[1], d2 = ib.t[2] - ia.t[2];
+  return sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+}
+
+// mode 0: after AddKeyFrame (only streams with kf_pending) -> BundleAdjustRecent; 1: BundleAdjustRecent on every
+// stream; 2: BundleAdjustAll on every stream.  Builds the Bundle problem of BundleAdjust (:854-902) in the pool.
+__global__ __launch_bounds__(BA_THREADS) void k_ba_assemble(MapDev m, TrackParams tp, BaPool pool, int mode) {
+  const int s = blockIdx.x;
+  TrackerState* st = &m.st[s];
+  const BaView v = ba_view(pool, s);
+  BaResult* R = v.res;
+  __shared__ int sh_go, sh_nc, sh_nadj, sh_nm;
+  __shared__ int view_of_kf[64];      // kf index -> camera id or -1
+  __shared__ int ired[BA_WAVES];
+  __shared__ int kf_cnt[64], kf_off[64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int P = tp.max_points, K = tp.max_keyframes;
+  const Pose* kfp = m.kf_pose + (size_t)s * K;
+  const int* kff = m.kf_fixed + (size_t)s * K;
+  const MeasDev* kfm = m.kf_meas + (size_t)s * K * P;
+  if (threadIdx.x == 0) {
+    sh_go = 0;
+    R->active = 0;
+    if (mode == 0 && st->kf_pending) {
+      st->n_kf++;                                                       // mMap.vpKeyFrames.push_back (:489)
+      st->kf_added = 1;
+      st->ba_converged_full = 0; st->ba_converged_recent = 0;           // :504-505
+    }
+    const bool want = st->map_good && (mode != 0 || st->kf_pending);
+    const int nk = st->n_kf;
+    for (int k = 0; k < 64; k++) view_of_kf[k] = -1;
+    if (want && mode != 2) {
+      if (nk < tp.ba_min_keyframes) { st->ba_converged_recent = 1; st->ba_accepted = -2; }   // :803-807
+      else {
+        // adjust set: newest + (window-1) nearest non-fixed (:812-820), camera ids in keyframe order
+        const int newest = nk - 1;
+        int N = tp.ba_window - 1; if (N > nk - 1) N = nk - 1;
+        bool chosen[64];
+        for (int k = 0; k < nk; k++) chosen[k] = false;
+        chosen[newest] = true;
+        bool taken[64];
+        for (int k = 0; k < nk; k++) taken[k] = false;
+        for (int n = 0; n < N; n++) {                                   // partial_sort by (distance, index)
+          int best = -1; double bd = 0;
+          for (int k = 0; k < nk; k++) {
+            if (k == newest || taken[k]) continue;
+            const double d = kfdist(kfp[newest], kfp[k]);
+            if (best < 0 || d < bd) { best = k; bd = d; }
+          }
+          if (best < 0) break;
+          taken[best] = true;
+          if (!kff[best]) chosen[best] = true;
+        }
+        int c = 0;
+        for (int k = 0; k < nk; k++) if (chosen[k]) { view_of_kf[k] = c; v.cam_fixed[c] = kff[k]; v.cam_pose[c] = kfp[k]; pool.id_view[(size_t)s * pool.max_cams + c] = k; c++; }
+        sh_nadj = c; sh_go = 1;
+      }
+    } else if (want && mode == 2) {                                     // BundleAdjustAll :776-798
+      int c = 0;
+      for (int k = 0; k < nk; k++) if (!kff[k]) { view_of_kf[k] = c; v.cam_fixed[c] = 0; v.cam_pose[c] = kfp[k]; pool.id_view[(size_t)s * pool.max_cams + c] = k; c++; }
+      sh_nadj = c; sh_go = c > 0;
+    }
+  }
+  __syncthreads();
+  if (!sh_go) return;
+  const int nk = st->n_kf, npts = st->n_points, nadj = sh_nadj;
+  MapPointDev* pts = m.pts + (size_t)s * P;
+  // ---- point set (:823-831 / :791-795), ids in map order; id_point translation ----
+  int* idp = pool.id_point + (size_t)s * pool.max_pts;
+  int base = 0;
+  for (int i0 = 0; i0 < npts; i0 += BA_THREADS) {
+    const int i = i0 + threadIdx.x;
+    bool in = false;
+    if (i < npts) {
+      if (mode == 2) in = !pts[i].bad;
+      else for (int k = 0; k < nk && !in; k++) if (view_of_kf[k] >= 0 && kfm[(size_t)k * P + i].valid) in = true;
+    }
+    const unsigned long long bm = __ballot(in);
+    __syncthreads();
+    if (lane == 0) ired[wave] = __popcll(bm);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; w++) off += ired[w];
+    if (i < npts) {
+      int id = -1;
+      if (in) { id = off + __popcll(bm & ((1ull << lane) - 1ull)); if (id < pool.max_pts) { idp[id] = i; for (int q = 0; q < 3; q++) v.pt_pos[3 * id + q] = pts[i].pos[q]; v.pt_nmeas[id] = 0; v.pt_nout[id] = 0; } }
+      ((int*)v.scratch)[i] = id;                    // scratch viewed as int[npts]: map point -> bundle point id
+    }
+    for (int w = 0; w < BA_WAVES; w++) base += ired[w];
+  }
+  __syncthreads();
+  const int np = base;
+  const int* pid_of = (const int*)v.scratch;
+  // ---- fixed set (:834-848): other keyframes measuring any point of the set; appended in keyframe order ----
+  if (mode != 2) {
+    for (int k = 0; k < nk; k++) {
+      if (view_of_kf[k] >= 0) continue;
+      int any = 0;
+      for (int i = threadIdx.x; i < npts && !any; i += BA_THREADS) if (pid_of[i] >= 0 && kfm[(size_t)k * P + i].valid) any = 1;
+      any = __syncthreads_or(any);
+      if (any && threadIdx.x == 0) { kf_cnt[k] = 1; } else if (threadIdx.x == 0) kf_cnt[k] = 0;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int c = nadj;
+    for (int k = 0; k < nk; k++) {
+      const bool fixed_member = mode == 2 ? (kff[k] != 0) : (view_of_kf[k] < 0 && kf_cnt[k]);
+      if (fixed_member && c < pool.max_cams) { view_of_kf[k] = c; v.cam_fixed[c] = 1; v.cam_pose[c] = kfp[k]; pool.id_view[(size_t)s * pool.max_cams + c] = k; c++; }
+    }
+    sh_nc = c;
+  }
+  __syncthreads();
+  const int ncam = sh_nc;
+  for (int t = threadIdx.x; t < ncam * pool.max_pts; t += BA_THREADS) v.lut[(size_t)(t / pool.max_pts) * pool.max_pts + t % pool.max_pts] = -1;
+  // ---- measurements in map keyframe order, points ascending (:888-902) ----
+  for (int k = 0; k < nk; k++) {                                         // counts per keyframe
+    int c = 0;
+    if (view_of_kf[k] >= 0) for (int i = threadIdx.x; i < npts; i += BA_THREADS) if (pid_of[i] >= 0 && kfm[(size_t)k * P + i].valid) c++;
+    c = ba_block_sum_i(c, ired);
+    if (threadIdx.x == 0) kf_cnt[k] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { int o = 0; for (int k = 0; k < nk; k++) { kf_off[k] = o; o += kf_cnt[k]; } sh_nm = o; }
+  __syncthreads();
+  const int nm = sh_nm;
+  if (np > pool.max_pts || nm > pool.max_meas || ncam > pool.max_cams) { if (threadIdx.x == 0) { R->active = 0; st->ba_accepted = -3; } return; }
+  for (int k = 0; k < nk; k++) {
+    if (view_of_kf[k] < 0) continue;
+    const int cam = view_of_kf[k];
+    int kb = kf_off[k];
+    for (int i0 = 0; i0 < npts; i0 += BA_THREADS) {
+      const int i = i0 + threadIdx.x;
+      const bool in = i < npts && pid_of[i] >= 0 && kfm[(size_t)k * P + i].valid;
+      const unsigned long long bm = __ballot(in);
+      __syncthreads();
+      if (lane == 0) ired[wave] = __popcll(bm);
+      __syncthreads();
+      int off = kb;
+      for (int w = 0; w < wave; w++) off += ired[w];
+      if (in) {
+        off += __popcll(bm & ((1ull << lane) - 1ull));
+        const MeasDev mm = kfm[(size_t)k * P + i];
+        const int pid = pid_of[i];
+        v.ms_p[off] = pid; v.ms_c[off] = cam; v.ms_state[off] = MS_OK;
+        v.ms_found[2 * off] = mm.root[0]; v.ms_found[2 * off + 1] = mm.root[1];
+        const int sc = 1 << mm.level;
+        v.ms_sin[off] = sqrt(1.0 / (double)(sc * sc));                   // :899 + AddMeas :115
+        v.lut[(size_t)cam * pool.max_pts + pid] = off;
+        atomicAdd(&v.pt_nmeas[pid], 1);
+      }
+      for (int w = 0; w < BA_WAVES; w++) kb += ired[w];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { R->n_cams = ncam; R->n_pts = np; R->n_meas = nm; R->active = (ncam > 0 && np > 0 && nm > 0); R->accepted = 0; R->n_outlier_meas = 0; }
+}
+
+// BundleAdjust tail (:904-959) + HandleBadPoints (:140-164)
+__global__ __launch_bounds__(BA_THREADS) void k_ba_writeback(MapDev m, TrackParams tp, BaPool pool, int mode) {
+  const int s = blockIdx.x;
+  TrackerState* st = &m.st[s];
+  const BaView v = ba_view(pool, s);
+  BaResult* R = v.res;
+  const int P = tp.max_points, K = tp.max_keyframes;
+  MapPointDev* pts = m.pts + (size_t)s * P;
+  MeasDev* kfm = m.kf_meas + (size_t)s * K * P;
+  if (R->active) {
+    const int* idp = pool.id_point + (size_t)s * pool.max_pts;
+    const int* idv = pool.id_view + (size_t)s * pool.max_cams;
+    const int acc = R->accepted;
+    if (acc > 0) {                                                       // :918-929
+      for (int i = threadIdx.x; i < R->n_pts; i += BA_THREADS) for (int q = 0; q < 3; q++) pts[idp[i]].pos[q] = v.pt_pos[3 * i + q];
+      for (int c = threadIdx.x; c < R->n_cams; c += BA_THREADS) m.kf_pose[(size_t)s * K + idv[c]] = v.cam_pose[c];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      st->ba_accepted = acc;
+      st->n_ba_trials += (unsigned long long)R->trials;
+      if (acc >= 0) {
+        if (acc > 0) { if (mode != 2) st->ba_converged_recent = 0; st->ba_converged_full = 0; }
+        if (R->converged) { st->ba_converged_recent = 1; if (mode == 2) st->ba_converged_full = 1; }   // :931-935
+        for (int o = 0; o < R->n_outlier_meas; o++) {                    // :941-959, sequential like the reference
+          const int pp = idp[v.outl[2 * o]], pk = idv[v.outl[2 * o + 1]];
+          MeasDev& mm = kfm[(size_t)pk * P + pp];
+          if (pts[pp].n_meas_kfs <= 2 || mm.source == 2 /* SRC_ROOT */) pts[pp].bad = 1;
+          else { mm.valid = 0; pts[pp].n_meas_kfs--; }                   // failure queue / never-retry sets feed "next" rows only
+        }
+      }
+      R->active = 0;
+    }
+    __syncthreads();
+  }
+  if (!(st->map_good && (mode != 0 || st->kf_pending))) return;
+  // HandleBadPoints :140-164
+  const int nk = st->n_kf;
+  for (int i = threadIdx.x; i < st->n_points; i += BA_THREADS) {
+    if (pts[i].n_out > 20 && pts[i].n_out > pts[i].n_in) pts[i].bad = 1;
+    if (pts[i].bad) for (int k = 0; k < nk; k++) kfm[(size_t)k * P + i].valid = 0;
+  }
+}
+
+// ---- host ---------------------------------------------------------------------------------------------------------
+struct BaSystemWs { BaPool pool; };
+
+int ba_alloc(vslam_system* sys) {
+  BaSystemWs* ws = new BaSystemWs();
+  sys->ba_ws = ws;
+  const int K = sys->p.max_keyframes, P = sys->p.max_points;
+  if (K > 64) { vslam_set_error("max_keyframes > 64"); return VSLAM_E_INVALID; }
+  // worst case of BundleAdjust: every keyframe a camera, every point, every (kf, point) slot a measurement
+  size_t M = (size_t)K * P;
+  if (M > 65536) M = 65536;
+  return pool_create(ws->pool, sys->allocs, sys->stream, sys->S, K, P, (int)M);
+}
+
+static void fill_kfcopy(vslam_system* sys, KfCopyArgs& a) {
+  for (int l = 0; l < NLEV; l++) {
+    a.src[l] = sys->fr.img[l]; a.src_sstride[l] = sys->fr.img_sstride[l]; a.src_pitch[l] = sys->fr.img_pitch[l];
+    a.w[l] = sys->geom[l].w; a.h[l] = sys->geom[l].h; a.kf_pitch[l] = sys->geom[l].pitch;
+    a.kf_stride[l] = (size_t)sys->geom[l].pitch * sys->geom[l].h;
+  }
+}
+
+// mode 0: tracker-driven AddKeyFrame + BundleAdjustRecent; 1: BundleAdjustRecent; 2: BundleAdjustAll
+int ba_run(vslam_system* sys, int mode) {
+  BaSystemWs* ws = (BaSystemWs*)sys->ba_ws;
+  const BaConfig cfg = make_cfg(sys->tp);
+  if (mode == 0) {
+    KfCopyArgs a; fill_kfcopy(sys, a);
+    hipLaunchKernelGGL(k_add_keyframe, dim3(32, sys->S), dim3(256), 0, sys->stream, sys->map, sys->tp, a);
+  }
+  hipLaunchKernelGGL(k_ba_assemble, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, mode);
+  hipLaunchKernelGGL(k_ba_compute, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, ws->pool, cfg);
+  hipLaunchKernelGGL(k_ba_writeback, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, mode);
+  HIPCHK(hipGetLastError());
+  return VSLAM_OK;
+}
+
+int ba_add_keyframe_and_adjust(vslam_system* sys) { return ba_run(sys, 0); }

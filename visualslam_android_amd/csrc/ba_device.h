@@ -1,0 +1,438 @@
+// Bundle::Compute (jni/Bundle.cc:136-178) / Do_LM_Step (:202-532) as ONE persistent workgroup per problem:
+// the whole Levenberg-Marquardt loop runs inside one launch, no host round-trip.
+//
+// Data layout (per problem, struct-of-arrays in HBM, fp64):
+//   cameras: pose, trial pose, fixed flag, start row, U (6x6 lower), epsilon_a
+//   points : position, trial position, V (3x3 lower), epsilon_b, V*^-1
+//   measurements in AddMeas order: (p, c), found, sqrt-inv-noise, state, v3Cam, epsilon, A (2x6), B (2x3), W (6x3)
+//   lut[c][p] -> measurement index (GenerateMeasLUTs :566-575)
+// Reductions are deterministic: "segmented" per-camera / per-camera-pair sums are taken by one wavefront each
+// (lanes stride over the points, then __shfl_xor butterflies), per-point sums by one lane in camera order.
+#pragma once
+#include "dev_math.h"
+
+#define BA_THREADS 512
+#define BA_WAVES (BA_THREADS / 64)
+
+#define MS_OK 0
+#define MS_BAD 1      // bBad: z <= 0 or zero Tukey weight in this step
+#define MS_ERASED 2   // erased from the measurement list (:517-528)
+
+struct BaResult {
+  int active;           // 0: nothing to do for this problem
+  int n_cams, n_pts, n_meas, n_free;
+  int accepted;         // Compute() return value (negative on error)
+  int converged, hit_max;
+  int counter;          // mnCounter
+  int n_outlier_meas;
+  double sigma2, lambda, lambda_factor;
+  long long trials;
+};
+
+struct BaView {          // pointers already offset to one problem
+  int max_cams, max_pts, max_meas;
+  BaResult* res;
+  Pose* cam_pose; Pose* cam_new; int* cam_fixed; int* cam_row; double* cam_U; double* cam_ea;
+  double* pt_pos; double* pt_new; double* pt_V; double* pt_eb; double* pt_Vinv; int* pt_nmeas; int* pt_nout;
+  int* ms_p; int* ms_c; int* ms_state; double* ms_found; double* ms_sin; double* ms_cam; double* ms_eps; double* ms_err2;
+  double* ms_derivs; double* ms_A; double* ms_B; double* ms_W;
+  int* lut;              // [max_cams][max_pts]
+  double* S; double* E; double* cam_up; double* map_up;
+  double* scratch;       // [max_meas]
+  int* outl;             // [max_meas][2] (p, c) in erase order
+  int* free_cams;        // [max_cams] indices of the adjustable cameras
+};
+
+struct BaConfig { CamModel cam; int max_iterations; double convergence_limit, min_sigma2; };
+
+DEVFN double ba_wave_sum(double v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d); return v; }
+DEVFN int ba_wave_sum_i(int v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d); return v; }
+
+// block-wide sum of one double per thread; result returned to every thread. red: LDS [BA_WAVES]
+DEVFN double ba_block_sum(double v, double* red) {
+  v = ba_wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0;
+  for (int w = 0; w < BA_WAVES; w++) t += red[w];
+  return t;
+}
+DEVFN int ba_block_sum_i(int v, int* red) {
+  v = ba_wave_sum_i(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int t = 0;
+  for (int w = 0; w < BA_WAVES; w++) t += red[w];
+  return t;
+}
+
+// k-th smallest (0-based) of n non-negative doubles in global memory (bit patterns order like the values):
+// MSB-first radix select, 8 bits per pass, histogram in LDS.  hist: LDS [256] ints, sel: LDS [2] u64.
+DEVFN double ba_radix_select(const double* v, int n, int k, int* hist, unsigned long long* sel) {
+  unsigned long long prefix = 0, mask = 0;
+  int kk = k;
+  for (int pass = 0; pass < 8; pass++) {
+    const int shift = 56 - 8 * pass;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const unsigned long long b = (unsigned long long)__double_as_longlong(v[i]);
+      if ((b & mask) == prefix) atomicAdd(&hist[(b >> shift) & 255], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int acc = 0, bin = 0;
+      for (; bin < 256; bin++) { if (acc + hist[bin] > kk) break; acc += hist[bin]; }
+      sel[0] = prefix | ((unsigned long long)bin << shift);
+      sel[1] = (unsigned long long)(kk - acc);
+    }
+    __syncthreads();
+    prefix = sel[0]; kk = (int)sel[1];
+    mask |= 255ull << shift;
+    __syncthreads();
+  }
+  return __longlong_as_double((long long)prefix);
+}
+
+// ProjectAndFindSquaredError, jni/Bundle.cc:181-199
+DEVFN void ba_project_meas(const BaView& v, const BaConfig& cfg, int i) {
+  const Pose& cam = v.cam_pose[v.ms_c[i]];
+  const double* X = v.pt_pos + 3 * v.ms_p[i];
+  double c[3];
+  pose_xform(cam, X, c);
+  v.ms_cam[3 * i] = c[0]; v.ms_cam[3 * i + 1] = c[1]; v.ms_cam[3 * i + 2] = c[2];
+  if (c[2] <= 0) { v.ms_state[i] = MS_BAD; return; }
+  v.ms_state[i] = MS_OK;
+  const CamProj pr = cam_project(cfg.cam, c[0] / c[2], c[1] / c[2]);
+  cam_derivs(cfg.cam, pr, v.ms_derivs + 4 * i);
+  const double sn = v.ms_sin[i];
+  const double e0 = (v.ms_found[2 * i] - pr.im[0]) * sn, e1 = (v.ms_found[2 * i + 1] - pr.im[1]) * sn;
+  v.ms_eps[2 * i] = e0; v.ms_eps[2 * i + 1] = e1;
+  v.ms_err2[i] = e0 * e0 + e1 * e1;
+}
+
+// Parallel in-place solve S x = E (n x n, row-major in global memory) by Gaussian elimination with partial
+// pivoting (stands in for Eigen's mS.inverse()*vE, jni/Bundle.cc:437).  Result in E.  Returns false if singular.
+DEVFN bool ba_block_solve(double* S, double* E, int n, int* ired) {
+  for (int k = 0; k < n; k++) {
+    if (threadIdx.x == 0) {
+      int piv = k; double best = fabs(S[(size_t)k * n + k]);
+      for (int r = k + 1; r < n; r++) { const double a = fabs(S[(size_t)r * n + k]); if (a > best) { best = a; piv = r; } }
+      ired[0] = best == 0.0 ? -1 : piv;
+    }
+    __syncthreads();
+    const int piv = ired[0];
+    if (piv < 0) return false;
+    if (piv != k) {
+      for (int c = threadIdx.x; c < n; c += blockDim.x) { const double t = S[(size_t)k * n + c]; S[(size_t)k * n + c] = S[(size_t)piv * n + c]; S[(size_t)piv * n + c] = t; }
+      if (threadIdx.x == 0) { const double t = E[k]; E[k] = E[piv]; E[piv] = t; }
+    }
+    __syncthreads();
+    const double inv = 1.0 / S[(size_t)k * n + k];
+    const int rem = n - k - 1;
+    // every row r > k: f = S[r][k] * inv; row r -= f * row k
+    for (int t = threadIdx.x; t < rem * (rem + 1); t += blockDim.x) {
+      const int r = k + 1 + t / (rem + 1), c = k + 1 + t % (rem + 1);   // c == n -> the right-hand side
+      const double f = S[(size_t)r * n + k] * inv;
+      if (c < n) S[(size_t)r * n + c] -= f * S[(size_t)k * n + c];
+      else E[r] -= f * E[k];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    for (int k = n - 1; k >= 0; k--) {
+      double s = E[k];
+      for (int c = k + 1; c < n; c++) s -= S[(size_t)k * n + c] * E[c];
+      E[k] = s / S[(size_t)k * n + k];
+    }
+  __syncthreads();
+  return true;
+}
+
+// Bundle::Compute.  Called by all BA_THREADS threads of one workgroup.
+DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
+  __shared__ double red[BA_WAVES];
+  __shared__ int ired[BA_WAVES];
+  __shared__ int hist[256];
+  __shared__ unsigned long long sel[2];
+  __shared__ double sh_lambda, sh_factor, sh_sigma2, sh_cur_err, sh_new_err;
+  __shared__ int sh_converged, sh_hitmax, sh_counter, sh_accepted, sh_error, sh_nout;
+  BaResult* R = v.res;
+  const int nc = R->n_cams, np = R->n_pts, nm = R->n_meas;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) {
+    int nf = 0, row = 0;
+    for (int j = 0; j < nc; j++) {            // AddCamera start rows, jni/Bundle.cc:79-85
+      if (!v.cam_fixed[j]) { v.cam_row[j] = row; row += 6; v.free_cams[nf++] = j; } else v.cam_row[j] = -999999999;
+    }
+    R->n_free = nf;
+    sh_lambda = 0.0001; sh_factor = 2.0;      // :144-145
+    sh_converged = 0; sh_hitmax = 0; sh_counter = 0; sh_accepted = 0; sh_error = 0; sh_nout = 0; sh_sigma2 = 0;
+    R->trials = 0;
+  }
+  __syncthreads();
+  const int nfree = R->n_free, nS = nfree * 6;
+
+  while (!sh_converged && !sh_hitmax && !sh_error) {             // :153 (no abort signal: the map-maker runs synchronously)
+    // ================= Do_LM_Step =================
+    // pass 1 (:209-215): project every measurement still in the list
+    int nvalid = 0;
+    for (int i = threadIdx.x; i < nm; i += BA_THREADS) {
+      double e2 = __builtin_huge_val();
+      if (v.ms_state[i] != MS_ERASED) {
+        ba_project_meas(v, cfg, i);
+        if (v.ms_state[i] == MS_OK) { e2 = v.ms_err2[i]; nvalid++; }
+      }
+      v.scratch[i] = e2;
+    }
+    nvalid = ba_block_sum_i(nvalid, ired);
+    if (nvalid == 0) { if (threadIdx.x == 0) sh_error = 1; __syncthreads(); break; }
+    {                                                              // :220-227 Tukey sigma, clamped
+      const double med = ba_radix_select(v.scratch, nm, nvalid / 2, hist, sel);
+      double s2 = tukey_sigma_squared(med, (unsigned long)nvalid);
+      if (s2 < cfg.min_sigma2) s2 = cfg.min_sigma2;
+      if (threadIdx.x == 0) sh_sigma2 = s2;
+      __syncthreads();
+    }
+    const double sigma2 = sh_sigma2;
+    // pass 2 (:241-321): weights, A, B, W, objective
+    double cur = 0.0;
+    for (int i = threadIdx.x; i < nm; i += BA_THREADS) {
+      const int stt = v.ms_state[i];
+      if (stt == MS_ERASED) continue;
+      if (stt == MS_BAD) { cur += 1.0; continue; }
+      const double dWeight = tukey_sqrt_weight(v.ms_err2[i], sigma2);
+      v.ms_eps[2 * i] *= dWeight; v.ms_eps[2 * i + 1] *= dWeight;
+      if (dWeight == 0) { v.ms_state[i] = MS_BAD; cur += 1.0; continue; }
+      cur += tukey_objective(v.ms_err2[i], sigma2);
+      const int c = v.ms_c[i];
+      const double* dd = v.ms_derivs + 4 * i;
+      const double sn = v.ms_sin[i];
+      const double d0 = sn * (dWeight * dd[0]), d1 = sn * (dWeight * dd[1]), d2 = sn * (dWeight * dd[2]), d3 = sn * (dWeight * dd[3]);
+      const double* cm = v.ms_cam + 3 * i;
+      const double ooz = 1.0 / cm[2];
+      double* A = v.ms_A + 12 * i; double* B = v.ms_B + 6 * i; double* W = v.ms_W + 18 * i;
+      const bool fixed = v.cam_fixed[c] != 0;
+      if (fixed) { for (int k = 0; k < 12; k++) A[k] = 0.0; }
+      else
+        for (int k = 0; k < 6; k++) {
+          double mot[3];
+          generator_field(k, cm, mot);
+          const double f0 = (mot[0] - cm[0] * mot[2] * ooz) * ooz, f1 = (mot[1] - cm[1] * mot[2] * ooz) * ooz;
+          A[k] = d0 * f0 + d1 * f1; A[6 + k] = d2 * f0 + d3 * f1;
+        }
+      const Pose& cp = v.cam_pose[c];
+      for (int k = 0; k < 3; k++) {
+        const double m0 = cp.R[k], m1 = cp.R[3 + k], m2 = cp.R[6 + k];
+        const double f0 = (m0 - cm[0] * m2 * ooz) * ooz, f1 = (m1 - cm[1] * m2 * ooz) * ooz;
+        B[k] = d0 * f0 + d1 * f1; B[3 + k] = d2 * f0 + d3 * f1;
+      }
+      if (fixed) { for (int k = 0; k < 18; k++) W[k] = 0.0; }
+      else for (int r = 0; r < 6; r++) for (int q = 0; q < 3; q++) W[r * 3 + q] = A[r] * B[q] + A[6 + r] * B[3 + q];
+    }
+    cur = ba_block_sum(cur, red);
+    if (threadIdx.x == 0) sh_cur_err = cur;
+    __syncthreads();
+    // V, epsilon_b per point: one lane per point, cameras in id order
+    for (int p = threadIdx.x; p < np; p += BA_THREADS) {
+      double V[6] = {0, 0, 0, 0, 0, 0}, eb[3] = {0, 0, 0};
+      for (int c = 0; c < nc; c++) {
+        const int i = v.lut[(size_t)c * v.max_pts + p];
+        if (i < 0 || v.ms_state[i] != MS_OK) continue;
+        const double* B = v.ms_B + 6 * i; const double* e = v.ms_eps + 2 * i;
+        int q = 0;
+        for (int r = 0; r < 3; r++) for (int cc = 0; cc <= r; cc++) V[q++] += B[r] * B[cc] + B[3 + r] * B[3 + cc];   // :49-56 LL triangle
+        for (int r = 0; r < 3; r++) eb[r] += B[r] * e[0] + B[3 + r] * e[1];
+      }
+      double* Vp = v.pt_V + 9 * p;
+      Vp[0] = V[0]; Vp[3] = V[1]; Vp[4] = V[2]; Vp[6] = V[3]; Vp[7] = V[4]; Vp[8] = V[5]; Vp[1] = Vp[2] = Vp[5] = 0.0;
+      v.pt_eb[3 * p] = eb[0]; v.pt_eb[3 * p + 1] = eb[1]; v.pt_eb[3 * p + 2] = eb[2];
+    }
+    // U, epsilon_a per adjustable camera: one wavefront per camera (segmented wave reduction)
+    for (int f = wave; f < nfree; f += BA_WAVES) {
+      const int j = v.free_cams[f];
+      double acc[27];
+      for (int k = 0; k < 27; k++) acc[k] = 0.0;
+      for (int p = lane; p < np; p += 64) {
+        const int i = v.lut[(size_t)j * v.max_pts + p];
+        if (i < 0 || v.ms_state[i] != MS_OK) continue;
+        const double* A = v.ms_A + 12 * i; const double* e = v.ms_eps + 2 * i;
+        int q = 0;
+        for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) acc[q++] += A[r] * A[c] + A[6 + r] * A[6 + c];       // :40-47
+        for (int r = 0; r < 6; r++) acc[21 + r] += A[r] * e[0] + A[6 + r] * e[1];
+      }
+      for (int k = 0; k < 27; k++) acc[k] = ba_wave_sum(acc[k]);
+      if (lane == 0) {
+        double* U = v.cam_U + 36 * j;
+        int q = 0;
+        for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) U[r * 6 + c] = acc[q++];
+        for (int r = 0; r < 6; r++) v.cam_ea[6 * j + r] = acc[21 + r];
+      }
+    }
+    __syncthreads();
+
+    // ---- inner loop over lambda (:326-501) ----
+    if (threadIdx.x == 0) sh_new_err = sh_cur_err + 9999;
+    __syncthreads();
+    while (sh_new_err > sh_cur_err && !sh_converged && !sh_hitmax && !sh_error) {
+      const double lambda = sh_lambda;
+      for (int p = threadIdx.x; p < np; p += BA_THREADS) {           // V*^-1 (:329-347)
+        const double* Vp = v.pt_V + 9 * p;
+        double* Vi = v.pt_Vinv + 9 * p;
+        if (Vp[0] * Vp[4] * Vp[8] == 0) { for (int k = 0; k < 9; k++) Vi[k] = 0.0; continue; }
+        double Vs[9] = {Vp[0], Vp[3], Vp[6], Vp[3], Vp[4], Vp[7], Vp[6], Vp[7], Vp[8]};
+        for (int k = 0; k < 3; k++) Vs[k * 3 + k] *= (1.0 + lambda);
+        inv3(Vs, Vi);
+      }
+      for (int t = threadIdx.x; t < nS * nS; t += BA_THREADS) v.S[t] = 0.0;
+      __syncthreads();
+      // S: diagonal blocks + E (:362-396) and off-diagonal blocks (:400-426); one wavefront per block
+      const int ntask = nfree + nfree * (nfree - 1) / 2;
+      for (int task = wave; task < ntask; task += BA_WAVES) {
+        if (task < nfree) {
+          const int j = v.free_cams[task], row = v.cam_row[j];
+          double acc[27];
+          for (int k = 0; k < 27; k++) acc[k] = 0.0;
+          for (int p = lane; p < np; p += 64) {
+            const int i = v.lut[(size_t)j * v.max_pts + p];
+            if (i < 0 || v.ms_state[i] != MS_OK) continue;
+            const double* W = v.ms_W + 18 * i; const double* Vi = v.pt_Vinv + 9 * p; const double* eb = v.pt_eb + 3 * p;
+            double Y[18];
+            for (int r = 0; r < 6; r++) for (int c = 0; c < 3; c++) Y[r * 3 + c] = W[r * 3] * Vi[c] + W[r * 3 + 1] * Vi[3 + c] + W[r * 3 + 2] * Vi[6 + c];
+            int q = 0;
+            for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) acc[q++] += Y[r * 3] * W[c * 3] + Y[r * 3 + 1] * W[c * 3 + 1] + Y[r * 3 + 2] * W[c * 3 + 2];
+            double ve[3];
+            for (int r = 0; r < 3; r++) ve[r] = Vi[r * 3] * eb[0] + Vi[r * 3 + 1] * eb[1] + Vi[r * 3 + 2] * eb[2];
+            for (int r = 0; r < 6; r++) acc[21 + r] += W[r * 3] * ve[0] + W[r * 3 + 1] * ve[1] + W[r * 3 + 2] * ve[2];
+          }
+          for (int k = 0; k < 27; k++) acc[k] = ba_wave_sum(acc[k]);
+          if (lane == 0) {
+            const double* U = v.cam_U + 36 * j;
+            int q = 0;
+            for (int r = 0; r < 6; r++)
+              for (int c = 0; c <= r; c++) {
+                double u = U[r * 6 + c];
+                if (r == c) u *= (1.0 + lambda);
+                const double val = u - acc[q++];
+                v.S[(size_t)(row + r) * nS + row + c] = val; v.S[(size_t)(row + c) * nS + row + r] = val;   // mirrored :431-434
+              }
+            for (int r = 0; r < 6; r++) v.E[row + r] = v.cam_ea[6 * j + r] - acc[21 + r];
+          }
+        } else {
+          int t = task - nfree, fj = 1;
+          while (t >= fj) { t -= fj; fj++; }                         // pair (fj > fk): free-camera ordinals
+          const int fk = t;
+          const int j = v.free_cams[fj], k = v.free_cams[fk];
+          const int jrow = v.cam_row[j], krow = v.cam_row[k];
+          double acc[36];
+          for (int q = 0; q < 36; q++) acc[q] = 0.0;
+          for (int p = lane; p < np; p += 64) {
+            const int ij = v.lut[(size_t)j * v.max_pts + p], ik = v.lut[(size_t)k * v.max_pts + p];
+            if (ij < 0 || ik < 0 || v.ms_state[ij] != MS_OK || v.ms_state[ik] != MS_OK) continue;
+            const double* Wj = v.ms_W + 18 * ij; const double* Wk = v.ms_W + 18 * ik; const double* Vi = v.pt_Vinv + 9 * p;
+            double Y[18];
+            for (int r = 0; r < 6; r++) for (int c = 0; c < 3; c++) Y[r * 3 + c] = Wj[r * 3] * Vi[c] + Wj[r * 3 + 1] * Vi[3 + c] + Wj[r * 3 + 2] * Vi[6 + c];
+            for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) acc[r * 6 + c] += Y[r * 3] * Wk[c * 3] + Y[r * 3 + 1] * Wk[c * 3 + 1] + Y[r * 3 + 2] * Wk[c * 3 + 2];
+          }
+          for (int q = 0; q < 36; q++) acc[q] = ba_wave_sum(acc[q]);
+          if (lane == 0)
+            for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) {
+              v.S[(size_t)(jrow + r) * nS + krow + c] = -acc[r * 6 + c];
+              v.S[(size_t)(krow + c) * nS + jrow + r] = -acc[r * 6 + c];
+            }
+        }
+      }
+      __syncthreads();
+      if (nS > 0 && !ba_block_solve(v.S, v.E, nS, ired)) { if (threadIdx.x == 0) sh_error = 1; __syncthreads(); break; }
+      for (int t = threadIdx.x; t < nS; t += BA_THREADS) v.cam_up[t] = v.E[t];
+      __syncthreads();
+      // map updates (:440-462)
+      double ssq = 0.0;
+      for (int p = threadIdx.x; p < np; p += BA_THREADS) {
+        double sum[3] = {0, 0, 0};
+        for (int f = 0; f < nfree; f++) {
+          const int j = v.free_cams[f];
+          const int i = v.lut[(size_t)j * v.max_pts + p];
+          if (i < 0 || v.ms_state[i] != MS_OK) continue;
+          const double* W = v.ms_W + 18 * i; const double* cu = v.cam_up + v.cam_row[j];
+          for (int c = 0; c < 3; c++) { double s = 0; for (int r = 0; r < 6; r++) s += W[r * 3 + c] * cu[r]; sum[c] += s; }
+        }
+        const double* eb = v.pt_eb + 3 * p; const double* Vi = v.pt_Vinv + 9 * p;
+        const double x[3] = {eb[0] - sum[0], eb[1] - sum[1], eb[2] - sum[2]};
+        for (int r = 0; r < 3; r++) {
+          const double u = Vi[r * 3] * x[0] + Vi[r * 3 + 1] * x[1] + Vi[r * 3 + 2] * x[2];
+          v.map_up[3 * p + r] = u; ssq += u * u;
+          v.pt_new[3 * p + r] = v.pt_pos[3 * p + r] + u;               // :484
+        }
+      }
+      for (int t = threadIdx.x; t < nS; t += BA_THREADS) ssq += v.cam_up[t] * v.cam_up[t];
+      ssq = ba_block_sum(ssq, red);                                    // :467-470
+      for (int j = threadIdx.x; j < nc; j += BA_THREADS) {             // :476-482
+        if (v.cam_fixed[j]) v.cam_new[j] = v.cam_pose[j];
+        else v.cam_new[j] = pose_mul(se3_exp(v.cam_up + v.cam_row[j]), v.cam_pose[j]);
+      }
+      __syncthreads();
+      // FindNewError (:537-561)
+      double ne = 0.0;
+      for (int i = threadIdx.x; i < nm; i += BA_THREADS) {
+        if (v.ms_state[i] == MS_ERASED) continue;
+        double c[3];
+        pose_xform(v.cam_new[v.ms_c[i]], v.pt_new + 3 * v.ms_p[i], c);
+        if (c[2] <= 0) { ne += 1.0; continue; }
+        const CamProj pr = cam_project(cfg.cam, c[0] / c[2], c[1] / c[2]);
+        const double sn = v.ms_sin[i];
+        const double e0 = (v.ms_found[2 * i] - pr.im[0]) * sn, e1 = (v.ms_found[2 * i + 1] - pr.im[1]) * sn;
+        ne += tukey_objective(e0 * e0 + e1 * e1, sigma2);
+      }
+      ne = ba_block_sum(ne, red);
+      if (threadIdx.x == 0) {
+        if (ssq < cfg.convergence_limit) sh_converged = 1;
+        sh_new_err = ne;
+        if (ne > sh_cur_err) { sh_lambda = sh_lambda * sh_factor; sh_factor = sh_factor * 2; }   // ModifyLambda_BadStep :614-617
+        sh_counter++; R->trials++;
+        if (sh_counter >= cfg.max_iterations) sh_hitmax = 1;           // :498-500
+      }
+      __syncthreads();
+    }
+    if (sh_error) break;
+    if (sh_new_err < sh_cur_err) {                                     // :503-514
+      for (int j = threadIdx.x; j < nc; j += BA_THREADS) v.cam_pose[j] = v.cam_new[j];
+      for (int t = threadIdx.x; t < 3 * np; t += BA_THREADS) v.pt_pos[t] = v.pt_new[t];
+      if (threadIdx.x == 0) { sh_factor = 2.0; sh_lambda *= 0.3; sh_accepted++; }   // ModifyLambda_GoodStep :609-612
+    }
+    __syncthreads();
+    // erase the outliers in list order (:517-528): ordered compaction of the (p, c) pairs
+    {
+      int base = sh_nout;
+      for (int i0 = 0; i0 < nm; i0 += BA_THREADS) {
+        const int i = i0 + threadIdx.x;
+        const bool bad = i < nm && v.ms_state[i] == MS_BAD;
+        const unsigned long long bm = __ballot(bad);
+        __syncthreads();
+        if (lane == 0) ired[wave] = __popcll(bm);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; w++) off += ired[w];
+        if (bad) {
+          off += __popcll(bm & ((1ull << lane) - 1ull));
+          v.outl[2 * off] = v.ms_p[i]; v.outl[2 * off + 1] = v.ms_c[i];
+          v.ms_state[i] = MS_ERASED;
+          v.lut[(size_t)v.ms_c[i] * v.max_pts + v.ms_p[i]] = -1;
+          atomicAdd(&v.pt_nout[v.ms_p[i]], 1);
+        }
+        for (int w = 0; w < BA_WAVES; w++) base += ired[w];
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) sh_nout = base;
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x == 0) {
+    R->accepted = sh_error ? -1 : sh_accepted;                         // :170-177
+    R->converged = sh_converged; R->hit_max = sh_hitmax; R->counter = sh_counter;
+    R->sigma2 = sh_sigma2; R->lambda = sh_lambda; R->lambda_factor = sh_factor; R->n_outlier_meas = sh_nout;
+  }
+  __syncthreads();
+}

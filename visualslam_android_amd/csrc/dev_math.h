@@ -1,0 +1,217 @@
+// Device-side math substrate (fp64): SO3/SE3 (jni/RT.h), ATAN/FOV camera (jni/ATANCamera.{h,cc}),
+// Tukey M-estimator (jni/MEstimator.h), small dense solves.  Pure functions, no state.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define DEVFN __device__ __forceinline__
+#define HDFN __host__ __device__ __forceinline__
+
+struct Pose { double R[9]; double t[3]; };   // camera-from-world, R row-major (mySE3, jni/RT.h:247-312)
+
+struct CamModel {   // ATANCamera after RefreshParams (jni/ATANCamera.cc:37-82)
+  double size[2], focal[2], center[2];
+  double w, winv, two_tan, distortion_enabled;
+  double largest_radius, max_r;
+};
+
+struct CamProj { double im[2]; double cam[2]; double r; double factor; int invalid; };
+
+HDFN void pose_xform(const Pose& T, const double p[3], double o[3]) {   // jni/RT.h:492-499
+  o[0] = T.t[0] + (T.R[0] * p[0] + T.R[1] * p[1] + T.R[2] * p[2]);
+  o[1] = T.t[1] + (T.R[3] * p[0] + T.R[4] * p[1] + T.R[5] * p[2]);
+  o[2] = T.t[2] + (T.R[6] * p[0] + T.R[7] * p[1] + T.R[8] * p[2]);
+}
+HDFN void pose_rot(const Pose& T, const double p[3], double o[3]) {
+  o[0] = T.R[0] * p[0] + T.R[1] * p[1] + T.R[2] * p[2];
+  o[1] = T.R[3] * p[0] + T.R[4] * p[1] + T.R[5] * p[2];
+  o[2] = T.R[6] * p[0] + T.R[7] * p[1] + T.R[8] * p[2];
+}
+HDFN Pose pose_mul(const Pose& a, const Pose& b) {                       // jni/RT.h:286-295
+  Pose r;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      r.R[i * 3 + j] = a.R[i * 3 + 0] * b.R[0 * 3 + j] + a.R[i * 3 + 1] * b.R[1 * 3 + j] + a.R[i * 3 + 2] * b.R[2 * 3 + j];
+  double rt[3];
+  pose_rot(a, b.t, rt);
+  for (int i = 0; i < 3; i++) r.t[i] = a.t[i] + rt[i];
+  return r;
+}
+HDFN Pose pose_inverse(const Pose& a) {                                 // jni/RT.h:274-282
+  Pose r;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.R[i * 3 + j] = a.R[j * 3 + i];
+  double rt[3];
+  pose_rot(r, a.t, rt);
+  for (int i = 0; i < 3; i++) r.t[i] = -rt[i];
+  return r;
+}
+
+HDFN void rodrigues(const double w[3], double A, double B, double R[9]) {   // jni/RT.h:98-129
+  const double wx2 = w[0] * w[0], wy2 = w[1] * w[1], wz2 = w[2] * w[2];
+  R[0] = 1.0 - B * (wy2 + wz2); R[4] = 1.0 - B * (wx2 + wz2); R[8] = 1.0 - B * (wx2 + wy2);
+  { const double a = A * w[2], b = B * (w[0] * w[1]); R[1] = b - a; R[3] = b + a; }
+  { const double a = A * w[1], b = B * (w[0] * w[2]); R[2] = b + a; R[6] = b - a; }
+  { const double a = A * w[0], b = B * (w[1] * w[2]); R[5] = b - a; R[7] = b + a; }
+}
+
+HDFN void so3_exp(const double w[3], double R[9]) {                      // jni/RT.h:134-165
+  const double one_6th = 1.0 / 6.0, one_20th = 1.0 / 20.0;
+  const double theta_sq = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  const double theta = sqrt(theta_sq);
+  double A, B;
+  if (theta_sq < 1e-8) { A = 1.0 - one_6th * theta_sq; B = 0.5; }
+  else if (theta_sq < 1e-6) { B = 0.5 - 0.25 * one_6th * theta_sq; A = 1.0 - theta_sq * one_6th * (1.0 - one_20th * theta_sq); }
+  else { const double inv_theta = 1.0 / theta; A = sin(theta) * inv_theta; B = (1 - cos(theta)) * (inv_theta * inv_theta); }
+  rodrigues(w, A, B, R);
+}
+
+HDFN void so3_ln(const double M[9], double result[3]) {                  // jni/RT.h:167-214
+  const double kSqrt1_2 = 0.70710678118654752440, kPi = 3.14159265358979323846;
+  const double cos_angle = (M[0] + M[4] + M[8] - 1.0) * 0.5;
+  result[0] = (M[7] - M[5]) / 2; result[1] = (M[2] - M[6]) / 2; result[2] = (M[3] - M[1]) / 2;
+  const double sin_angle_abs = sqrt(result[0] * result[0] + result[1] * result[1] + result[2] * result[2]);
+  if (cos_angle > kSqrt1_2) {
+    if (sin_angle_abs > 0) { const double f = asin(sin_angle_abs) / sin_angle_abs; result[0] *= f; result[1] *= f; result[2] *= f; }
+  } else if (cos_angle > -kSqrt1_2) {
+    const double f = acos(cos_angle) / sin_angle_abs;
+    result[0] *= f; result[1] *= f; result[2] *= f;
+  } else {
+    const double angle = kPi - asin(sin_angle_abs);
+    const double d0 = M[0] - cos_angle, d1 = M[4] - cos_angle, d2 = M[8] - cos_angle;
+    double r2[3];
+    if (d0 * d0 > d1 * d1 && d0 * d0 > d2 * d2) { r2[0] = d0; r2[1] = (M[3] + M[1]) / 2; r2[2] = (M[2] + M[6]) / 2; }
+    else if (d1 * d1 > d2 * d2) { r2[0] = (M[3] + M[1]) / 2; r2[1] = d1; r2[2] = (M[7] + M[5]) / 2; }
+    else { r2[0] = (M[2] + M[6]) / 2; r2[1] = (M[7] + M[5]) / 2; r2[2] = d2; }
+    if (r2[0] * result[0] + r2[1] * result[1] + r2[2] * result[2] < 0) { r2[0] = -r2[0]; r2[1] = -r2[1]; r2[2] = -r2[2]; }
+    const double inv = 1.0 / sqrt(r2[0] * r2[0] + r2[1] * r2[1] + r2[2] * r2[2]);
+    for (int i = 0; i < 3; i++) result[i] = (r2[i] * inv) * angle;
+  }
+}
+
+HDFN Pose se3_exp(const double mu[6]) {                                  // jni/RT.h:318-352
+  const double one_6th = 1.0 / 6.0, one_20th = 1.0 / 20.0;
+  Pose result;
+  const double w[3] = {mu[3], mu[4], mu[5]};
+  const double theta_sq = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  const double theta = sqrt(theta_sq);
+  double A, B;
+  const double cr[3] = {w[1] * mu[2] - w[2] * mu[1], w[2] * mu[0] - w[0] * mu[2], w[0] * mu[1] - w[1] * mu[0]};
+  if (theta_sq < 1e-8) {
+    A = 1.0 - one_6th * theta_sq; B = 0.5;
+    for (int i = 0; i < 3; i++) result.t[i] = mu[i] + 0.5 * cr[i];
+  } else {
+    double C;
+    if (theta_sq < 1e-6) { C = one_6th * (1.0 - one_20th * theta_sq); A = 1.0 - theta_sq * C; B = 0.5 - 0.25 * one_6th * theta_sq; }
+    else { const double inv_theta = 1.0 / theta; A = sin(theta) * inv_theta; B = (1 - cos(theta)) * (inv_theta * inv_theta); C = (1 - A) * (inv_theta * inv_theta); }
+    const double wc[3] = {w[1] * cr[2] - w[2] * cr[1], w[2] * cr[0] - w[0] * cr[2], w[0] * cr[1] - w[1] * cr[0]};
+    for (int i = 0; i < 3; i++) result.t[i] = mu[i] + B * cr[i] + C * wc[i];
+  }
+  rodrigues(w, A, B, result.R);
+  return result;
+}
+
+HDFN void se3_ln(const Pose& T, double out[6]) {                         // jni/RT.h:354-383
+  double rotv[3];
+  so3_ln(T.R, rotv);
+  const double rr = rotv[0] * rotv[0] + rotv[1] * rotv[1] + rotv[2] * rotv[2];
+  const double theta = sqrt(rr);
+  double shtot = 0.5;
+  if (theta > 0.00001) shtot = sin(theta / 2) / theta;
+  const double half[3] = {rotv[0] * -0.5, rotv[1] * -0.5, rotv[2] * -0.5};
+  Pose hr;
+  so3_exp(half, hr.R);
+  double rottrans[3];
+  pose_rot(hr, T.t, rottrans);
+  const double tdr = T.t[0] * rotv[0] + T.t[1] * rotv[1] + T.t[2] * rotv[2];
+  const double f = theta > 0.001 ? (tdr * (1 - 2 * shtot) / rr) : (tdr / 24);
+  const double inv = 1.0 / (2 * shtot);
+  for (int i = 0; i < 3; i++) out[i] = (rottrans[i] - rotv[i] * f) * inv;
+  out[3] = rotv[0]; out[4] = rotv[1]; out[5] = rotv[2];
+}
+
+// mySE3::generator_field(i, (x, y, z, 1)), jni/RT.h:297-308
+HDFN void generator_field(int i, const double pos[3], double out[3]) {
+  out[0] = out[1] = out[2] = 0;
+  if (i < 3) { out[i] = 1.0; return; }
+  out[(i + 1) % 3] = -pos[(i + 2) % 3];
+  out[(i + 2) % 3] = pos[(i + 1) % 3];
+}
+
+// ---- camera -------------------------------------------------------------------------------------------------
+HDFN double cam_rtrans_factor(const CamModel& c, double r) {              // jni/ATANCamera.h:136-142
+  if (r < 0.001 || c.w == 0.0) return 1.0;
+  return c.winv * atan(r * c.two_tan) / r;
+}
+HDFN CamProj cam_project(const CamModel& c, double cx, double cy) {        // jni/ATANCamera.cc:133-145
+  CamProj p;
+  p.cam[0] = cx; p.cam[1] = cy;
+  p.r = sqrt(cx * cx + cy * cy);
+  p.invalid = (p.r > c.max_r);
+  p.factor = cam_rtrans_factor(c, p.r);
+  p.im[0] = c.center[0] + c.focal[0] * (cx * p.factor);
+  p.im[1] = c.center[1] + c.focal[1] * (cy * p.factor);
+  return p;
+}
+HDFN void cam_derivs(const CamModel& c, const CamProj& p, double d[4]) {   // jni/ATANCamera.cc:198-231
+  double fx, fy;
+  const double k = c.two_tan, x = p.cam[0], y = p.cam[1];
+  const double r = p.r * c.distortion_enabled;
+  if (r < 0.01) { fx = 0.0; fy = 0.0; }
+  else {
+    fx = c.winv * (k * x) / (r * r * (1 + k * k * r * r)) - x * p.factor / (r * r);
+    fy = c.winv * (k * y) / (r * r * (1 + k * k * r * r)) - y * p.factor / (r * r);
+  }
+  d[0] = c.focal[0] * (fx * x + p.factor);
+  d[2] = c.focal[1] * (fx * y);
+  d[1] = c.focal[0] * (fy * x);
+  d[3] = c.focal[1] * (fy * y + p.factor);
+}
+
+// ---- Tukey (jni/MEstimator.h:42-77) --------------------------------------------------------------------------
+HDFN double tukey_sqrt_weight(double e2, double s2) { return e2 > s2 ? 0.0 : 1.0 - (e2 / s2); }
+HDFN double tukey_weight(double e2, double s2) { const double d = tukey_sqrt_weight(e2, s2); return d * d; }
+HDFN double tukey_objective(double e2, double s2) { if (e2 > s2) return 1.0; const double d = 1.0 - e2 / s2; return 1.0 - d * d * d; }
+HDFN double tukey_sigma_squared(double median, unsigned long n) {
+  double sigma = 1.4826 * (1 + 5.0 / (n * 2 - 6)) * sqrt(median);   // size_t arithmetic as in the reference
+  sigma = 4.6851 * sigma;
+  return sigma * sigma;
+}
+
+// ---- dense solves --------------------------------------------------------------------------------------------
+// Gaussian elimination with partial pivoting (stands in for Eigen's PartialPivLU  A.inverse()*b). A n x n row-major.
+HDFN bool lu_solve_n(double* A, double* b, int n) {
+  for (int k = 0; k < n; k++) {
+    int piv = k; double best = fabs(A[k * n + k]);
+    for (int r = k + 1; r < n; r++) if (fabs(A[r * n + k]) > best) { best = fabs(A[r * n + k]); piv = r; }
+    if (best == 0.0) return false;
+    if (piv != k) { for (int c = 0; c < n; c++) { const double t = A[k * n + c]; A[k * n + c] = A[piv * n + c]; A[piv * n + c] = t; } const double t = b[k]; b[k] = b[piv]; b[piv] = t; }
+    const double inv = 1.0 / A[k * n + k];
+    for (int r = k + 1; r < n; r++) {
+      const double f = A[r * n + k] * inv;
+      if (f == 0.0) continue;
+      for (int c = k + 1; c < n; c++) A[r * n + c] -= f * A[k * n + c];
+      b[r] -= f * b[k];
+    }
+  }
+  for (int k = n - 1; k >= 0; k--) {
+    double s = b[k];
+    for (int c = k + 1; c < n; c++) s -= A[k * n + c] * b[c];
+    b[k] = s / A[k * n + k];
+  }
+  return true;
+}
+
+HDFN void inv3(const double m[9], double o[9]) {   // cofactor inverse (Eigen fixed 3x3)
+  const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+  const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+  const double id = 1.0 / det;
+  o[0] = c00 * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+  o[3] = c01 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+  o[6] = c02 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+HDFN void inv2(const double m[4], double o[4]) {
+  const double id = 1.0 / (m[0] * m[3] - m[1] * m[2]);
+  o[0] = m[3] * id; o[1] = -m[1] * id; o[2] = -m[2] * id; o[3] = m[0] * id;
+}
+
+HDFN double level_zero_pos(double p, int l) { return (p + 0.5) * (1 << l) - 0.5; }   // jni/LevelHelpers.h:23-25
+HDFN double level_n_pos(double p, int l) { return (p + 0.5) / (1 << l) - 0.5; }      // jni/LevelHelpers.h:37-39

@@ -1,0 +1,310 @@
+// Map upload, per-frame entry points (Tracker::TrackFrame / JNI-equivalent update) and read-back of the C ABI.
+#include "vslam_internal.h"
+#include <stdio.h>
+#include <string.h>
+
+#define CHK_STREAM(sys, s) do { if (!(sys) || (s) < 0 || (s) >= (sys)->S) { vslam_set_error("bad system/stream"); return VSLAM_E_INVALID; } } while (0)
+
+static int get_state(vslam_system* sys, int s, TrackerState* st) {
+  HIPCHK(hipMemcpyAsync(st, sys->map.st + s, sizeof(TrackerState), hipMemcpyDeviceToHost, sys->stream));
+  HIPCHK(hipStreamSynchronize(sys->stream));
+  return VSLAM_OK;
+}
+static int put_state(vslam_system* sys, int s, const TrackerState* st) {
+  HIPCHK(hipMemcpyAsync(sys->map.st + s, st, sizeof(TrackerState), hipMemcpyHostToDevice, sys->stream));
+  HIPCHK(hipStreamSynchronize(sys->stream));
+  return VSLAM_OK;
+}
+
+// one pyramid level of a stored keyframe: (a+b+c+d+2)>>2 (jni/KeyFrame.cc:19-23, see frontend.hip)
+__global__ void k_halve_plain(const uint8_t* src, int sp, uint8_t* dst, int dp, int dw, int dh) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= dw || y >= dh) return;
+  const uint8_t* r0 = src + (size_t)(2 * y) * sp + 2 * x;
+  const uint8_t* r1 = r0 + sp;
+  dst[(size_t)y * dp + x] = (uint8_t)((r0[0] + r0[1] + r1[0] + r1[1] + 2) >> 2);
+}
+
+extern "C" int vslam_map_add_keyframe(vslam_system* sys, int s, const double pose12[12], int fixed, const uint8_t* gray,
+                                      size_t row_stride, double depth_mean, double depth_sigma) {
+  CHK_STREAM(sys, s);
+  if (!pose12 || !gray || (int)row_stride < sys->geom[0].w) { vslam_set_error("map_add_keyframe: bad argument"); return VSLAM_E_INVALID; }
+  TrackerState st;
+  int r = get_state(sys, s, &st); if (r) return r;
+  const int K = sys->p.max_keyframes;
+  if (st.n_kf >= K) { vslam_set_error("keyframe capacity %d reached", K); return VSLAM_E_CAPACITY; }
+  const int k = st.n_kf;
+  const LevelGeom* g = sys->geom;
+  uint8_t* lvl[NLEV];
+  for (int l = 0; l < NLEV; l++) lvl[l] = sys->map.kf_img[l] + ((size_t)s * K + k) * ((size_t)g[l].pitch * g[l].h);
+  HIPCHK(hipMemcpy2DAsync(lvl[0], g[0].pitch, gray, row_stride, g[0].w, g[0].h, hipMemcpyHostToDevice, sys->stream));
+  for (int l = 1; l < NLEV; l++)
+    hipLaunchKernelGGL(k_halve_plain, dim3((g[l].w + 255) / 256, g[l].h), dim3(256), 0, sys->stream, lvl[l - 1], g[l - 1].pitch, lvl[l], g[l].pitch, g[l].w, g[l].h);
+  Pose p;
+  for (int i = 0; i < 9; i++) p.R[i] = pose12[i];
+  for (int i = 0; i < 3; i++) p.t[i] = pose12[9 + i];
+  const double dd[2] = {depth_mean, depth_sigma};
+  const int fx = fixed ? 1 : 0;
+  HIPCHK(hipMemcpyAsync(sys->map.kf_pose + (size_t)s * K + k, &p, sizeof(Pose), hipMemcpyHostToDevice, sys->stream));
+  HIPCHK(hipMemcpyAsync(sys->map.kf_fixed + (size_t)s * K + k, &fx, sizeof(int), hipMemcpyHostToDevice, sys->stream));
+  HIPCHK(hipMemcpyAsync(sys->map.kf_depth + ((size_t)s * K + k) * 2, dd, sizeof(dd), hipMemcpyHostToDevice, sys->stream));
+  HIPCHK(hipMemsetAsync(sys->map.kf_meas + ((size_t)s * K + k) * sys->p.max_points, 0, sizeof(MeasDev) * sys->p.max_points, sys->stream));
+  st.n_kf = k + 1;
+  r = put_state(sys, s, &st); if (r) return r;
+  return k;
+}
+
+extern "C" int vslam_map_add_point(vslam_system* sys, int s, const double pos[3], int src_keyframe, int src_level, int ir_x,
+                                   int ir_y, const double right[3], const double down[3]) {
+  CHK_STREAM(sys, s);
+  TrackerState st;
+  int r = get_state(sys, s, &st); if (r) return r;
+  if (!pos || !right || !down || src_keyframe < 0 || src_keyframe >= st.n_kf || src_level < 0 || src_level >= NLEV) { vslam_set_error("map_add_point: bad argument"); return VSLAM_E_INVALID; }
+  const int P = sys->p.max_points;
+  if (st.n_points >= P) { vslam_set_error("map point capacity %d reached", P); return VSLAM_E_CAPACITY; }
+  const int i = st.n_points;
+  MapPointDev mp; memset(&mp, 0, sizeof(mp));
+  for (int q = 0; q < 3; q++) { mp.pos[q] = pos[q]; mp.right[q] = right[q]; mp.down[q] = down[q]; }
+  mp.src_kf = src_keyframe; mp.src_level = src_level; mp.irx = ir_x; mp.iry = ir_y;
+  TrackData td; memset(&td, 0, sizeof(td));
+  td.last_warp[0] = 9999.9; td.last_warp[3] = 9999.9;   // jni/PatchFinder.cc:23
+  td.level = -1;
+  HIPCHK(hipMemcpyAsync(sys->map.pts + (size_t)s * P + i, &mp, sizeof(mp), hipMemcpyHostToDevice, sys->stream));
+  HIPCHK(hipMemcpyAsync(sys->map.td + (size_t)s * P + i, &td, sizeof(td), hipMemcpyHostToDevice, sys->stream));
+  st.n_points = i + 1;
+  r = put_state(sys, s, &st); if (r) return r;
+  return i;
+}
+
+extern "C" int vslam_map_add_measurement(vslam_system* sys, int s, int keyframe, int point, int level, const double root_pos[2],
+                                         int subpix, int source) {
+  CHK_STREAM(sys, s);
+  TrackerState st;
+  int r = get_state(sys, s, &st); if (r) return r;
+  if (!root_pos || keyframe < 0 || keyframe >= st.n_kf || point < 0 || point >= st.n_points || level < 0 || level >= NLEV) { vslam_set_error("map_add_measurement: bad argument"); return VSLAM_E_INVALID; }
+  const int P = sys->p.max_points, K = sys->p.max_keyframes;
+  MeasDev* slot = sys->map.kf_meas + ((size_t)s * K + keyframe) * P + point;
+  MeasDev old;
+  HIPCHK(hipMemcpy(&old, slot, sizeof(old), hipMemcpyDeviceToHost));
+  MeasDev m; memset(&m, 0, sizeof(m));
+  m.root[0] = root_pos[0]; m.root[1] = root_pos[1]; m.valid = 1; m.level = (signed char)level; m.subpix = subpix ? 1 : 0; m.source = (signed char)source;
+  HIPCHK(hipMemcpy(slot, &m, sizeof(m), hipMemcpyHostToDevice));
+  if (!old.valid) {   // MapMakerData::sMeasurementKFs.insert
+    MapPointDev mp;
+    HIPCHK(hipMemcpy(&mp, sys->map.pts + (size_t)s * P + point, sizeof(mp), hipMemcpyDeviceToHost));
+    mp.n_meas_kfs++;
+    HIPCHK(hipMemcpy(sys->map.pts + (size_t)s * P + point, &mp, sizeof(mp), hipMemcpyHostToDevice));
+  }
+  return VSLAM_OK;
+}
+
+// bulk upload used by the Python mirror for speed: arrays of n measurements
+extern "C" int vslam_map_add_measurements(vslam_system* sys, int s, int n, const int* keyframe, const int* point, const int* level,
+                                          const double* root_pos, const int* subpix, const int* source) {
+  CHK_STREAM(sys, s);
+  TrackerState st;
+  int r = get_state(sys, s, &st); if (r) return r;
+  const int P = sys->p.max_points, K = sys->p.max_keyframes;
+  std::vector<MeasDev> km((size_t)K * P);
+  std::vector<MapPointDev> pts(P);
+  HIPCHK(hipMemcpy(km.data(), sys->map.kf_meas + (size_t)s * K * P, sizeof(MeasDev) * km.size(), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(pts.data(), sys->map.pts + (size_t)s * P, sizeof(MapPointDev) * P, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; i++) {
+    if (keyframe[i] < 0 || keyframe[i] >= st.n_kf || point[i] < 0 || point[i] >= st.n_points || level[i] < 0 || level[i] >= NLEV) { vslam_set_error("map_add_measurements: bad entry %d", i); return VSLAM_E_INVALID; }
+    MeasDev& m = km[(size_t)keyframe[i] * P + point[i]];
+    if (!m.valid) pts[point[i]].n_meas_kfs++;
+    m.root[0] = root_pos[2 * i]; m.root[1] = root_pos[2 * i + 1]; m.valid = 1; m.level = (signed char)level[i]; m.subpix = subpix[i] ? 1 : 0; m.source = (signed char)source[i]; m.pad = 0;
+  }
+  HIPCHK(hipMemcpy(sys->map.kf_meas + (size_t)s * K * P, km.data(), sizeof(MeasDev) * km.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(sys->map.pts + (size_t)s * P, pts.data(), sizeof(MapPointDev) * P, hipMemcpyHostToDevice));
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_map_set_good(vslam_system* sys, int s) {
+  CHK_STREAM(sys, s);
+  TrackerState st;
+  int r = get_state(sys, s, &st); if (r) return r;
+  if (st.n_kf < 1) { vslam_set_error("map_set_good: no keyframes"); return VSLAM_E_STATE; }
+  double dd[2];
+  HIPCHK(hipMemcpy(dd, sys->map.kf_depth + (size_t)s * sys->p.max_keyframes * 2, sizeof(dd), hipMemcpyDeviceToHost));
+  st.map_good = 1;
+  st.wiggle_depth_norm = sys->p.wiggle_scale / dd[0];   // jni/MapMaker.cc:353
+  st.ba_converged_recent = 1; st.ba_converged_full = 1; // MapMaker::Reset :72-73
+  return put_state(sys, s, &st);
+}
+
+static void reset_tracker_fields(TrackerState& st) {   // Tracker::Reset, jni/Tracker.cc:45-62 (first call for a stream)
+  if (st.frame == 0 && st.last_kf_dropped == 0 && st.depth_mean == 0.0) {
+    st.quality = 2; st.last_kf_dropped = -20; st.depth_mean = 1.0; st.depth_sigma = 1.0; st.ba_accepted = -2;
+    for (int i = 0; i < 9; i++) st.pose_final.R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    st.pose_cur = st.pose_final; st.start_pose = st.pose_final;
+  }
+}
+
+extern "C" int vslam_set_pose(vslam_system* sys, int s, const double pose12[12]) {
+  CHK_STREAM(sys, s);
+  TrackerState st;
+  int r = get_state(sys, s, &st); if (r) return r;
+  reset_tracker_fields(st);
+  for (int i = 0; i < 9; i++) st.pose_final.R[i] = pose12[i];
+  for (int i = 0; i < 3; i++) st.pose_final.t[i] = pose12[9 + i];
+  st.pose_cur = st.pose_final; st.start_pose = st.pose_final;
+  return put_state(sys, s, &st);
+}
+
+extern "C" int vslam_set_velocity(vslam_system* sys, int s, const double v6[6]) {
+  CHK_STREAM(sys, s);
+  TrackerState st;
+  int r = get_state(sys, s, &st); if (r) return r;
+  reset_tracker_fields(st);
+  for (int i = 0; i < 6; i++) st.velocity[i] = v6[i];
+  {   // mdMSDScaledVelocityMagnitude as UpdateMotionModel would leave it (jni/Tracker.cc:811-819)
+    double ss = 0;
+    for (int i = 0; i < 6; i++) { double v = v6[i]; if (i < 3) v *= 1.0 / st.depth_mean; ss += v * v; }
+    st.msd_vel = sqrt(ss);
+  }
+  return put_state(sys, s, &st);
+}
+
+int map_init_states(vslam_system* sys) {
+  std::vector<TrackerState> v(sys->S);
+  memset(v.data(), 0, sizeof(TrackerState) * sys->S);
+  for (auto& st : v) reset_tracker_fields(st);
+  HIPCHK(hipMemcpy(sys->map.st, v.data(), sizeof(TrackerState) * sys->S, hipMemcpyHostToDevice));
+  return VSLAM_OK;
+}
+
+// ---- per-frame entry points -------------------------------------------------------------------------------------
+extern "C" int vslam_track_frame(vslam_system* sys, const uint8_t* gray, size_t row_stride, size_t stream_stride, int on_device) {
+  if (!sys) return VSLAM_E_INVALID;
+  int r = fe_make_keyframe_lite(sys, gray, row_stride, stream_stride, on_device);   // jni/Tracker.cc:85
+  if (r) return r;
+  r = trk_track_map(sys);                                                            // :103-124
+  if (r) return r;
+  return ba_add_keyframe_and_adjust(sys);                                            // :128-132 -> MapMaker::AddKeyFrame
+}
+
+extern "C" int vslam_update(vslam_system* sys, const uint8_t* gray, size_t row_stride, size_t stream_stride) {
+  int r = vslam_track_frame(sys, gray, row_stride, stream_stride, 0);
+  if (r) return r;
+  HIPCHK(hipStreamSynchronize(sys->stream));   // the caller may reuse its buffer (TrackFrame copies its input)
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_touch(vslam_system* sys) { return sys ? VSLAM_OK : VSLAM_E_INVALID; }
+
+int ba_run(vslam_system* sys, int mode);
+extern "C" int vslam_bundle_adjust_recent(vslam_system* sys) { if (!sys) return VSLAM_E_INVALID; return ba_run(sys, 1); }
+extern "C" int vslam_bundle_adjust_all(vslam_system* sys) { if (!sys) return VSLAM_E_INVALID; return ba_run(sys, 2); }
+
+// ---- read-back ------------------------------------------------------------------------------------------------------
+extern "C" int vslam_get_state(vslam_system* sys, int s, vslam_track_state* o) {
+  CHK_STREAM(sys, s);
+  if (!o) return VSLAM_E_INVALID;
+  TrackerState st;
+  int r = get_state(sys, s, &st); if (r) return r;
+  for (int i = 0; i < 9; i++) o->pose[i] = st.pose_final.R[i];
+  for (int i = 0; i < 3; i++) o->pose[9 + i] = st.pose_final.t[i];
+  for (int i = 0; i < 6; i++) o->velocity[i] = st.velocity[i];
+  o->msd_velocity = st.msd_vel; o->depth_mean = st.depth_mean; o->depth_sigma = st.depth_sigma;
+  for (int i = 0; i < NLEV; i++) { o->attempted[i] = st.attempted[i]; o->found[i] = st.found[i]; }
+  o->quality = st.quality; o->lost_frames = st.lost_frames; o->frame = st.frame; o->did_coarse = st.did_coarse;
+  o->kf_added = st.kf_added; o->n_keyframes = st.n_kf; o->n_points = st.n_points; o->ba_accepted = st.ba_accepted;
+  o->n_zmssd = (long long)st.n_zmssd; o->n_ba_trials = (long long)st.n_ba_trials;
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_get_message(vslam_system* sys, int s, char* buf, size_t cap) {
+  CHK_STREAM(sys, s);
+  TrackerState st;
+  int r = get_state(sys, s, &st); if (r) return r;
+  if (!buf || !cap) return VSLAM_E_INVALID;
+  if (!st.map_good) snprintf(buf, cap, "Point camera at planar scene and press spacebar to start tracking for initial map.");   // jni/Tracker.cc:240
+  else if (st.lost_frames >= 3) snprintf(buf, cap, "** Attempting recovery **.");                                                // :134
+  else snprintf(buf, cap, "Tracking Map, quality %s Found: %d/%d %d/%d %d/%d %d/%d Map: %dP, %dKF%s",                            // :110-124
+                st.quality == 2 ? "good." : st.quality == 1 ? "poor." : "bad.", st.found[0], st.attempted[0], st.found[1], st.attempted[1],
+                st.found[2], st.attempted[2], st.found[3], st.attempted[3], st.n_points, st.n_kf, st.kf_added ? " Adding key-frame." : "");
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_get_point_tracks(vslam_system* sys, int s, int* found, int* searched, int* level, int* subpix, double* vfound,
+                                      double* image, int cap) {
+  CHK_STREAM(sys, s);
+  TrackerState st;
+  int r = get_state(sys, s, &st); if (r) return r;
+  const int n = st.n_points < cap ? st.n_points : cap;
+  std::vector<TrackData> td(n > 0 ? n : 1);
+  if (n > 0) HIPCHK(hipMemcpy(td.data(), sys->map.td + (size_t)s * sys->p.max_points, sizeof(TrackData) * n, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; i++) {
+    if (found) found[i] = (td[i].flags & TDF_FOUND) ? 1 : 0;
+    if (searched) searched[i] = (td[i].flags & TDF_SEARCHED) ? 1 : 0;
+    if (level) level[i] = td[i].level;
+    if (subpix) subpix[i] = (td[i].flags & TDF_SUBPIX) ? 1 : 0;
+    if (vfound) { vfound[2 * i] = td[i].vfound[0]; vfound[2 * i + 1] = td[i].vfound[1]; }
+    if (image) { image[2 * i] = td[i].image[0]; image[2 * i + 1] = td[i].image[1]; }
+  }
+  return st.n_points;
+}
+
+extern "C" int vslam_get_points(vslam_system* sys, int s, double* pos3, int* bad, int* n_in, int* n_out, int cap) {
+  CHK_STREAM(sys, s);
+  TrackerState st;
+  int r = get_state(sys, s, &st); if (r) return r;
+  const int n = st.n_points < cap ? st.n_points : cap;
+  std::vector<MapPointDev> p(n > 0 ? n : 1);
+  if (n > 0) HIPCHK(hipMemcpy(p.data(), sys->map.pts + (size_t)s * sys->p.max_points, sizeof(MapPointDev) * n, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; i++) {
+    if (pos3) for (int q = 0; q < 3; q++) pos3[3 * i + q] = p[i].pos[q];
+    if (bad) bad[i] = p[i].bad;
+    if (n_in) n_in[i] = p[i].n_in;
+    if (n_out) n_out[i] = p[i].n_out;
+  }
+  return st.n_points;
+}
+
+extern "C" int vslam_get_keyframe_pose(vslam_system* sys, int s, int k, double pose12[12]) {
+  CHK_STREAM(sys, s);
+  if (k < 0 || k >= sys->p.max_keyframes || !pose12) return VSLAM_E_INVALID;
+  Pose p;
+  HIPCHK(hipStreamSynchronize(sys->stream));
+  HIPCHK(hipMemcpy(&p, sys->map.kf_pose + (size_t)s * sys->p.max_keyframes + k, sizeof(p), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 9; i++) pose12[i] = p.R[i];
+  for (int i = 0; i < 3; i++) pose12[9 + i] = p.t[i];
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_get_keyframe_measurements(vslam_system* sys, int s, int k, int* point, int* level, double* root_pos, int* source, int cap) {
+  CHK_STREAM(sys, s);
+  TrackerState st;
+  int r = get_state(sys, s, &st); if (r) return r;
+  if (k < 0 || k >= st.n_kf) return VSLAM_E_INVALID;
+  const int P = sys->p.max_points;
+  std::vector<MeasDev> km(P);
+  HIPCHK(hipMemcpy(km.data(), sys->map.kf_meas + ((size_t)s * sys->p.max_keyframes + k) * P, sizeof(MeasDev) * P, hipMemcpyDeviceToHost));
+  int n = 0;
+  for (int i = 0; i < st.n_points; i++) {
+    if (!km[i].valid) continue;
+    if (n < cap) {
+      if (point) point[n] = i;
+      if (level) level[n] = km[i].level;
+      if (root_pos) { root_pos[2 * n] = km[i].root[0]; root_pos[2 * n + 1] = km[i].root[1]; }
+      if (source) source[n] = km[i].source;
+    }
+    n++;
+  }
+  return n;
+}
+
+extern "C" int vslam_get_template(vslam_system* sys, int s, int point, uint8_t* tmpl, int* sum, int* sumsq, int* bad) {
+  CHK_STREAM(sys, s);
+  const int P = sys->p.max_points, PS = sys->p.patch_size;
+  if (point < 0 || point >= P) return VSLAM_E_INVALID;
+  TrackData td;
+  HIPCHK(hipStreamSynchronize(sys->stream));
+  HIPCHK(hipMemcpy(&td, sys->map.td + (size_t)s * P + point, sizeof(td), hipMemcpyDeviceToHost));
+  if (tmpl) HIPCHK(hipMemcpy(tmpl, sys->map.tmpl + ((size_t)s * P + point) * TMPL_PITCH, PS * PS, hipMemcpyDeviceToHost));
+  if (sum) *sum = td.tsum;
+  if (sumsq) *sumsq = td.tsumsq;
+  if (bad) *bad = (td.flags & TDF_TMPL_BAD) ? 1 : 0;
+  return (td.flags & TDF_HAVE_LAST) ? 1 : 0;
+}

@@ -102,6 +102,14 @@ extern "C" int vslam_create(const vslam_params* p, vslam_system** out) {
   ALLOC(sys->fr.ncorners, (size_t)S * NLEV);
   ALLOC(sys->fr.nmax, (size_t)S * NLEV);
   ALLOC(sys->fr.overflow, 1);
+  sys->ba_ws = nullptr;
+  {
+    int r = trk_alloc(sys);
+    if (!r) r = ba_alloc(sys);
+    if (!r && hipStreamSynchronize(sys->stream) != hipSuccess) r = VSLAM_E_HIP;
+    if (!r) r = map_init_states(sys);
+    if (r) { vslam_destroy(sys); return r; }
+  }
   if (hipStreamSynchronize(sys->stream) != hipSuccess) { vslam_set_error("create: sync failed"); vslam_destroy(sys); return VSLAM_E_HIP; }
   *out = sys;
   return VSLAM_OK;

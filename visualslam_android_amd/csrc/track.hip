@@ -1,0 +1,765 @@
+// Tracker::TrackMap (jni/Tracker.cc:358-626) for all streams of a system, fully device resident:
+// no host round-trip inside a frame.  One launch per dependent stage, each batched over the streams:
+//
+//   k_pvs      ApplyMotionModel (:781-798) + per map point TrackerData::Project / GetDerivsUnsafe
+//              (jni/TrackerData.h:69-95) + PatchFinder::CalcSearchLevelAndWarpMatrix (jni/PatchFinder.cc:31-68)
+//   k_plan     potentially-visible-set lists per level in map order (the reference's random_shuffle is the
+//              identity permutation here), coarse-stage selection (:399-461) / fine-stage selection (:493-535)
+//   k_search   one wavefront per patch: warped template (MakeTemplateCoarseCont, transform_image), ZMSSD at the
+//              FAST corners of the row-LUT window (FindPatchCoarse/ZMSSDAtPoint) with 8 lanes per candidate and
+//              __shfl reductions, optional inverse-compositional sub-pixel refinement (IterateSubPix*)
+//   k_pose     one workgroup per stream: the 10 Gauss-Newton iterations of a stage (:466-488 / :543-577):
+//              re-projection, 2x6 Jacobians, Tukey sigma (bitonic sort in LDS for the median), weighted normal
+//              equations reduced with wave shuffles, 6x6 solve, SE3 exp; then measurement export, scene depth,
+//              UpdateMotionModel, AssessTrackingQuality and the new-keyframe decision (:594-625, :802-878, :128-132)
+#include "vslam_internal.h"
+
+#define TRK_THREADS 256
+#define SORT_CAP 4096
+
+// ---------------------------------------------------------------------------------------------------------------
+// TrackerData::Project (jni/TrackerData.h:69-87).  Returns true when Cam.Project ran (pr valid).
+DEVFN bool td_project(TrackData& td, const MapPointDev& p, const Pose& pose, const CamModel& cam, CamProj& pr) {
+  td.flags &= ~TDF_IN_IMAGE;
+  double c[3];
+  pose_xform(pose, p.pos, c);
+  td.cam[0] = c[0]; td.cam[1] = c[1]; td.cam[2] = c[2];
+  if (c[2] < 0.001) return false;
+  td.implane[0] = c[0] / c[2]; td.implane[1] = c[1] / c[2];
+  if (td.implane[0] * td.implane[0] + td.implane[1] * td.implane[1] > cam.largest_radius * cam.largest_radius) return false;
+  pr = cam_project(cam, td.implane[0], td.implane[1]);
+  td.image[0] = pr.im[0]; td.image[1] = pr.im[1];
+  if (pr.invalid) return true;
+  if (td.image[0] < 0 || td.image[1] < 0 || td.image[0] > cam.size[0] || td.image[1] > cam.size[1]) return true;
+  td.flags |= TDF_IN_IMAGE;
+  return true;
+}
+
+// TrackerData::ProjectAndDerivs (:98-102); derivatives refreshed only for found points whose projection ran
+// (see oracle/tracker.cpp td_project_and_derivs for the one deliberate deviation).
+DEVFN void td_project_and_derivs(TrackData& td, const MapPointDev& p, const Pose& pose, const CamModel& cam) {
+  CamProj pr;
+  const bool projected = td_project(td, p, pose, cam, pr);
+  if ((td.flags & TDF_FOUND) && projected) cam_derivs(cam, pr, td.derivs);
+}
+
+// TrackerData::CalcJacobian (:107-122)
+DEVFN void td_calc_jacobian(TrackData& td) {
+  const double ooz = 1.0 / td.cam[2];
+  for (int m = 0; m < 6; m++) {
+    double mot[3];
+    generator_field(m, td.cam, mot);
+    const double f0 = (mot[0] - td.cam[0] * mot[2] * ooz) * ooz;
+    const double f1 = (mot[1] - td.cam[1] * mot[2] * ooz) * ooz;
+    td.jac[m] = td.derivs[0] * f0 + td.derivs[1] * f1;
+    td.jac[6 + m] = td.derivs[2] * f0 + td.derivs[3] * f1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TRK_THREADS) void k_pvs(MapDev m, TrackParams tp) {
+  const int s = blockIdx.y;
+  TrackerState* st = &m.st[s];
+  const bool tracking = st->map_good && st->lost_frames < 3;       // jni/Tracker.cc:103-104
+  __shared__ Pose pred;
+  if (threadIdx.x == 0 && tracking) pred = pose_mul(se3_exp(st->velocity), st->pose_final);   // ApplyMotionModel, mbUseSBIInit = false
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->frame++;                                                   // :100
+    st->kf_pending = 0; st->kf_added = 0;
+    if (tracking) {
+      st->start_pose = st->pose_final; st->pose_cur = pred;
+      for (int l = 0; l < NLEV; l++) { st->attempted[l] = 0; st->found[l] = 0; }   // :360-361
+      st->n_search = 0; st->n_coarse = 0; st->n_iter = 0; st->n_l3 = 0; st->coarse_found = 0;
+    }
+  }
+  if (!tracking) return;
+  const int i = blockIdx.x * TRK_THREADS + threadIdx.x;
+  if (i >= st->n_points) return;
+  const MapPointDev& p = m.pts[(size_t)s * tp.max_points + i];
+  TrackData& td = m.td[(size_t)s * tp.max_points + i];
+  td.level = -1;
+  if (p.bad) return;
+  CamProj pr;
+  td_project(td, p, pred, tp.cam, pr);                             // :379-381
+  if (!(td.flags & TDF_IN_IMAGE)) return;
+  cam_derivs(tp.cam, pr, td.derivs);                               // :384 GetDerivsUnsafe
+  // CalcSearchLevelAndWarpMatrix, jni/PatchFinder.cc:31-68
+  const double ooz = 1.0 / td.cam[2];
+  double mr[3], md[3];
+  pose_rot(pred, p.right, mr);
+  pose_rot(pred, p.down, md);
+  const double r0 = mr[0] - td.cam[0] * mr[2] * ooz, r1 = mr[1] - td.cam[1] * mr[2] * ooz;
+  const double d0 = md[0] - td.cam[0] * md[2] * ooz, d1 = md[1] - td.cam[1] * md[2] * ooz;
+  const double* d = td.derivs;
+  td.warp_inv[0] = (d[0] * r0 + d[1] * r1) * ooz; td.warp_inv[2] = (d[2] * r0 + d[3] * r1) * ooz;
+  td.warp_inv[1] = (d[0] * d0 + d[1] * d1) * ooz; td.warp_inv[3] = (d[2] * d0 + d[3] * d1) * ooz;
+  double det = td.warp_inv[0] * td.warp_inv[3] - td.warp_inv[1] * td.warp_inv[2];
+  int level = 0;
+  while (det > 3 && level < NLEV - 1) { level++; det *= 0.25; }
+  if (det > 3 || det < 0.25) { td.flags |= TDF_TMPL_BAD; return; }   // mbTemplateBad = true; return -1
+  td.flags &= ~(TDF_SEARCHED | TDF_FOUND);                         // :389-390
+  td.level = level;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// stage 0: PVS lists + coarse selection; stage 1: fine selection (after the coarse pose update).
+__global__ __launch_bounds__(TRK_THREADS) void k_plan(MapDev m, TrackParams tp, int stage) {
+  const int s = blockIdx.x;
+  TrackerState* st = &m.st[s];
+  if (!(st->map_good && st->lost_frames < 3)) return;
+  const int P = tp.max_points;
+  TrackData* td = m.td + (size_t)s * P;
+  const MapPointDev* pts = m.pts + (size_t)s * P;
+  int* pvs = m.pvs_list + (size_t)s * NLEV * P;
+  int2* slist = m.search_list + (size_t)s * P;
+  int* ilist = m.iter_list + (size_t)s * P;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ int cnt[NLEV];
+  __shared__ int wcnt[TRK_THREADS / 64][NLEV];
+  __shared__ int plan[8];
+  if (stage == 0) {
+    if (threadIdx.x < NLEV) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int n = st->n_points;
+    for (int base = 0; base < n; base += TRK_THREADS) {             // avPVS[l] in map order (:369-392)
+      const int i = base + threadIdx.x;
+      const int lvl = i < n ? td[i].level : -1;
+      unsigned long long b[NLEV];
+      for (int l = 0; l < NLEV; l++) { b[l] = __ballot(lvl == l); if (lane == 0) wcnt[wave][l] = __popcll(b[l]); }
+      __syncthreads();
+      if (lvl >= 0) {
+        int off = cnt[lvl];
+        for (int w = 0; w < wave; w++) off += wcnt[w][lvl];
+        off += __popcll(b[lvl] & ((1ull << lane) - 1ull));
+        pvs[lvl * P + off] = i;
+      }
+      __syncthreads();
+      if (threadIdx.x < NLEV) { int t = cnt[threadIdx.x]; for (int w = 0; w < TRK_THREADS / 64; w++) t += wcnt[w][threadIdx.x]; cnt[threadIdx.x] = t; }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      for (int l = 0; l < NLEV; l++) { st->pvs_count[l] = cnt[l]; st->pvs_head[l] = 0; }
+      unsigned nCoarseMax = tp.coarse_max, nCoarseRange = tp.coarse_range;   // :405-432
+      st->did_coarse = 0;
+      bool bTry = true;
+      if (tp.coarse_disabled || st->msd_vel < tp.coarse_min_vel || nCoarseMax == 0) bTry = false;
+      if (st->just_recovered) { bTry = true; nCoarseMax *= 2; nCoarseRange *= 2; st->just_recovered = 0; }
+      int c3 = 0, c2 = 0;
+      const unsigned n3 = cnt[3], n2 = cnt[2];
+      if (bTry && n3 + n2 > (unsigned)tp.coarse_min) {              // :437-461
+        unsigned take3 = n3 <= nCoarseMax ? n3 : nCoarseMax;
+        st->pvs_head[3] = take3;
+        c3 = take3;
+        if (take3 < nCoarseMax) {
+          const unsigned more = nCoarseMax - take3;
+          if (n2 <= more) { c3 = 0; c2 = n2; st->pvs_head[2] = n2; }   // :454-456 replaces the L3 selection (PTAM bug kept)
+          else { c2 = more; st->pvs_head[2] = more; }
+        }
+      }
+      plan[0] = c3; plan[1] = c2;
+      st->coarse_range = nCoarseRange;
+      st->n_coarse = c3 + c2; st->n_search = c3 + c2; st->n_iter = c3 + c2;
+    }
+    __syncthreads();
+    const int c3 = plan[0], c2 = plan[1];
+    for (int e = threadIdx.x; e < c3 + c2; e += TRK_THREADS) {
+      const int idx = e < c3 ? pvs[3 * P + e] : pvs[2 * P + (e - c3)];
+      slist[e] = make_int2(idx, tp.coarse_subpix_its);
+      ilist[e] = idx;
+    }
+  } else {
+    // fine stage (:493-535)
+    __shared__ Pose pose;
+    if (threadIdx.x == 0) {
+      pose = st->pose_cur;
+      const int nit = st->n_iter;                                    // coarse entries already in vIterationSet
+      const int h3 = st->pvs_head[3], n3 = st->pvs_count[3] - h3;
+      int nother = (st->pvs_count[2] - st->pvs_head[2]) + st->pvs_count[1] + st->pvs_count[0];
+      int nFine = tp.max_patches - (nit + n3);                       // :519-521
+      if (nFine < 0) nFine = 0;
+      if (nother > nFine) nother = nFine;                            // :522-526 (identity shuffle, then chop)
+      plan[0] = nit; plan[1] = n3; plan[2] = nother;
+      st->fine_range = st->did_coarse ? 5 : 10;                      // :495-497
+      st->n_l3 = n3; st->n_search = n3 + nother; st->n_iter = nit + n3 + nother;
+    }
+    __syncthreads();
+    const int nit = plan[0], n3 = plan[1], nother = plan[2];
+    const int h3 = st->pvs_head[3], h2 = st->pvs_head[2];
+    const int r2 = st->pvs_count[2] - h2, r1 = st->pvs_count[1];
+    const int did_coarse = st->did_coarse;
+    for (int e = threadIdx.x; e < n3 + nother; e += TRK_THREADS) {
+      int idx, its;
+      if (e < n3) { idx = pvs[3 * P + h3 + e]; its = tp.fine_subpix_its; }
+      else {
+        const int k = e - n3;                                        // order: level 2, 1, 0 (:512-514)
+        if (k < r2) idx = pvs[2 * P + h2 + k];
+        else if (k < r2 + r1) idx = pvs[1 * P + (k - r2)];
+        else idx = pvs[0 * P + (k - r2 - r1)];
+        its = 0;
+      }
+      if (e < n3 || did_coarse) td_project_and_derivs(td[idx], pts[idx], pose, tp.cam);   // :503-504, :529-532
+      slist[e] = make_int2(idx, its);
+      ilist[nit + e] = idx;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+DEVFN int wave_sum_i(int v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d); return v; }
+DEVFN double wave_sum_d(double v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d); return v; }
+
+struct SearchArgs {
+  const uint8_t* img[NLEV]; size_t img_sstride[NLEV]; int img_pitch[NLEV];   // current frame pyramid
+  const uint32_t* corners[NLEV]; const int* rowlut[NLEV]; const int* ncorners;
+  int w[NLEV], h[NLEV], cap[NLEV];
+  size_t kf_stride[NLEV];       // bytes per keyframe image at level l
+  int kf_pitch[NLEV];
+};
+
+// One wavefront per patch (jni/Tracker.cc:629-674 SearchForPoints body).
+template <int PS>
+__global__ __launch_bounds__(64) void k_search(MapDev m, TrackParams tp, SearchArgs a, int stage) {
+  const int s = blockIdx.y, e = blockIdx.x;
+  TrackerState* st = &m.st[s];
+  if (!(st->map_good && st->lost_frames < 3) || e >= st->n_search) return;
+  constexpr int NPIX = PS * PS, HALF = PS / 2, Q = PS - 2;
+  const int lane = threadIdx.x;
+  const int2 ent = m.search_list[(size_t)s * tp.max_points + e];
+  const int idx = ent.x, nSubPixIts = ent.y;
+  const int nRangeL0 = stage == 0 ? st->coarse_range : st->fine_range;
+  TrackData& td = m.td[(size_t)s * tp.max_points + idx];
+  const MapPointDev& p = m.pts[(size_t)s * tp.max_points + idx];
+  uint8_t* gtmpl = m.tmpl + ((size_t)s * tp.max_points + idx) * TMPL_PITCH;
+  __shared__ uint8_t tmpl[TMPL_PITCH];
+  __shared__ int cand[64];
+  const int level = td.level, scale = 1 << level;
+  int flags = td.flags;
+
+  // ---- MakeTemplateCoarseCont, jni/PatchFinder.cc:79-125 ----
+  double inv[4];
+  inv2(td.warp_inv, inv);
+  const double m2[4] = {inv[0] * scale, inv[1] * scale, inv[2] * scale, inv[3] * scale};
+  bool refresh = !(flags & TDF_HAVE_LAST);
+  for (int i = 0; !refresh && i < 2; i++) {
+    const double dx = m2[i] - td.last_warp[i], dy = m2[2 + i] - td.last_warp[2 + i];
+    if (dx * dx + dy * dy > 0.07 * 0.07) refresh = true;
+  }
+  int tsum, tsumsq;
+  if (refresh) {
+    // transform_image (jni/vision/ImageHandler.cpp:21-113): same accumulated stepping of the sample position
+    const int sl = p.src_level;
+    const uint8_t* src = m.kf_img[sl] + ((size_t)s * tp.max_keyframes + p.src_kf) * a.kf_stride[sl];
+    const int sp = a.kf_pitch[sl], iw = a.w[sl], ih = a.h[sl];
+    const double across[2] = {m2[0], m2[2]}, down[2] = {m2[1], m2[3]};
+    double px = (double)p.irx - (m2[0] * HALF + m2[1] * HALF), py = (double)p.iry - (m2[2] * HALF + m2[3] * HALF);
+    const double cr[2] = {down[0] - PS * across[0], down[1] - PS * across[1]};
+    double myx[2] = {0, 0}, myy[2] = {0, 0};
+    for (int i = 0; i < PS; i++) {
+      for (int j = 0; j < PS; j++) {
+        const int k = i * PS + j;
+        if ((k & 63) == lane) { myx[k >> 6] = px; myy[k >> 6] = py; }
+        px += across[0]; py += across[1];
+      }
+      px += cr[0]; py += cr[1];
+    }
+    int nOutside = 0, sum = 0, sumsq = 0;
+    const float x_bound = (float)(iw - 1), y_bound = (float)(ih - 1);
+    for (int q = 0; q < (NPIX + 63) / 64; q++) {
+      const int k = q * 64 + lane;
+      if (k < NPIX) {
+        double x = myx[q], y = myy[q];
+        int v = 0;
+        if (0 <= x && 0 <= y && x < x_bound && y < y_bound) {
+          const int lx = (int)x, ly = (int)y;                        // sample(), ImageHandler.cpp:12-19
+          x -= lx; y -= ly;
+          const uint8_t* q0 = src + (size_t)ly * sp + lx;
+          v = (uint8_t)((1 - y) * ((1 - x) * q0[0] + x * q0[1]) + y * ((1 - x) * q0[sp] + x * q0[sp + 1]));
+        } else nOutside++;
+        tmpl[k] = (uint8_t)v; gtmpl[k] = (uint8_t)v;
+        sum += v; sumsq += v * v;
+      }
+    }
+    nOutside = wave_sum_i(nOutside);
+    tsum = wave_sum_i(sum); tsumsq = wave_sum_i(sumsq);             // MakeTemplateSums :152-164
+    flags = nOutside ? (flags | TDF_TMPL_BAD) : (flags & ~TDF_TMPL_BAD);
+    flags |= TDF_HAVE_LAST;
+    if (lane == 0) { td.tsum = tsum; td.tsumsq = tsumsq; for (int i = 0; i < 4; i++) td.last_warp[i] = m2[i]; }
+  } else {
+    for (int k = lane; k < NPIX; k += 64) tmpl[k] = gtmpl[k];
+    tsum = td.tsum; tsumsq = td.tsumsq;
+  }
+  __syncthreads();
+  if (flags & TDF_TMPL_BAD) {                                        // jni/Tracker.cc:637-640
+    if (lane == 0) td.flags = flags & ~(TDF_IN_IMAGE | TDF_FOUND);
+    return;
+  }
+  if (lane == 0) atomicAdd(&st->attempted[level], 1);               // :641
+
+  // ---- FindPatchCoarse, jni/PatchFinder.cc:170-235 ----
+  const double irx = td.image[0] / scale, iry = td.image[1] / scale;
+  const unsigned nRange = ((unsigned)nRangeL0 + scale - 1) / scale;
+  int nTop = (int)(iry - nRange);
+  const int nBottomPlusOne = (int)(iry + nRange + 1);
+  const int nLeft = (int)(irx - nRange), nRight = (int)(irx + nRange);
+  const int rows = a.h[level], cols = a.w[level];
+  if (nTop < 0) nTop = 0;
+  int nBestSSD = tp.max_ssd + 1;
+  int bestIdx = 0x7fffffff;
+  unsigned nEval = 0;
+  const uint32_t* corners = a.corners[level] + (size_t)s * a.cap[level];
+  if (!(nTop >= rows) && !(nBottomPlusOne <= 0)) {
+    const int* lut = a.rowlut[level] + (size_t)s * (rows + 1);
+    const int i0 = lut[nTop];
+    const int i1 = nBottomPlusOne >= rows ? a.ncorners[s * NLEV + level] : lut[nBottomPlusOne];
+    const uint8_t* img = a.img[level] + (size_t)s * a.img_sstride[level];
+    const int ip = a.img_pitch[level];
+    const double r2max = (double)(nRange * nRange);
+    const int grp = lane >> 3, sub = lane & 7;
+    for (int base = i0; base < i1; base += 64) {
+      // filter 64 corners at a time (:216-219), compact the survivors in raster order
+      const int ci = base + lane;
+      bool ok = false;
+      if (ci < i1) {
+        const uint32_t c = corners[ci];
+        const int cx = c & 0xFFFF, cy = c >> 16;
+        if (!(cx < nLeft || cx > nRight)) {
+          const double dx = irx - cx, dy = iry - cy;
+          ok = !(dx * dx + dy * dy > r2max);
+        }
+      }
+      const unsigned long long bm = __ballot(ok);
+      const int nc = __popcll(bm);
+      if (ok) cand[__popcll(bm & ((1ull << lane) - 1ull))] = ci;
+      __syncthreads();
+      nEval += nc;
+      // ZMSSDAtPoint (:352-380): 8 candidates at a time, 8 lanes per candidate
+      for (int c0 = 0; c0 < nc; c0 += 8) {
+        const int k = c0 + grp;
+        int ssd = 0x7fffffff, cidx = 0x7fffffff;
+        if (k < nc) {
+          cidx = cand[k];
+          const uint32_t c = corners[cidx];
+          const int cx = c & 0xFFFF, cy = c >> 16;
+          int sA = 0, sQ = 0, sX = 0;
+          const bool inside = cx >= HALF && cy >= HALF && cx < cols - HALF && cy < rows - HALF;   // in_image_with_border
+          if (inside) {
+            const uint8_t* ibase = img + (size_t)(cy - HALF) * ip + (cx - HALF);
+            for (int q = sub; q < NPIX; q += 8) {
+              const int r = q / PS, cc = q - r * PS;
+              const int n = ibase[r * ip + cc], t = tmpl[q];
+              sA += n; sQ += n * n; sX += n * t;
+            }
+          }
+          for (int d = 1; d < 8; d <<= 1) { sA += __shfl_xor(sA, d); sQ += __shfl_xor(sQ, d); sX += __shfl_xor(sX, d); }
+          if (inside) {
+            const int SA = tsum, SB = sA;
+            ssd = ((2 * SA * SB - SA * SA - SB * SB) / NPIX + sQ + tsumsq - 2 * sX);
+          } else ssd = tp.max_ssd + 1;
+        }
+        // first strict minimum in raster order (:223): lexicographic (ssd, corner index) minimum
+        for (int d = 8; d < 64; d <<= 1) {
+          const int os = __shfl_xor(ssd, d), oi = __shfl_xor(cidx, d);
+          if (os < ssd || (os == ssd && oi < cidx)) { ssd = os; cidx = oi; }
+        }
+        if (ssd < nBestSSD) { nBestSSD = ssd; bestIdx = cidx; }
+      }
+      __syncthreads();
+    }
+  }
+  flags |= TDF_SEARCHED;                                             // :645
+  if (lane == 0 && nEval) atomicAdd(&st->n_zmssd, (unsigned long long)nEval);
+  if (!(nBestSSD < tp.max_ssd)) {                                    // :646-649
+    if (lane == 0) td.flags = flags & ~TDF_FOUND;
+    return;
+  }
+  const uint32_t bc = corners[bestIdx];
+  const double coarse[2] = {level_zero_pos((double)(bc & 0xFFFF), level), level_zero_pos((double)(bc >> 16), level)};
+  flags |= TDF_FOUND;
+  if (nSubPixIts <= 0) {                                             // :668-671
+    flags &= ~TDF_SUBPIX;
+    if (lane == 0) {
+      td.flags = flags; td.sqrt_inv_noise = 1.0 / scale; td.vfound[0] = coarse[0]; td.vfound[1] = coarse[1];
+      atomicAdd(&st->found[level], 1);
+    }
+    return;
+  }
+  // ---- MakeSubPixTemplate (:242-271) + IterateSubPixToConvergence (:273-350) ----
+  flags |= TDF_SUBPIX;
+  double gx[2], gy[2];
+  double h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0;
+  for (int q = 0; q < (Q * Q + 63) / 64; q++) {
+    const int k = q * 64 + lane;
+    gx[q] = 0; gy[q] = 0;
+    if (k < Q * Q) {
+      const int x = k / Q + 1, y = k % Q + 1;
+      gx[q] = 0.5 * (tmpl[y * PS + x + 1] - tmpl[y * PS + x - 1]);
+      gy[q] = 0.5 * (tmpl[(y + 1) * PS + x] - tmpl[(y - 1) * PS + x]);
+      h00 += gx[q] * gx[q]; h01 += gx[q] * gy[q]; h02 += gx[q]; h11 += gy[q] * gy[q]; h12 += gy[q]; h22 += 1.0;
+    }
+  }
+  h00 = wave_sum_d(h00); h01 = wave_sum_d(h01); h02 = wave_sum_d(h02);     // quarter-integers: exact in any order
+  h11 = wave_sum_d(h11); h12 = wave_sum_d(h12); h22 = wave_sum_d(h22);
+  const double H[9] = {h00, h01, h02, h01, h11, h12, h02, h12, h22};
+  double Hinv[9];
+  inv3(H, Hinv);
+  double sub0 = coarse[0], sub1 = coarse[1], meanDiff = 0.0;
+  const uint8_t* img = a.img[level] + (size_t)s * a.img_sstride[level];
+  const int ip = a.img_pitch[level];
+  bool converged = false;
+  for (int it = 0; it < nSubPixIts; it++) {
+    const double cx = level_n_pos(sub0, level), cy = level_n_pos(sub1, level);
+    const int xb = (int)(cx > 0.0 ? cx + 0.5 : cx - 0.5), yb = (int)(cy > 0.0 ? cy + 0.5 : cy - 0.5);
+    const int b = HALF + 1;
+    if (!(xb >= b && yb >= b && xb < cols - b && yb < rows - b)) break;         // went off edge -> fail
+    const double bx = cx - HALF, by = cy - HALF;
+    const double dX = bx - floor(bx), dY = by - floor(by);
+    const float fTL = (float)((1.0 - dX) * (1.0 - dY)), fTR = (float)((dX) * (1.0 - dY));
+    const float fBL = (float)((1.0 - dX) * (dY)), fBR = (float)((dX) * (dY));
+    double a0 = 0, a1 = 0, a2 = 0;
+    for (int q = 0; q < (Q * Q + 63) / 64; q++) {
+      const int k = q * 64 + lane;
+      if (k < Q * Q) {
+        const int x = k / Q + 1, y = k % Q + 1;
+        const uint8_t* tl = img + (size_t)((int)by + y) * ip + (int)bx + x;
+        const float fPixel = fTL * tl[0] + fTR * tl[1] + fBL * tl[ip] + fBR * tl[ip + 1];
+        const double dDiff = (fPixel - (float)tmpl[y * PS + x]) + meanDiff;
+        a0 += dDiff * gx[q]; a1 += dDiff * gy[q]; a2 += dDiff;
+      }
+    }
+    a0 = wave_sum_d(a0); a1 = wave_sum_d(a1); a2 = wave_sum_d(a2);
+    const double u0 = Hinv[0] * a0 + Hinv[1] * a1 + Hinv[2] * a2;
+    const double u1 = Hinv[3] * a0 + Hinv[4] * a1 + Hinv[5] * a2;
+    const double u2 = Hinv[6] * a0 + Hinv[7] * a1 + Hinv[8] * a2;
+    sub0 -= u0 * scale; sub1 -= u1 * scale; meanDiff -= u2;
+    if (u0 * u0 + u1 * u1 < 0.03 * 0.03) { converged = true; break; }
+  }
+  if (lane == 0) {
+    if (!converged) td.flags = flags & ~TDF_FOUND;                   // :658-666 un-finds the point
+    else {
+      td.flags = flags; td.sqrt_inv_noise = 1.0 / scale; td.vfound[0] = sub0; td.vfound[1] = sub1;
+      atomicAdd(&st->found[level], 1);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Block-wide helpers for k_pose
+DEVFN void bitonic_sort_lds(double* buf, int npad) {
+  for (int k = 2; k <= npad; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < npad; i += TRK_THREADS) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const double x = buf[i], y = buf[ixj];
+          const bool up = (i & k) == 0;
+          if ((x > y) == up) { buf[i] = y; buf[ixj] = x; }
+        }
+      }
+      __syncthreads();
+    }
+}
+
+// CalcPoseUpdate, jni/Tracker.cc:683-774 (Tukey).  All threads of the workgroup call it; result in up[6] (LDS).
+DEVFN void calc_pose_update(TrackData* td, MapPointDev* pts, const int* ilist, int n, const TrackParams& tp,
+                            double dOverrideSigma, bool bMarkOutliers, double* sortbuf, double* red /* [4][28] */,
+                            double* up /* [6] */, int* icnt) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int npad = 64;
+  while (npad < n) npad <<= 1;
+  int nvalid = 0;
+  for (int e = threadIdx.x; e < npad; e += TRK_THREADS) {
+    double e2 = __builtin_huge_val();
+    if (e < n) {
+      TrackData& t = td[ilist[e]];
+      if (t.flags & TDF_FOUND) {
+        t.err[0] = (t.vfound[0] - t.image[0]) * t.sqrt_inv_noise;   // :707
+        t.err[1] = (t.vfound[1] - t.image[1]) * t.sqrt_inv_noise;
+        e2 = t.err[0] * t.err[0] + t.err[1] * t.err[1];
+        nvalid++;
+      }
+    }
+    sortbuf[e] = e2;
+  }
+  nvalid = wave_sum_i(nvalid);
+  if (lane == 0) icnt[wave] = nvalid;
+  __syncthreads();
+  nvalid = icnt[0] + icnt[1] + icnt[2] + icnt[3];
+  if (nvalid == 0) {                                                // :712-716
+    if (threadIdx.x < 6) up[threadIdx.x] = 0.0;
+    __syncthreads();
+    return;
+  }
+  double sigma2;
+  if (dOverrideSigma > 0) sigma2 = dOverrideSigma;                  // :720-721
+  else {
+    bitonic_sort_lds(sortbuf, npad);                                // Tukey::FindSigmaSquared, jni/MEstimator.h:67-77
+    sigma2 = tukey_sigma_squared(sortbuf[nvalid / 2], (unsigned long)nvalid);
+  }
+  const bool qint = (tp.quirks & VSLAM_Q_POSE_INT_RESIDUAL) != 0;
+  double acc[27];
+  for (int i = 0; i < 27; i++) acc[i] = 0.0;
+  for (int e = threadIdx.x; e < n; e += TRK_THREADS) {
+    const int idx = ilist[e];
+    TrackData& t = td[idx];
+    if (!(t.flags & TDF_FOUND)) continue;
+    const double es = t.err[0] * t.err[0] + t.err[1] * t.err[1];
+    const double w = tukey_weight(es, sigma2);
+    if (w == 0.0) { if (bMarkOutliers) pts[idx].n_out++; continue; }   // :749-756
+    else if (bMarkOutliers) pts[idx].n_in++;
+    for (int row = 0; row < 2; row++) {                              // wls.add_mJ x2 (:766-767), jni/myWLS.h:39-50
+      const double mm = qint ? (double)(int)t.err[row] : t.err[row];
+      double J[6];
+      for (int k = 0; k < 6; k++) J[k] = t.sqrt_inv_noise * t.jac[row * 6 + k];
+      int q = 0;
+      for (int r = 0; r < 6; r++) {
+        const double Jw = w * J[r];
+        acc[21 + r] += mm * Jw;
+        for (int c = r; c < 6; c++) acc[q++] += Jw * J[c];
+      }
+    }
+  }
+  for (int i = 0; i < 27; i++) { const double v = wave_sum_d(acc[i]); if (lane == 0) red[wave * 28 + i] = v; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double C[36], v[6];
+    int q = 0;
+    for (int r = 0; r < 6; r++)
+      for (int c = r; c < 6; c++) {
+        const double x = ((red[q] + red[28 + q]) + red[56 + q]) + red[84 + q];
+        C[r * 6 + c] = x; C[c * 6 + r] = x; q++;
+      }
+    for (int r = 0; r < 6; r++) { C[r * 6 + r] += tp.wls_prior; v[r] = ((red[21 + r] + red[28 + 21 + r]) + red[56 + 21 + r]) + red[84 + 21 + r]; }   // add_prior(100), :734
+    if (!lu_solve_n(C, v, 6)) for (int r = 0; r < 6; r++) v[r] = 0.0;
+    for (int r = 0; r < 6; r++) up[r] = v[r];
+  }
+  __syncthreads();
+}
+
+// KeyFrameLinearDist, jni/MapMaker.cc:705-712
+DEVFN double kf_linear_dist(const Pose& a, const Pose& b) {
+  const Pose ia = pose_inverse(a), ib = pose_inverse(b);
+  const double d0 = ib.t[0] - ia.t[0], d1 = ib.t[1] - ia.t[1], d2 = ib.t[2] - ia.t[2];
+  return sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+}
+
+// stage 0: coarse GN iterations (:463-490); stage 1: fine GN iterations + end of TrackMap/TrackFrame.
+__global__ __launch_bounds__(TRK_THREADS) void k_pose(MapDev m, TrackParams tp, int stage) {
+  const int s = blockIdx.x;
+  TrackerState* st = &m.st[s];
+  if (!(st->map_good && st->lost_frames < 3)) return;
+  const int P = tp.max_points;
+  TrackData* td = m.td + (size_t)s * P;
+  MapPointDev* pts = m.pts + (size_t)s * P;
+  const int* ilist = m.iter_list + (size_t)s * P;
+  __shared__ double sortbuf[SORT_CAP];
+  __shared__ double red[4 * 28];
+  __shared__ double up[6], last_up[6];
+  __shared__ int icnt[4];
+  __shared__ Pose pose;
+  if (threadIdx.x == 0) pose = st->pose_cur;
+  __syncthreads();
+  if (stage == 0) {
+    const int n = st->n_coarse;
+    if (n == 0) return;
+    const int nFound = st->found[0] + st->found[1] + st->found[2] + st->found[3];
+    if (nFound < tp.coarse_min) return;                              // :465
+    for (int iter = 0; iter < 10; iter++) {
+      for (int e = threadIdx.x; e < n; e += TRK_THREADS) {
+        TrackData& t = td[ilist[e]];
+        if (!(t.flags & TDF_FOUND)) continue;
+        if (iter != 0) td_project_and_derivs(t, pts[ilist[e]], pose, tp.cam);
+        td_calc_jacobian(t);
+      }
+      __syncthreads();
+      calc_pose_update(td, pts, ilist, n, tp, iter > 5 ? 1.0 : 0.0, false, sortbuf, red, up, icnt);
+      if (threadIdx.x == 0) pose = pose_mul(se3_exp(up), pose);      // :487
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) { st->pose_cur = pose; st->did_coarse = 1; }
+    return;
+  }
+  const int n = st->n_iter;
+  if (threadIdx.x < 6) last_up[threadIdx.x] = 0.0;
+  __syncthreads();
+  for (int iter = 0; iter < 10; iter++) {                            // :543-577
+    const bool nonlinear = (iter == 0 || iter == 4 || iter == 9);
+    for (int e = threadIdx.x; e < n; e += TRK_THREADS) {
+      TrackData& t = td[ilist[e]];
+      if (!(t.flags & TDF_FOUND)) continue;
+      if (iter != 0) {
+        if (nonlinear) td_project_and_derivs(t, pts[ilist[e]], pose, tp.cam);
+        else {                                                       // LinearUpdate, jni/TrackerData.h:125-131
+          double a = 0, b = 0;
+          for (int k = 0; k < 6; k++) { a += t.jac[k] * last_up[k]; b += t.jac[6 + k] * last_up[k]; }
+          t.image[0] += a; t.image[1] += b;
+        }
+      }
+      if (nonlinear) td_calc_jacobian(t);
+    }
+    __syncthreads();
+    calc_pose_update(td, pts, ilist, n, tp, iter > 5 ? 16.0 : 0.0, iter == 9, sortbuf, red, up, icnt);
+    if (threadIdx.x == 0) pose = pose_mul(se3_exp(up), pose);
+    if (threadIdx.x < 6) last_up[threadIdx.x] = up[threadIdx.x];
+    __syncthreads();
+  }
+  // ---- measurement export (:594-607) and scene depth (:610-625) ----
+  MeasDev* cm = m.cur_meas + (size_t)s * P;
+  for (int i = threadIdx.x; i < st->n_points; i += TRK_THREADS) cm[i].valid = 0;
+  __syncthreads();
+  double dSum = 0, dSumSq = 0; int nNum = 0;
+  for (int e = threadIdx.x; e < n; e += TRK_THREADS) {
+    const int idx = ilist[e];
+    const TrackData& t = td[idx];
+    if (!(t.flags & TDF_FOUND)) continue;
+    MeasDev mm;
+    mm.root[0] = t.vfound[0]; mm.root[1] = t.vfound[1];
+    mm.valid = 1; mm.level = (signed char)t.level; mm.subpix = (t.flags & TDF_SUBPIX) ? 1 : 0; mm.source = 0 /* SRC_TRACKER */; mm.pad = 0;
+    cm[idx] = mm;
+    const double z = t.cam[2];
+    dSum += z; dSumSq += z * z; nNum++;
+  }
+  dSum = wave_sum_d(dSum); dSumSq = wave_sum_d(dSumSq); nNum = wave_sum_i(nNum);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[wave * 28] = dSum; red[wave * 28 + 1] = dSumSq; icnt[wave] = nNum; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  dSum = ((red[0] + red[28]) + red[56]) + red[84];
+  dSumSq = ((red[1] + red[29]) + red[57]) + red[85];
+  nNum = icnt[0] + icnt[1] + icnt[2] + icnt[3];
+  if (nNum > 20) {
+    st->depth_mean = dSum / nNum;
+    st->depth_sigma = sqrt((dSumSq / nNum) - (st->depth_mean) * (st->depth_mean));
+  }
+  st->pose_cur = pose; st->pose_final = pose;
+  {                                                                  // UpdateMotionModel, :802-820
+    const Pose nfo = pose_mul(pose, pose_inverse(st->start_pose));
+    double motion[6];
+    se3_ln(nfo, motion);
+    double ss = 0;
+    for (int i = 0; i < 6; i++) {
+      st->velocity[i] = 0.9 * (0.5 * motion[i] + 0.5 * st->velocity[i]);
+      double v = st->velocity[i];
+      if (i < 3) v *= 1.0 / st->depth_mean;
+      ss += v * v;
+    }
+    st->msd_vel = sqrt(ss);
+  }
+  const Pose* kfp = m.kf_pose + (size_t)s * tp.max_keyframes;
+  double closest = 9999999999.9;                                     // ClosestKeyFrame, jni/MapMaker.cc:737-758
+  for (int k = 0; k < st->n_kf; k++) { const double d = kf_linear_dist(pose, kfp[k]); if (d < closest) closest = d; }
+  {                                                                  // AssessTrackingQuality, :832-878
+    int ta = 0, tf = 0, la = 0, lf = 0;
+    for (int i = 0; i < NLEV; i++) { ta += st->attempted[i]; tf += st->found[i]; if (i >= 2) { la += st->attempted[i]; lf += st->found[i]; } }
+    int quality;
+    if (tf == 0 || ta == 0) quality = 0;
+    else {
+      const double dTotal = (double)tf / ta;
+      const double dLarge = la > 10 ? (double)lf / la : dTotal;
+      if (dTotal > 0.3) quality = 2; else if (dLarge < 0.13) quality = 0; else quality = 1;
+    }
+    if (quality == 1 && closest > tp.wiggle_scale * 10.0) quality = 0;   // IsDistanceToNearestKeyFrameExcessive
+    if (quality == 0) st->lost_frames++; else st->lost_frames = 0;
+    st->quality = quality;
+  }
+  {                                                                  // jni/Tracker.cc:128-132 + NeedNewKeyFrame, jni/MapMaker.cc:761-773
+    double dDist = closest;
+    dDist *= (1.0 / st->depth_mean);
+    const bool need = dDist > tp.max_kf_dist_wiggle_mult * st->wiggle_depth_norm;
+    if (st->quality == 2 && need && st->frame - st->last_kf_dropped > tp.min_frames_between_kf && st->n_kf < tp.max_keyframes) {
+      st->kf_pending = 1;
+      st->last_kf_dropped = st->frame;
+    }
+  }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+template <class T>
+static int dalloc(vslam_system* sys, T** out, size_t count) {
+  void* ptr = nullptr;
+  HIPCHK(hipMalloc(&ptr, count * sizeof(T) + 64));
+  HIPCHK(hipMemsetAsync(ptr, 0, count * sizeof(T) + 64, sys->stream));
+  sys->allocs.push_back(ptr);
+  *out = (T*)ptr;
+  return VSLAM_OK;
+}
+#define TALLOC(ptr, count) do { int _r = dalloc(sys, &(ptr), (count)); if (_r) return _r; } while (0)
+
+int trk_alloc(vslam_system* sys) {
+  const vslam_params& p = sys->p;
+  const size_t S = sys->S, P = p.max_points, K = p.max_keyframes;
+  if (P > SORT_CAP) { vslam_set_error("max_points %d exceeds %d", (int)P, SORT_CAP); return VSLAM_E_INVALID; }
+  MapDev& m = sys->map;
+  TALLOC(m.pts, S * P); TALLOC(m.td, S * P); TALLOC(m.tmpl, S * P * TMPL_PITCH);
+  TALLOC(m.kf_meas, S * K * P); TALLOC(m.cur_meas, S * P);
+  TALLOC(m.kf_pose, S * K); TALLOC(m.kf_fixed, S * K); TALLOC(m.kf_depth, S * K * 2);
+  for (int l = 0; l < NLEV; l++) TALLOC(m.kf_img[l], S * K * (size_t)sys->geom[l].pitch * sys->geom[l].h);
+  TALLOC(m.st, S); TALLOC(m.pvs_list, S * NLEV * P); TALLOC(m.search_list, S * P); TALLOC(m.iter_list, S * P);
+  trk_fill_params(p, sys->tp);
+  return VSLAM_OK;
+}
+
+// device parameter block; camera per ATANCamera::RefreshParams (jni/ATANCamera.cc:37-82)
+void trk_fill_params(const vslam_params& p, TrackParams& t) {
+  {
+  CamModel& c = t.cam;
+  c.size[0] = p.width; c.size[1] = p.height;
+  c.focal[0] = c.size[0] * p.cam[0]; c.focal[1] = c.size[1] * p.cam[1];
+  c.center[0] = c.size[0] * p.cam[2] - 0.5; c.center[1] = c.size[1] * p.cam[3] - 0.5;
+  c.w = p.cam[4];
+  double one_over_2tan = 0;
+  if (c.w != 0.0) { c.two_tan = 2.0 * tan(c.w / 2.0); one_over_2tan = 1.0 / c.two_tan; c.winv = 1.0 / c.w; c.distortion_enabled = 1.0; }
+  else { c.winv = 0; c.two_tan = 0; c.distortion_enabled = 0; }
+  double v2[2];
+  if (p.quirks & VSLAM_Q_CAM_INT_RADIUS) {   // :70-78 int-typed operands (quirk #5)
+    int m1 = (int)p.cam[2], m2 = (int)(1.0 - p.cam[2]);
+    v2[0] = (m1 > m2 ? m1 : m2) / p.cam[0];
+    m1 = (int)p.cam[3]; m2 = (int)(1.0 - p.cam[3]);
+    v2[1] = (m1 > m2 ? m1 : m2) / p.cam[1];
+  } else {
+    v2[0] = (p.cam[2] > 1.0 - p.cam[2] ? p.cam[2] : 1.0 - p.cam[2]) / p.cam[0];
+    v2[1] = (p.cam[3] > 1.0 - p.cam[3] ? p.cam[3] : 1.0 - p.cam[3]) / p.cam[1];
+  }
+  const double rr = sqrt(v2[0] * v2[0] + v2[1] * v2[1]);
+  c.largest_radius = c.w == 0.0 ? rr : tan(rr * c.w) * one_over_2tan;   // invrtrans, jni/ATANCamera.h:145-150
+  c.max_r = 1.5 * c.largest_radius;
+  }
+  t.P = p.patch_size; t.max_ssd = 500 * p.patch_size * p.patch_size;
+  t.max_patches = p.max_patches_per_frame; t.coarse_min = p.coarse_min; t.coarse_max = p.coarse_max; t.coarse_range = p.coarse_range;
+  t.coarse_subpix_its = p.coarse_subpix_its; t.coarse_disabled = p.coarse_disabled; t.fine_subpix_its = p.fine_subpix_its;
+  t.coarse_min_vel = p.coarse_min_vel; t.wls_prior = p.wls_prior;
+  t.min_frames_between_kf = p.min_frames_between_kf; t.max_kf_dist_wiggle_mult = p.max_kf_dist_wiggle_mult; t.wiggle_scale = p.wiggle_scale;
+  t.ba_max_iterations = p.ba_max_iterations; t.ba_convergence_limit = p.ba_convergence_limit;
+  t.ba_min_sigma2 = p.ba_min_tukey_sigma * p.ba_min_tukey_sigma; t.ba_window = p.ba_window; t.ba_min_keyframes = p.ba_min_keyframes;
+  t.quirks = p.quirks; t.max_points = p.max_points; t.max_keyframes = p.max_keyframes;
+
+}
+
+int trk_track_map(vslam_system* sys) {
+  const int S = sys->S, P = sys->p.max_points;
+  MapDev& m = sys->map;
+  const TrackParams& tp = sys->tp;
+  SearchArgs a;
+  for (int l = 0; l < NLEV; l++) {
+    a.img[l] = sys->fr.img[l]; a.img_sstride[l] = sys->fr.img_sstride[l]; a.img_pitch[l] = sys->fr.img_pitch[l];
+    a.corners[l] = sys->fr.corners[l]; a.rowlut[l] = sys->fr.rowlut[l];
+    a.w[l] = sys->geom[l].w; a.h[l] = sys->geom[l].h; a.cap[l] = sys->geom[l].cap;
+    a.kf_pitch[l] = sys->geom[l].pitch; a.kf_stride[l] = (size_t)sys->geom[l].pitch * sys->geom[l].h;
+  }
+  a.ncorners = sys->fr.ncorners;
+  const int maxSearch = tp.max_patches + 2 * tp.coarse_max < P ? tp.max_patches + 2 * tp.coarse_max : P;
+  hipLaunchKernelGGL(k_pvs, dim3((P + TRK_THREADS - 1) / TRK_THREADS, S), dim3(TRK_THREADS), 0, sys->stream, m, tp);
+  hipLaunchKernelGGL(k_plan, dim3(S), dim3(TRK_THREADS), 0, sys->stream, m, tp, 0);
+  if (!tp.coarse_disabled) {
+    const int nc = 2 * tp.coarse_max;
+    if (tp.P == 8) hipLaunchKernelGGL(k_search<8>, dim3(nc, S), dim3(64), 0, sys->stream, m, tp, a, 0);
+    else hipLaunchKernelGGL(k_search<11>, dim3(nc, S), dim3(64), 0, sys->stream, m, tp, a, 0);
+    hipLaunchKernelGGL(k_pose, dim3(S), dim3(TRK_THREADS), 0, sys->stream, m, tp, 0);
+  }
+  hipLaunchKernelGGL(k_plan, dim3(S), dim3(TRK_THREADS), 0, sys->stream, m, tp, 1);
+  if (tp.P == 8) hipLaunchKernelGGL(k_search<8>, dim3(maxSearch, S), dim3(64), 0, sys->stream, m, tp, a, 1);
+  else hipLaunchKernelGGL(k_search<11>, dim3(maxSearch, S), dim3(64), 0, sys->stream, m, tp, a, 1);
+  hipLaunchKernelGGL(k_pose, dim3(S), dim3(TRK_THREADS), 0, sys->stream, m, tp, 1);
+  HIPCHK(hipGetLastError());
+  return VSLAM_OK;
+}

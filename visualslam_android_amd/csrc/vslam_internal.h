@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 #include "../../include/vslam_c.h"
+#include "dev_math.h"
 
 #define NLEV VSLAM_LEVELS
 
@@ -47,6 +48,79 @@ struct FrameDev {
   int* nmax;                        // [S][NLEV]
 };
 
+
+// ---- map + tracker state (all device resident) -------------------------------------------------------------------
+#define TMPL_PITCH 128      // bytes reserved per cached template (11 x 11 = 121)
+
+struct MapPointDev {        // MapPoint, jni/MapPoint.h:22-69
+  double pos[3], right[3], down[3];   // v3WorldPos, v3PixelRight_W, v3PixelDown_W
+  int src_kf, src_level, irx, iry;    // pPatchSourceKF, nSourceLevel, irCenter
+  int bad, n_in, n_out, n_meas_kfs;   // bBad, nMEstimatorInlier/OutlierCount, |MapMakerData::sMeasurementKFs|
+};
+
+#define TDF_IN_IMAGE 1
+#define TDF_FOUND 2
+#define TDF_SEARCHED 4
+#define TDF_SUBPIX 8
+#define TDF_TMPL_BAD 16
+#define TDF_HAVE_LAST 32
+
+struct TrackData {          // TrackerData (jni/TrackerData.h:36-66) + persistent PatchFinder state (jni/PatchFinder.h:96-128)
+  double cam[3], implane[2], image[2], derivs[4];
+  double vfound[2], sqrt_inv_noise, err[2], jac[12];
+  double warp_inv[4], last_warp[4];
+  int level, flags, tsum, tsumsq;
+};
+
+struct MeasDev {            // Measurement, jni/KeyFrame.h:46-51 (one slot per keyframe x map point)
+  double root[2];
+  signed char valid, level, subpix, source;
+  int pad;
+};
+
+struct TrackerState {       // Tracker members, jni/Tracker.h:77-150 (+ MapMaker flags used by the BA driver)
+  Pose pose_final, start_pose, pose_cur;
+  double velocity[6];
+  double msd_vel, depth_mean, depth_sigma, wiggle_depth_norm;
+  int frame, last_kf_dropped, lost_frames, quality;
+  int attempted[NLEV], found[NLEV];
+  int did_coarse, just_recovered, map_good, kf_pending;
+  int n_points, n_kf;
+  int pvs_count[NLEV], pvs_head[NLEV];
+  int n_coarse, n_search, n_iter, n_l3;
+  int coarse_range, fine_range, coarse_found;
+  int ba_accepted, kf_added, ba_converged_recent, ba_converged_full;
+  unsigned long long n_zmssd, n_ba_trials;
+};
+
+struct TrackParams {        // device copy of the tunables the kernels read
+  CamModel cam;
+  int P;                    // patch size
+  int max_ssd;              // 500 * P * P (jni/PatchFinder.cc:19-20)
+  int max_patches, coarse_min, coarse_max, coarse_range, coarse_subpix_its, coarse_disabled, fine_subpix_its;
+  double coarse_min_vel, wls_prior;
+  int min_frames_between_kf; double max_kf_dist_wiggle_mult, wiggle_scale;
+  int ba_max_iterations; double ba_convergence_limit, ba_min_sigma2; int ba_window, ba_min_keyframes;
+  int quirks;
+  int max_points, max_keyframes;
+};
+
+struct MapDev {             // device pointers of the map + tracker of all streams
+  MapPointDev* pts;         // [S][max_points]
+  TrackData* td;            // [S][max_points]
+  uint8_t* tmpl;            // [S][max_points][TMPL_PITCH]
+  MeasDev* kf_meas;         // [S][max_keyframes][max_points]
+  MeasDev* cur_meas;        // [S][max_points]            mCurrentKF.mMeasurements
+  Pose* kf_pose;            // [S][max_keyframes]
+  int* kf_fixed;            // [S][max_keyframes]
+  double* kf_depth;         // [S][max_keyframes][2]
+  uint8_t* kf_img[NLEV];    // [S][max_keyframes][h*pitch]
+  TrackerState* st;         // [S]
+  int* pvs_list;            // [S][NLEV][max_points]
+  int2* search_list;        // [S][max_points]  (point index, sub-pixel iterations)
+  int* iter_list;           // [S][max_points]  vIterationSet
+};
+
 struct vslam_system {
   vslam_params p;
   int S;
@@ -56,9 +130,23 @@ struct vslam_system {
   uint8_t* d_lvl[NLEV];        // owned level images (level 0 = staging copy for host input)
   std::vector<void*> allocs;   // everything to hipFree
   bool have_frame;
+  TrackParams tp;
+  MapDev map;
+  void* ba_ws;                 // bundle-adjustment workspace (ba.hip)
 };
 
 // frontend.hip
 int fe_make_keyframe_lite(vslam_system* sys, const uint8_t* gray, size_t row_stride, size_t stream_stride,
                           int on_device);
 int fe_fast_nonmax(vslam_system* sys);
+// track.hip
+void trk_fill_params(const vslam_params& p, TrackParams& t);
+int trk_alloc(vslam_system* sys);
+int trk_track_map(vslam_system* sys);
+// ba.hip
+int ba_alloc(vslam_system* sys);
+int ba_add_keyframe_and_adjust(vslam_system* sys);
+int ba_run(vslam_system* sys, int mode);
+// map.hip
+int map_init_states(vslam_system* sys);
+
