@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X PTAM hot path: frames/sec of Tracker::TrackFrame + local bundle adjustment.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one vslam_track_frame over one batch of frames: every one of the S independent sequences (streams) on
+this GPU advances by one 640x480 frame -- MakeKeyFrame_Lite (pyramid + FAST-10), TrackMap (PVS, patch search, 10+10
+Gauss-Newton iterations), and, whenever the tracker asks for a keyframe (every ~21 frames per stream),
+MapMaker::AddKeyFrame + one BundleAdjustRecent, all on device.  Frames are synthetic (seeded feeder) and resident in
+HBM before the timed region.  Sequences shard across GPUs with no data-path collective (weak scaling); RCCL is used only
+to gather the per-rank statistics and the max-over-ranks time.
+
+Prints ONE JSON line (rank 0) with `roofline` for the dominant kernel (HIP-event time measured live over the timed
+region on the library's own stream) and `cpu_baseline` (the oracle's TrackFrame+BA on one host core, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def dist_env():
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+
+
+def aggregate(elapsed_s, stats, world):
+    """max-over-ranks time and gathered per-rank stats (RCCL all_gather of a small fp64 vector; gloo in CPU tests)."""
+    import torch
+    import torch.distributed as dist
+    if world == 1 or not dist.is_initialized():
+        return elapsed_s, [list(stats)]
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([elapsed_s], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    mine = torch.tensor(list(stats), dtype=torch.float64, device=dev)
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return float(t.item()), [o.cpu().tolist() for o in out]
+
+
+def algorithmic_bytes(stage, S, W, H, P, per_stream):
+    """SURVEY.md 8(d) algorithmic bytes of ONE launch of `stage` over S streams (per-stream averages in per_stream)."""
+    ncorn, npatch, nzm, nfound, ba_m, ba_c, ba_p, ba_trials_per_launch = (per_stream[k] for k in
+        ("corners", "patches", "zmssd", "found", "ba_meas", "ba_cams", "ba_pts", "ba_trials_per_launch"))
+    hsum = sum(H >> l for l in range(4))
+    b_fast = W * H * (1 + 21.0 / 64.0) + 4 * ncorn + 4 * hsum
+    b_patch = P * P * (npatch + nzm) + 48 * npatch
+    b_pose = 10 * (nfound * 120 + 216)
+    b_ba = ba_trials_per_launch * (ba_m * 176 + ba_c * 312 + ba_p * 168)
+    table = {"pyr_fast0": W * H * (1 + 21.0 / 64.0) + (W * H) / 8.0, "fast_lvl": W * H * (21.0 / 64.0) * (1 + 1 / 8.0),
+             "compact": 4 * ncorn + 4 * hsum + (W * H * (1 + 21.0 / 64.0)) / 8.0,
+             "search_fine": b_patch, "search_coarse": 0.0, "pose_fine": b_pose, "pose_coarse": 0.0, "ba_compute": b_ba,
+             "fast_stage": b_fast}
+    return S * table.get(stage, 0.0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("VSLAM_BENCH_STREAMS", 64)), help="sequences per GPU")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--patch", type=int, default=8, help="PatchFinder template side (BASELINE configs: 8; reference default 11)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
+    ap.add_argument("--no-events", action="store_true", help="skip the per-stage HIP events in the timed region")
+    args = ap.parse_args()
+    rank, world, local_rank = dist_env()
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from visualslam_android_amd import capi, feeder
+    S, W, H, K, Wm = args.streams, args.width, args.height, args.steps, args.warmup
+    T = Wm + K
+    nthreads = min(16, os.cpu_count() or 8)
+
+    # ---- synthetic scenes: one seeded feeder, trajectory and ground-truth map per stream -----------------------------
+    t_setup = time.time()
+    seeds = [1234 + rank * S + s for s in range(S)]
+    with ThreadPoolExecutor(nthreads) as ex:
+        feeders = list(ex.map(lambda sd: feeder.Feeder(W, H, seed=sd), seeds))
+    vp = capi.default_params(W, H, S, patch_size=args.patch, device=local_rank)
+    fe = capi.System(capi.default_params(W, H, 1, patch_size=args.patch, device=local_rank))   # front-end used to pick map corners
+
+    def corner_fn(gray):
+        fe.make_keyframe_lite(gray[None])
+        fe.fast_nonmax()
+        return [fe.read_max_corners(0, l)[0] for l in range(4)]
+
+    maps = [feeder.build_map(f, corner_fn) for f in feeders]
+    fe.close()
+    sysm = capi.System(vp)
+    for s in range(S):
+        sysm.load_map(s, maps[s])
+        sysm.set_pose(s, feeders[s].pose(-1))
+    frames_dev = torch.empty((T, S, H, W), dtype=torch.uint8, device="cuda")
+    host_frames0 = None
+    with ThreadPoolExecutor(max(1, nthreads // 4)) as ex:
+        for s, fr in enumerate(ex.map(lambda f: f.render(0, T, threads=4), feeders)):
+            frames_dev[:, s].copy_(torch.from_numpy(fr))
+            if s == 0:
+                host_frames0 = fr
+    torch.cuda.synchronize()
+    setup_s = time.time() - t_setup
+    base = frames_dev.data_ptr()
+    fstride = S * H * W
+
+    def step(t):
+        sysm.track_frame_device(base + t * fstride, W, H * W)
+
+    # ---- warm-up, then the timed region ---------------------------------------------------------------------------------
+    for t in range(Wm):
+        step(t)
+    sysm.synchronize()
+    st0 = [sysm.state(s) for s in range(S)]
+    if not args.no_events:
+        sysm.profile_begin(K)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(Wm, T):
+        step(t)
+    sysm.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    stage_ms, nprof = ({}, 0) if args.no_events else sysm.profile_end()
+    st1 = [sysm.state(s) for s in range(S)]
+
+    # ---- per-stream workload statistics (for the algorithmic-byte formulas) ---------------------------------------------
+    zm = float(np.mean([(b.n_zmssd - a.n_zmssd) / K for a, b in zip(st0, st1)]))
+    att = float(np.mean([sum(b.attempted) for b in st1]))
+    fnd = float(np.mean([sum(b.found) for b in st1]))
+    kf_adds = float(np.mean([b.n_keyframes - a.n_keyframes for a, b in zip(st0, st1)]))
+    ba_trials = float(np.mean([b.n_ba_trials - a.n_ba_trials for a, b in zip(st0, st1)]))
+    good = int(sum(1 for b in st1 if b.quality == 2))
+    ncorn = float(len(sysm.read_corners(0, 0)))
+    km = sysm.keyframe_meas(0, st1[0].n_keyframes - 1)
+    ba_meas = float(len(km["pt"])) * 5 + 0.0
+    per_stream = {"corners": ncorn, "patches": att, "zmssd": zm, "found": fnd, "ba_meas": ba_meas, "ba_cams": 5.0,
+                  "ba_pts": float(len(km["pt"])), "ba_trials_per_launch": ba_trials / K}
+
+    total_t, gathered = aggregate(elapsed, [elapsed, S * K, zm, att, fnd, kf_adds, ba_trials, good], world)
+    frames_total = sum(g[1] for g in gathered)
+    value = frames_total / total_t
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel (HIP events over the timed region) -----------------------------------------
+        roof = None
+        stages = {}
+        if stage_ms:
+            for name, ms in stage_ms.items():
+                per_launch_ms = ms / max(1, nprof)
+                ab = algorithmic_bytes(name, S, W, H, args.patch, per_stream)
+                stages[name] = {"ms_per_launch": round(per_launch_ms, 5), "algorithmic_GBps": round(ab / (per_launch_ms * 1e-3) / 1e9, 3) if per_launch_ms > 0 and ab > 0 else None}
+            dom = max((n for n in stage_ms if algorithmic_bytes(n, S, W, H, args.patch, per_stream) > 0), key=lambda n: stage_ms[n])
+            dms = stage_ms[dom] / max(1, nprof)
+            ach = algorithmic_bytes(dom, S, W, H, args.patch, per_stream) / (dms * 1e-3) / 1e9
+            roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None, "ms_per_launch": round(dms, 5)}
+        # ---- CPU baseline: the oracle's TrackFrame + BA on one core over a bounded sample of the same frames -------------
+        from oracle import binding as orc
+        o = orc.OracleSystem(orc.params_from_vslam(vp))
+        o.load_map(maps[0])
+        o.set_pose(feeders[0].pose(-1))
+        tc = time.perf_counter()
+        n_cpu = 0
+        for t in range(T):
+            o.track_frame(host_frames0[t])
+            n_cpu += 1
+            if time.perf_counter() - tc > args.cpu_seconds:
+                break
+        cpu_s = time.perf_counter() - tc
+        pose_diff = None
+        if n_cpu == T:
+            pose_diff = float(np.abs(np.array(o.state().pose[:]) - np.array(st1[0].pose[:])).max())
+        out = {
+            "metric": "frames/sec (TrackFrame+local BA) on 640x480 synthetic", "value": round(value, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(1e3 * total_t / K, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %dx%d 4-level FAST-10 + %dx%d PatchFinder ZMSSD search, TrackMap pose update, "
+                                   "AddKeyFrame + BundleAdjustRecent on keyframe frames" % (W, H, args.patch, args.patch),
+                       "streams_per_gpu": S, "patch_size": args.patch, "corners_l0_per_frame": ncorn,
+                       "patches_attempted_per_frame": round(att, 1), "patches_found_per_frame": round(fnd, 1),
+                       "zmssd_evals_per_frame": round(zm, 1), "keyframes_added_per_stream": kf_adds,
+                       "ba_trials_per_stream": ba_trials, "streams_tracking_good": good, "setup_seconds": round(setup_s, 1)},
+            "roofline": roof,
+            "cpu_baseline": {"value": round(n_cpu / cpu_s, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+                             "sample": "oracle TrackFrame+BA on the first %d frames of stream 0 (same frames, same map)" % n_cpu},
+            "stages": stages,
+            "parity_pose_maxdiff_stream0": pose_diff,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -163,6 +163,15 @@ int vslam_get_keyframe_measurements(vslam_system* sys, int stream, int keyframe,
 int vslam_get_template(vslam_system* sys, int stream, int point, uint8_t* tmpl /* P*P */, int* sum, int* sumsq,
                        int* bad);
 
+/* ---- measurement: HIP-event time per stage of vslam_track_frame, on the system's own stream ---- */
+#define VSLAM_N_STAGES 14
+/* stages: 0 pyr_fast0, 1 fast_lvl, 2 compact, 3 pvs, 4 plan_coarse, 5 search_coarse, 6 pose_coarse, 7 plan_fine,
+ * 8 search_fine, 9 pose_fine, 10 add_keyframe, 11 ba_assemble, 12 ba_compute, 13 ba_writeback */
+const char* vslam_stage_name(int stage);
+int vslam_profile_begin(vslam_system* sys, int max_frames);
+/* synchronises; stage_ms[VSLAM_N_STAGES] = summed milliseconds over the recorded frames */
+int vslam_profile_end(vslam_system* sys, double* stage_ms, int* n_frames);
+
 /* ---- mapping ------------------------------------------------------------------------------- */
 /* MapMaker::BundleAdjustRecent / BundleAdjustAll (jni/MapMaker.cc:801-851, 776-798) on every stream, followed by
  * HandleBadPoints (:140-164); what the reference's map-maker thread loop (:80-123) would run next. */

@@ -5,6 +5,7 @@ import os
 import numpy as np
 
 LEVELS = 4
+N_STAGES = 14
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvslam_hip.so")
 
@@ -78,6 +79,9 @@ SYMBOLS = {
     "vslam_get_keyframe_pose": (_i, [_sys, _i, _i, _vp]),
     "vslam_get_keyframe_measurements": (_i, [_sys, _i, _i, _vp, _vp, _vp, _vp, _i]),
     "vslam_get_template": (_i, [_sys, _i, _i, _vp, _ip, _ip, _ip]),
+    "vslam_stage_name": (C.c_char_p, [_i]),
+    "vslam_profile_begin": (_i, [_sys, _i]),
+    "vslam_profile_end": (_i, [_sys, _vp, _ip]),
     "vslam_bundle_adjust_recent": (_i, [_sys]),
     "vslam_bundle_adjust_all": (_i, [_sys]),
     "vslam_bundle_create": (_i, [C.POINTER(Params), _i, _i, _i, _i, C.POINTER(_vp)]),
@@ -290,6 +294,16 @@ class System:
         s, sq, bad = C.c_int(0), C.c_int(0), C.c_int(0)
         have = _check(self.lib.vslam_get_template(self.h, stream, pt, t.ctypes.data, C.byref(s), C.byref(sq), C.byref(bad)))
         return {"tmpl": t.reshape(P, P), "sum": s.value, "sumsq": sq.value, "bad": bad.value, "have": have}
+
+    def profile_begin(self, max_frames):
+        _check(self.lib.vslam_profile_begin(self.h, max_frames))
+
+    def profile_end(self):
+        """-> ({stage name: summed ms}, n_frames) measured with HIP events on the system's stream"""
+        ms = np.zeros(N_STAGES)
+        n = C.c_int(0)
+        _check(self.lib.vslam_profile_end(self.h, ms.ctypes.data, C.byref(n)))
+        return {self.lib.vslam_stage_name(k).decode(): float(ms[k]) for k in range(N_STAGES)}, n.value
 
     def bundle_adjust_recent(self):
         _check(self.lib.vslam_bundle_adjust_recent(self.h))

@@ -499,10 +499,14 @@ int ba_run(vslam_system* sys, int mode) {
   const BaConfig cfg = make_cfg(sys->tp);
   if (mode == 0) {
     KfCopyArgs a; fill_kfcopy(sys, a);
+    prof_mark(sys, 10);
     hipLaunchKernelGGL(k_add_keyframe, dim3(32, sys->S), dim3(256), 0, sys->stream, sys->map, sys->tp, a);
   }
+  if (mode == 0) prof_mark(sys, 11);
   hipLaunchKernelGGL(k_ba_assemble, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, mode);
+  if (mode == 0) prof_mark(sys, 12);
   hipLaunchKernelGGL(k_ba_compute, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, ws->pool, cfg);
+  if (mode == 0) prof_mark(sys, 13);
   hipLaunchKernelGGL(k_ba_writeback, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, mode);
   HIPCHK(hipGetLastError());
   return VSLAM_OK;

@@ -1,6 +1,7 @@
 // Synthetic frame feeder (include/vslam_feeder.h): host-only C++, replaces the Android camera plumbing.
 #include "../../include/vslam_feeder.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -117,7 +118,8 @@ extern "C" int vslam_feeder_create(int width, int height, const double cam[5], u
                          fy * ((1 - fx) * lat[(iy + 1) * (G + 1) + ix] + fx * lat[(iy + 1) * (G + 1) + ix + 1]);
         f->tex[(size_t)y * TEX + x] = (uint8_t)(128 + 18 * n);
       }
-    const int nrect = 2600;
+    int nrect = 1000;   // ~1000 FAST-10 corners per 640x480 frame at level 0 (BASELINE.json configs[1])
+    if (const char* e = getenv("VSLAM_FEEDER_NRECT")) nrect = atoi(e);
     for (int i = 0; i < nrect; i++) {
       const int rw = rng.range(20, 160), rh = rng.range(20, 160);
       const int x0 = rng.range(0, TEX - rw), y0 = rng.range(0, TEX - rh);

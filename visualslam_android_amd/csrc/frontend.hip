@@ -350,12 +350,15 @@ int fe_make_keyframe_lite(vslam_system* sys, const uint8_t* gray, size_t row_str
   const int lp0 = (g[0].w + 15) & ~15, lp1 = (g[1].w + 15) & ~15, lp2 = (g[2].w + 15) & ~15;
   const size_t lds0 = (size_t)(BAND + 2 * HALO) * lp0 + (BAND / 2) * lp1 + (BAND / 4) * lp2 + BAND * sizeof(int);
   const int nb0 = (g[0].h + BAND - 1) / BAND;
+  prof_mark(sys, 0);
   hipLaunchKernelGGL(k_pyr_fast0, dim3(nb0, sys->S), dim3(FE_THREADS), lds0, sys->stream, a, lp0, lp1, lp2);
   int nb = 0;
   a.band_first[0] = 0;
   for (int l = 1; l < NLEV; l++) { a.band_first[l] = nb; nb += (g[l].h + BAND - 1) / BAND; }
   const size_t lds1 = (size_t)(BAND + 2 * HALO) * lp1 + BAND * sizeof(int);
+  prof_mark(sys, 1);
   hipLaunchKernelGGL(k_fast_lvl, dim3(nb, sys->S), dim3(FE_THREADS), lds1, sys->stream, a);
+  prof_mark(sys, 2);
   hipLaunchKernelGGL(k_compact, dim3(COMPACT_RB, NLEV, sys->S), dim3(FE_THREADS), 0, sys->stream, a);
   HIPCHK(hipGetLastError());
   sys->have_frame = true;

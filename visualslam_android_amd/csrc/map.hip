@@ -181,7 +181,37 @@ extern "C" int vslam_track_frame(vslam_system* sys, const uint8_t* gray, size_t 
   if (r) return r;
   r = trk_track_map(sys);                                                            // :103-124
   if (r) return r;
-  return ba_add_keyframe_and_adjust(sys);                                            // :128-132 -> MapMaker::AddKeyFrame
+  r = ba_add_keyframe_and_adjust(sys);                                               // :128-132 -> MapMaker::AddKeyFrame
+  prof_mark(sys, VSLAM_N_STAGES);
+  if (sys->prof_on && sys->prof_frame < sys->prof_cap) sys->prof_frame++;
+  return r;
+}
+
+static const char* kStageNames[VSLAM_N_STAGES] = {"pyr_fast0", "fast_lvl", "compact", "pvs", "plan_coarse", "search_coarse", "pose_coarse",
+                                                  "plan_fine", "search_fine", "pose_fine", "add_keyframe", "ba_assemble", "ba_compute", "ba_writeback"};
+extern "C" const char* vslam_stage_name(int stage) { return stage >= 0 && stage < VSLAM_N_STAGES ? kStageNames[stage] : ""; }
+
+extern "C" int vslam_profile_begin(vslam_system* sys, int max_frames) {
+  if (!sys || max_frames < 1) return VSLAM_E_INVALID;
+  HIPCHK(hipStreamSynchronize(sys->stream));
+  while ((int)sys->prof_ev.size() < max_frames * PROF_MARKS) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); sys->prof_ev.push_back(e); }
+  sys->prof_cap = max_frames; sys->prof_frame = 0; sys->prof_on = true;
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_profile_end(vslam_system* sys, double* stage_ms, int* n_frames) {
+  if (!sys || !stage_ms) return VSLAM_E_INVALID;
+  HIPCHK(hipStreamSynchronize(sys->stream));
+  sys->prof_on = false;
+  for (int k = 0; k < VSLAM_N_STAGES; k++) stage_ms[k] = 0.0;
+  for (int f = 0; f < sys->prof_frame; f++)
+    for (int k = 0; k < VSLAM_N_STAGES; k++) {
+      float ms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, sys->prof_ev[(size_t)f * PROF_MARKS + k], sys->prof_ev[(size_t)f * PROF_MARKS + k + 1]));
+      stage_ms[k] += ms;
+    }
+  if (n_frames) *n_frames = sys->prof_frame;
+  return VSLAM_OK;
 }
 
 extern "C" int vslam_update(vslam_system* sys, const uint8_t* gray, size_t row_stride, size_t stream_stride) {

@@ -748,17 +748,24 @@ int trk_track_map(vslam_system* sys) {
   }
   a.ncorners = sys->fr.ncorners;
   const int maxSearch = tp.max_patches + 2 * tp.coarse_max < P ? tp.max_patches + 2 * tp.coarse_max : P;
+  prof_mark(sys, 3);
   hipLaunchKernelGGL(k_pvs, dim3((P + TRK_THREADS - 1) / TRK_THREADS, S), dim3(TRK_THREADS), 0, sys->stream, m, tp);
+  prof_mark(sys, 4);
   hipLaunchKernelGGL(k_plan, dim3(S), dim3(TRK_THREADS), 0, sys->stream, m, tp, 0);
+  prof_mark(sys, 5);
   if (!tp.coarse_disabled) {
     const int nc = 2 * tp.coarse_max;
     if (tp.P == 8) hipLaunchKernelGGL(k_search<8>, dim3(nc, S), dim3(64), 0, sys->stream, m, tp, a, 0);
     else hipLaunchKernelGGL(k_search<11>, dim3(nc, S), dim3(64), 0, sys->stream, m, tp, a, 0);
+    prof_mark(sys, 6);
     hipLaunchKernelGGL(k_pose, dim3(S), dim3(TRK_THREADS), 0, sys->stream, m, tp, 0);
-  }
+  } else prof_mark(sys, 6);
+  prof_mark(sys, 7);
   hipLaunchKernelGGL(k_plan, dim3(S), dim3(TRK_THREADS), 0, sys->stream, m, tp, 1);
+  prof_mark(sys, 8);
   if (tp.P == 8) hipLaunchKernelGGL(k_search<8>, dim3(maxSearch, S), dim3(64), 0, sys->stream, m, tp, a, 1);
   else hipLaunchKernelGGL(k_search<11>, dim3(maxSearch, S), dim3(64), 0, sys->stream, m, tp, a, 1);
+  prof_mark(sys, 9);
   hipLaunchKernelGGL(k_pose, dim3(S), dim3(TRK_THREADS), 0, sys->stream, m, tp, 1);
   HIPCHK(hipGetLastError());
   return VSLAM_OK;

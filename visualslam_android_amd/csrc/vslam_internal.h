@@ -133,7 +133,16 @@ struct vslam_system {
   TrackParams tp;
   MapDev map;
   void* ba_ws;                 // bundle-adjustment workspace (ba.hip)
+  // per-stage HIP-event timing of vslam_track_frame (vslam_profile_begin/end)
+  std::vector<hipEvent_t> prof_ev;
+  int prof_cap = 0, prof_frame = 0;
+  bool prof_on = false;
 };
+
+#define PROF_MARKS (VSLAM_N_STAGES + 1)
+static inline void prof_mark(vslam_system* sys, int k) {
+  if (sys->prof_on && sys->prof_frame < sys->prof_cap) (void)hipEventRecord(sys->prof_ev[(size_t)sys->prof_frame * PROF_MARKS + k], sys->stream);
+}
 
 // frontend.hip
 int fe_make_keyframe_lite(vslam_system* sys, const uint8_t* gray, size_t row_stride, size_t stream_stride,
