@@ -151,3 +151,16 @@ int orc_zmssd(const uint8_t* tmpl, int P, const uint8_t* img, int w, int h, int 
 }
 
 }  // extern "C"
+
+// PatchFinder sub-pixel refinement alone (jni/PatchFinder.cc:242-350) on a level-0 image: template P x P, start at the
+// integer position (x, y); returns 1 if converged and writes the refined position.
+extern "C" int orc_subpix_refine(const uint8_t* tmpl, int P, const uint8_t* img, int w, int h, int x, int y, int max_its, double out[2]) {
+  Finder f; f.P = P; f.max_ssd = P * P * 500; f.tmpl.assign(tmpl, tmpl + P * P); f.level = 0;
+  f.coarse[0] = x; f.coarse[1] = y;
+  KeyFrame kf;
+  kf.w[0] = w; kf.h[0] = h; kf.im[0].assign(img, img + (size_t)w * h);
+  finder_make_subpix(f);
+  const bool ok = finder_iterate_subpix_to_convergence(f, kf, max_its);
+  out[0] = f.subpix[0]; out[1] = f.subpix[1];
+  return ok ? 1 : 0;
+}

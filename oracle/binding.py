@@ -355,3 +355,10 @@ def transform_image(img, P, M, in_orig, out_orig):
 def zmssd(tmpl, img, x, y):
     tmpl = np.ascontiguousarray(tmpl, np.uint8); img = np.ascontiguousarray(img, np.uint8)
     return lib().orc_zmssd(_p(tmpl), tmpl.shape[0], _p(img), img.shape[1], img.shape[0], img.shape[1], int(x), int(y))
+
+
+def subpix_refine(tmpl, img, x, y, max_its=10):
+    tmpl = np.ascontiguousarray(tmpl, np.uint8); img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros(2)
+    ok = lib().orc_subpix_refine(_p(tmpl), tmpl.shape[0], _p(img), img.shape[1], img.shape[0], int(x), int(y), int(max_its), _p(out))
+    return bool(ok), out

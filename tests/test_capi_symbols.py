@@ -8,8 +8,8 @@ from visualslam_android_amd import capi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "vslam_c.h")).read()
+def declared_symbols(header="vslam_c.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(vslam_[a-z0-9_]+)\s*\(", text)))
 
@@ -22,6 +22,11 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), "libvslam_hip.so does not export %s" % s
     # and the Python mirror binds exactly that set
     assert sorted(capi.SYMBOLS) == syms
+    from visualslam_android_amd import feeder
+    fsyms = declared_symbols("vslam_feeder.h")
+    for s in fsyms:
+        assert hasattr(lib, s), "libvslam_hip.so does not export %s" % s
+    assert sorted(feeder.FEEDER_SYMBOLS) == fsyms
 
 
 def test_params_struct_defaults():
