@@ -35,7 +35,12 @@ void orc_sys_add_meas(void* s, int kf, int pt, int level, const double root[2], 
 }
 void orc_sys_set_map_good(void* s) { ((System*)s)->SetMapGood(); }
 void orc_sys_set_pose(void* s, const double pose12[12]) { ((System*)s)->pose = pose_from12(pose12); }
-void orc_sys_set_velocity(void* s, const double v6[6]) { for (int i = 0; i < 6; i++) ((System*)s)->velocity[i] = v6[i]; }
+void orc_sys_set_velocity(void* sv, const double v6[6]) {
+  System* s = (System*)sv;
+  double ss = 0;   // mdMSDScaledVelocityMagnitude as UpdateMotionModel would leave it (jni/Tracker.cc:811-819)
+  for (int i = 0; i < 6; i++) { s->velocity[i] = v6[i]; double v = v6[i]; if (i < 3) v *= 1.0 / s->cur.depth_mean; ss += v * v; }
+  s->msd_vel = sqrt(ss);
+}
 void orc_sys_track_frame(void* s, const uint8_t* gray, int stride) { ((System*)s)->TrackFrame(gray, stride); }
 
 void orc_sys_get_state(void* sv, orc_track_state* o) {

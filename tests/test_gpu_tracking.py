@@ -22,11 +22,11 @@ def compare_frame(o, g, s, tag):
     assert d < POSE_TOL and d < TIGHT, (tag, d)
     to, tg = o.point_tracks(), g.point_tracks(s)
     assert np.array_equal(to["found"], tg["found"]) and np.array_equal(to["searched"], tg["searched"]), tag
-    f = to["found"] == 1
+    f = (to["found"] == 1) & (tg["level"] >= 0)        # bFound is stale for points outside this frame's PVS
     assert np.array_equal(to["level"][f], tg["level"][f]) and np.array_equal(to["subpix"][f], tg["subpix"][f]), tag
     coarse = f & (to["subpix"] == 0)
     assert np.array_equal(to["vfound"][coarse], tg["vfound"][coarse]), tag              # FAST-corner positions: exact
-    assert np.abs(to["vfound"][f] - tg["vfound"][f]).max() < 1e-9, tag                  # sub-pixel refined: fp round-off
+    assert not f.any() or np.abs(to["vfound"][f] - tg["vfound"][f]).max() < 1e-9, tag                  # sub-pixel refined: fp round-off
     assert np.abs(np.array(so.velocity[:]) - np.array(sg.velocity[:])).max() < TIGHT
 
 
