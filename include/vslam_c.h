@@ -104,6 +104,15 @@ int vslam_read_row_lut(vslam_system* sys, int stream, int level, int* lut /* hei
 int vslam_read_max_corners(vslam_system* sys, int stream, int level, uint32_t* corners, int* scores,
                            int cap, int* n);
 
+/* ---- MiniPatch (jni/MiniPatch.cc), the primitives of the reference's trail tracking ------------- */
+/* MiniPatch::SampleFromImage (:71-83): 9x9 patches around n integer positions of the current frame's level 0
+ * of `stream`; ok[i] = 0 where the patch would leave the image (the reference asserts). Synchronous. */
+int vslam_minipatch_sample(vslam_system* sys, int stream, int n, const int* pos_xy, uint8_t* patches /* n*81 */, int* ok);
+/* MiniPatch::FindPatch (:35-68): for each patch, best raw SSD at the FAST corners inside the +-range box around
+ * pos_xy[i]; on success pos_xy[i] is replaced by the corner and found[i] = 1 (SSD < max_ssd, jni/Tracker.cc:226). */
+int vslam_minipatch_find(vslam_system* sys, int stream, int n, const uint8_t* patches, int* pos_xy, int range, int max_ssd,
+                         int* found);
+
 /* ---- map (jni/Map.h:21-34) ---------------------------------------------------------------- */
 /* The reference fills its map through InitFromStereo / AddPointEpipolar (bootstrap and map growth: out of
  * scope / "next" rows); the feeder supplies a ground-truth map through these instead. */
@@ -177,6 +186,10 @@ int vslam_profile_end(vslam_system* sys, double* stage_ms, int* n_frames);
  * HandleBadPoints (:140-164); what the reference's map-maker thread loop (:80-123) would run next. */
 int vslam_bundle_adjust_recent(vslam_system* sys);
 int vslam_bundle_adjust_all(vslam_system* sys);
+/* MapMaker::AddKeyFrame (jni/MapMaker.cc:470-478) called from the host: the current frame of `stream` (all streams
+ * if stream < 0) becomes a keyframe now, followed by the same BundleAdjustRecent + HandleBadPoints as the
+ * tracker-driven path.  Needs a tracked current frame. */
+int vslam_add_keyframe(vslam_system* sys, int stream);
 
 /* ---- stand-alone Bundle (jni/Bundle.h:111-121), batched: n_problems independent problems ---- */
 typedef struct vslam_bundle vslam_bundle;

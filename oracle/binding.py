@@ -362,3 +362,18 @@ def subpix_refine(tmpl, img, x, y, max_its=10):
     out = np.zeros(2)
     ok = lib().orc_subpix_refine(_p(tmpl), tmpl.shape[0], _p(img), img.shape[1], img.shape[0], int(x), int(y), int(max_its), _p(out))
     return bool(ok), out
+
+
+def minipatch_sample(img, x, y):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros((9, 9), np.uint8)
+    ok = lib().orc_minipatch_sample(_p(img), img.shape[1], img.shape[0], img.shape[1], int(x), int(y), _p(out))
+    return out if ok else None
+
+
+def minipatch_find(patch, img, corners, x, y, rng=10, max_ssd=100000):
+    img = np.ascontiguousarray(img, np.uint8); patch = np.ascontiguousarray(patch, np.uint8)
+    corners = np.ascontiguousarray(corners, np.uint32)
+    pos = np.array([x, y], np.int32)
+    ok = lib().orc_minipatch_find(_p(patch), _p(img), img.shape[1], img.shape[0], img.shape[1], _p(corners), len(corners), int(rng), int(max_ssd), _p(pos))
+    return bool(ok), int(pos[0]), int(pos[1])

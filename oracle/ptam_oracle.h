@@ -68,6 +68,11 @@ int orc_make_keyframe_lite(const uint8_t* gray, int w, int h, int stride, const 
                            uint8_t* const lvl_img[ORC_LEVELS], uint32_t* const corners[ORC_LEVELS],
                            int cap, int ncorners[ORC_LEVELS], int* const lut[ORC_LEVELS]);
 
+/* MiniPatch (jni/MiniPatch.cc): 9x9 raw SSD search at FAST corners inside a +-range box */
+int orc_minipatch_sample(const uint8_t* img, int w, int h, int stride, int x, int y, uint8_t* patch /* 81 */);
+int orc_minipatch_find(const uint8_t* patch, const uint8_t* img, int w, int h, int stride, const uint32_t* corners,
+                       int n, int range, int max_ssd, int pos[2]);
+
 /* ---- whole-path oracle: one sequence (stream) ------------------------------------------------ */
 
 typedef struct orc_params {           /* mirrors the hot-path fields of vslam_params */

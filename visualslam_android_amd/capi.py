@@ -62,6 +62,9 @@ SYMBOLS = {
     "vslam_read_corners": (_i, [_sys, _i, _i, _vp, _i, _ip]),
     "vslam_read_row_lut": (_i, [_sys, _i, _i, _vp]),
     "vslam_read_max_corners": (_i, [_sys, _i, _i, _vp, _vp, _i, _ip]),
+    "vslam_minipatch_sample": (_i, [_sys, _i, _i, _vp, _vp, _vp]),
+    "vslam_minipatch_find": (_i, [_sys, _i, _i, _vp, _vp, _i, _i, _vp]),
+    "vslam_add_keyframe": (_i, [_sys, _i]),
     "vslam_map_add_keyframe": (_i, [_sys, _i, _vp, _i, _vp, _sz, _d, _d]),
     "vslam_map_add_point": (_i, [_sys, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "vslam_map_add_measurement": (_i, [_sys, _i, _i, _i, _i, _vp, _i, _i]),
@@ -213,6 +216,25 @@ class System:
         n = C.c_int(0)
         _check(self.lib.vslam_read_max_corners(self.h, stream, level, out.ctypes.data, sc.ctypes.data, cap, C.byref(n)))
         return out[:n.value].copy(), sc
+
+    def minipatch_sample(self, stream, pos_xy):
+        pos = np.ascontiguousarray(pos_xy, np.int32).reshape(-1, 2)
+        n = len(pos)
+        patches = np.zeros((n, 9, 9), np.uint8)
+        ok = np.zeros(n, np.int32)
+        _check(self.lib.vslam_minipatch_sample(self.h, stream, n, pos.ctypes.data, patches.ctypes.data, ok.ctypes.data))
+        return patches, ok
+
+    def minipatch_find(self, stream, patches, pos_xy, rng=10, max_ssd=100000):
+        pos = np.ascontiguousarray(pos_xy, np.int32).reshape(-1, 2).copy()
+        p = np.ascontiguousarray(patches, np.uint8)
+        found = np.zeros(len(pos), np.int32)
+        _check(self.lib.vslam_minipatch_find(self.h, stream, len(pos), p.ctypes.data, pos.ctypes.data, rng, max_ssd, found.ctypes.data))
+        return found, pos
+
+    def add_keyframe_now(self, stream=-1):
+        _check(self.lib.vslam_add_keyframe(self.h, stream))
+        self.synchronize()
 
     # ---- map ---------------------------------------------------------------------------------
     def add_keyframe(self, stream, pose12, fixed, gray, dmean, dsigma):

@@ -513,3 +513,19 @@ int ba_run(vslam_system* sys, int mode) {
 }
 
 int ba_add_keyframe_and_adjust(vslam_system* sys) { return ba_run(sys, 0); }
+
+__global__ void k_request_keyframe(MapDev m, TrackParams tp, int S, int stream) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  TrackerState* st = &m.st[s];
+  const bool want = (stream < 0 || s == stream) && st->map_good && st->n_kf < tp.max_keyframes;
+  st->kf_pending = want ? 1 : 0;                      // a request left over from the last frame has been served already
+  if (want) st->last_kf_dropped = st->frame;          // Tracker::AddNewKeyFrame, jni/Tracker.cc:823-827
+}
+
+extern "C" int vslam_add_keyframe(vslam_system* sys, int stream) {
+  if (!sys || stream >= sys->S) { vslam_set_error("add_keyframe: bad argument"); return VSLAM_E_INVALID; }
+  if (!sys->have_frame) { vslam_set_error("add_keyframe: no current frame"); return VSLAM_E_STATE; }
+  hipLaunchKernelGGL(k_request_keyframe, dim3((sys->S + 63) / 64), dim3(64), 0, sys->stream, sys->map, sys->tp, sys->S, stream);
+  return ba_run(sys, 0);
+}
