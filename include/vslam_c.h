@@ -124,6 +124,9 @@ int vslam_map_add_keyframe(vslam_system* sys, int stream, const double pose12[12
 /* MapPoint (jni/MapPoint.h:22-69). Returns the point index or a negative error. */
 int vslam_map_add_point(vslam_system* sys, int stream, const double pos[3], int src_keyframe, int src_level,
                         int ir_x, int ir_y, const double pixel_right_w[3], const double pixel_down_w[3]);
+/* the same for n points at once (pos, pixel_right_w, pixel_down_w: 3n doubles; ir_xy: 2n ints). Returns the new point count. */
+int vslam_map_add_points(vslam_system* sys, int stream, int n, const double* pos, const int* src_keyframe, const int* src_level,
+                         const int* ir_xy, const double* pixel_right_w, const double* pixel_down_w);
 /* Measurement (jni/KeyFrame.h:46-51): source 0 TRACKER 1 REFIND 2 ROOT 3 TRAIL 4 EPIPOLAR */
 int vslam_map_add_measurement(vslam_system* sys, int stream, int keyframe, int point, int level,
                               const double root_pos[2], int subpix, int source);

@@ -67,6 +67,7 @@ SYMBOLS = {
     "vslam_add_keyframe": (_i, [_sys, _i]),
     "vslam_map_add_keyframe": (_i, [_sys, _i, _vp, _i, _vp, _sz, _d, _d]),
     "vslam_map_add_point": (_i, [_sys, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "vslam_map_add_points": (_i, [_sys, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vslam_map_add_measurement": (_i, [_sys, _i, _i, _i, _i, _vp, _i, _i]),
     "vslam_map_add_measurements": (_i, [_sys, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vslam_map_set_good": (_i, [_sys, _i]),
@@ -249,8 +250,13 @@ class System:
         """m: dict from visualslam_android_amd.feeder.build_map"""
         for k in m["keyframes"]:
             self.add_keyframe(stream, k["pose"], k["fixed"], k["image"], k["depth_mean"], k["depth_sigma"])
-        for q in m["points"]:
-            self.add_point(stream, q["pos"], q["src_kf"], q["level"], q["irx"], q["iry"], q["right"], q["down"])
+        pts = m["points"]
+        if pts:
+            pos = np.array([q["pos"] for q in pts], np.float64); right = np.array([q["right"] for q in pts], np.float64)
+            down = np.array([q["down"] for q in pts], np.float64); kf_ = np.array([q["src_kf"] for q in pts], np.int32)
+            lv_ = np.array([q["level"] for q in pts], np.int32); ir = np.array([[q["irx"], q["iry"]] for q in pts], np.int32)
+            _check(self.lib.vslam_map_add_points(self.h, stream, len(pts), pos.ctypes.data, kf_.ctypes.data, lv_.ctypes.data,
+                                                 ir.ctypes.data, right.ctypes.data, down.ctypes.data))
         ms = m["meas"]
         n = len(ms)
         kf = np.array([x[0] for x in ms], np.int32); pt = np.array([x[1] for x in ms], np.int32)

@@ -157,7 +157,11 @@ extern "C" int vslam_bundle_compute(vslam_bundle* b) {
     HIPCHK(hipMemcpyAsync(v.pt_pos, h.pts.data(), sizeof(double) * 3 * r.n_pts, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipMemcpyAsync(v.ms_p, h.mp.data(), sizeof(int) * r.n_meas, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipMemcpyAsync(v.ms_c, h.mc.data(), sizeof(int) * r.n_meas, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipMemcpyAsync(v.ms_found, h.mfound.data(), sizeof(double) * 2 * r.n_meas, hipMemcpyHostToDevice, b->stream));
+    std::vector<double> fx(r.n_meas), fy(r.n_meas);   // component-major on device (ba_device.h MS())
+    for (int i = 0; i < r.n_meas; i++) { fx[i] = h.mfound[2 * i]; fy[i] = h.mfound[2 * i + 1]; }
+    HIPCHK(hipMemcpyAsync(v.ms_found, fx.data(), sizeof(double) * r.n_meas, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(v.ms_found + P.max_meas, fy.data(), sizeof(double) * r.n_meas, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
     HIPCHK(hipMemcpyAsync(v.ms_sin, h.msin.data(), sizeof(double) * r.n_meas, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipMemsetAsync(v.ms_state, 0, sizeof(int) * r.n_meas, b->stream));
     HIPCHK(hipMemsetAsync(v.pt_nout, 0, sizeof(int) * r.n_pts, b->stream));
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_assemble(MapDev m, TrackParam
         const MeasDev mm = kfm[(size_t)k * P + i];
         const int pid = pid_of[i];
         v.ms_p[off] = pid; v.ms_c[off] = cam; v.ms_state[off] = MS_OK;
-        v.ms_found[2 * off] = mm.root[0]; v.ms_found[2 * off + 1] = mm.root[1];
+        MS(ms_found, 0, off) = mm.root[0]; MS(ms_found, 1, off) = mm.root[1];
         const int sc = 1 << mm.level;
         v.ms_sin[off] = sqrt(1.0 / (double)(sc * sc));                   // :899 + AddMeas :115
         v.lut[(size_t)cam * pool.max_pts + pid] = off;
@@ -513,6 +517,15 @@ int ba_run(vslam_system* sys, int mode) {
 }
 
 int ba_add_keyframe_and_adjust(vslam_system* sys) { return ba_run(sys, 0); }
+
+#ifdef VSLAM_BA_PROF
+extern "C" int vslam_debug_ba_prof(unsigned long long* out32, int reset) {
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_ba_prof), sizeof(unsigned long long) * 32));
+  if (reset) { unsigned long long z[32] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_ba_prof), z, sizeof(z))); }
+  return VSLAM_OK;
+}
+#endif
 
 __global__ void k_request_keyframe(MapDev m, TrackParams tp, int S, int stream) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;

@@ -12,6 +12,7 @@
 #include "dev_math.h"
 
 #define BA_THREADS 512
+#define BA_LDS_N 60      // reduced camera systems up to 60 x 60 (10 adjustable cameras) are solved in LDS
 #define BA_WAVES (BA_THREADS / 64)
 
 #define MS_OK 0
@@ -43,6 +44,21 @@ struct BaView {          // pointers already offset to one problem
   int* free_cams;        // [max_cams] indices of the adjustable cameras
 };
 
+// Diagnostic build only (-DVSLAM_BA_PROF): clock64() stamps of block 0 / lane 0 per phase of ba_compute, accumulated in
+// g_ba_prof[phase]; read with vslam_debug_ba_prof().  Never compiled into the product library.
+#ifdef VSLAM_BA_PROF
+__device__ unsigned long long g_ba_prof[32];
+#define BA_STAMP(id) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = clock64(); g_ba_prof[id] += t_ - ba_t0; ba_t0 = t_; } } while (0)
+#else
+#define BA_STAMP(id) do { } while (0)
+#endif
+
+// Measurement- and point-indexed fp64 arrays are component-major ("transposed"): component k of item i lives at
+// arr[k * max + i], so the 64 lanes of a wave (consecutive i) touch 512 contiguous bytes per load/store instead of
+// 64 scattered 8-byte words (the AoS form made pass 2 of Do_LM_Step 48 % of the kernel).
+#define MS(arr, k, i) v.arr[(size_t)(k) * v.max_meas + (i)]
+#define PT(arr, k, p) v.arr[(size_t)(k) * v.max_pts + (p)]
+
 struct BaConfig { CamModel cam; int max_iterations; double convergence_limit, min_sigma2; };
 
 DEVFN double ba_wave_sum(double v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d); return v; }
@@ -68,48 +84,22 @@ DEVFN int ba_block_sum_i(int v, int* red) {
   return t;
 }
 
-// k-th smallest (0-based) of n non-negative doubles in global memory (bit patterns order like the values):
-// MSB-first radix select, 8 bits per pass, histogram in LDS.  hist: LDS [256] ints, sel: LDS [2] u64.
-DEVFN double ba_radix_select(const double* v, int n, int k, int* hist, unsigned long long* sel) {
-  unsigned long long prefix = 0, mask = 0;
-  int kk = k;
-  for (int pass = 0; pass < 8; pass++) {
-    const int shift = 56 - 8 * pass;
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      const unsigned long long b = (unsigned long long)__double_as_longlong(v[i]);
-      if ((b & mask) == prefix) atomicAdd(&hist[(b >> shift) & 255], 1);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int acc = 0, bin = 0;
-      for (; bin < 256; bin++) { if (acc + hist[bin] > kk) break; acc += hist[bin]; }
-      sel[0] = prefix | ((unsigned long long)bin << shift);
-      sel[1] = (unsigned long long)(kk - acc);
-    }
-    __syncthreads();
-    prefix = sel[0]; kk = (int)sel[1];
-    mask |= 255ull << shift;
-    __syncthreads();
-  }
-  return __longlong_as_double((long long)prefix);
-}
-
 // ProjectAndFindSquaredError, jni/Bundle.cc:181-199
 DEVFN void ba_project_meas(const BaView& v, const BaConfig& cfg, int i) {
   const Pose& cam = v.cam_pose[v.ms_c[i]];
   const double* X = v.pt_pos + 3 * v.ms_p[i];
   double c[3];
   pose_xform(cam, X, c);
-  v.ms_cam[3 * i] = c[0]; v.ms_cam[3 * i + 1] = c[1]; v.ms_cam[3 * i + 2] = c[2];
+  MS(ms_cam, 0, i) = c[0]; MS(ms_cam, 1, i) = c[1]; MS(ms_cam, 2, i) = c[2];
   if (c[2] <= 0) { v.ms_state[i] = MS_BAD; return; }
   v.ms_state[i] = MS_OK;
   const CamProj pr = cam_project(cfg.cam, c[0] / c[2], c[1] / c[2]);
-  cam_derivs(cfg.cam, pr, v.ms_derivs + 4 * i);
+  double dd[4];
+  cam_derivs(cfg.cam, pr, dd);
+  MS(ms_derivs, 0, i) = dd[0]; MS(ms_derivs, 1, i) = dd[1]; MS(ms_derivs, 2, i) = dd[2]; MS(ms_derivs, 3, i) = dd[3];
   const double sn = v.ms_sin[i];
-  const double e0 = (v.ms_found[2 * i] - pr.im[0]) * sn, e1 = (v.ms_found[2 * i + 1] - pr.im[1]) * sn;
-  v.ms_eps[2 * i] = e0; v.ms_eps[2 * i + 1] = e1;
+  const double e0 = (MS(ms_found, 0, i) - pr.im[0]) * sn, e1 = (MS(ms_found, 1, i) - pr.im[1]) * sn;
+  MS(ms_eps, 0, i) = e0; MS(ms_eps, 1, i) = e1;
   v.ms_err2[i] = e0 * e0 + e1 * e1;
 }
 
@@ -151,6 +141,52 @@ DEVFN bool ba_block_solve(double* S, double* E, int n, int* ired) {
   return true;
 }
 
+// The same solve with the augmented system held in LDS (n <= BA_LDS_N): pivot search by wave shuffles, elimination by
+// the whole workgroup, back-substitution by wave 0.  A: LDS [n][n+1].
+DEVFN bool ba_block_solve_lds(const double* S, double* E, int n, double* A, int* ired) {
+  const int ld = n + 1, lane = threadIdx.x & 63;
+  for (int t = threadIdx.x; t < n * ld; t += blockDim.x) { const int r = t / ld, c = t - r * ld; A[t] = c < n ? S[(size_t)r * n + c] : E[r]; }
+  __syncthreads();
+  for (int k = 0; k < n; k++) {
+    if (threadIdx.x < 64) {                                        // partial pivoting: first row of maximal |A[r][k]|, r >= k
+      double best = -1.0; int piv = k;
+      for (int r = k + lane; r < n; r += 64) { const double a = fabs(A[r * ld + k]); if (a > best) { best = a; piv = r; } }
+      for (int d = 32; d > 0; d >>= 1) {
+        const double ob = __shfl_xor(best, d); const int op = __shfl_xor(piv, d);
+        if (ob > best || (ob == best && op < piv)) { best = ob; piv = op; }
+      }
+      if (lane == 0) ired[0] = best == 0.0 ? -1 : piv;
+    }
+    __syncthreads();
+    const int piv = ired[0];
+    if (piv < 0) return false;
+    if (piv != k) for (int c = threadIdx.x; c < ld; c += blockDim.x) { const double t = A[k * ld + c]; A[k * ld + c] = A[piv * ld + c]; A[piv * ld + c] = t; }
+    __syncthreads();
+    const double inv = 1.0 / A[k * ld + k];
+    const int rem = n - k - 1, wid = ld - k - 1;                    // columns k+1 .. n (the last one is the right-hand side)
+    for (int t = threadIdx.x; t < rem * wid; t += blockDim.x) {
+      const int r = k + 1 + t / wid, c = k + 1 + t % wid;
+      const double f = A[r * ld + k] * inv;
+      A[r * ld + c] -= f * A[k * ld + c];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 64) {
+    for (int k = n - 1; k >= 0; k--) {
+      double s = 0.0;
+      for (int c = k + 1 + lane; c < n; c += 64) s += A[k * ld + c] * A[c * ld + n];
+      for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+      if (lane == 0) A[k * ld + n] = (A[k * ld + n] - s) / A[k * ld + k];
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < n; t += blockDim.x) E[t] = A[t * ld + n];
+  __syncthreads();
+  return true;
+}
+
 // Bundle::Compute.  Called by all BA_THREADS threads of one workgroup.
 DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
   __shared__ double red[BA_WAVES];
@@ -158,6 +194,7 @@ DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
   __shared__ int hist[256];
   __shared__ unsigned long long sel[2];
   __shared__ double sh_lambda, sh_factor, sh_sigma2, sh_cur_err, sh_new_err;
+  __shared__ double lds_A[BA_LDS_N * (BA_LDS_N + 1)];
   __shared__ int sh_converged, sh_hitmax, sh_counter, sh_accepted, sh_error, sh_nout;
   BaResult* R = v.res;
   const int nc = R->n_cams, np = R->n_pts, nm = R->n_meas;
@@ -174,6 +211,9 @@ DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
   }
   __syncthreads();
   const int nfree = R->n_free, nS = nfree * 6;
+#ifdef VSLAM_BA_PROF
+  unsigned long long ba_t0 = clock64();
+#endif
 
   while (!sh_converged && !sh_hitmax && !sh_error) {             // :153 (no abort signal: the map-maker runs synchronously)
     // ================= Do_LM_Step =================
@@ -188,15 +228,17 @@ DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
       v.scratch[i] = e2;
     }
     nvalid = ba_block_sum_i(nvalid, ired);
+    BA_STAMP(1);
     if (nvalid == 0) { if (threadIdx.x == 0) sh_error = 1; __syncthreads(); break; }
     {                                                              // :220-227 Tukey sigma, clamped
-      const double med = ba_radix_select(v.scratch, nm, nvalid / 2, hist, sel);
+      const double med = block_radix_select(v.scratch, nm, nvalid / 2, hist, sel);
       double s2 = tukey_sigma_squared(med, (unsigned long)nvalid);
       if (s2 < cfg.min_sigma2) s2 = cfg.min_sigma2;
       if (threadIdx.x == 0) sh_sigma2 = s2;
       __syncthreads();
     }
     const double sigma2 = sh_sigma2;
+    BA_STAMP(2);
     // pass 2 (:241-321): weights, A, B, W, objective
     double cur = 0.0;
     for (int i = threadIdx.x; i < nm; i += BA_THREADS) {
@@ -204,121 +246,137 @@ DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
       if (stt == MS_ERASED) continue;
       if (stt == MS_BAD) { cur += 1.0; continue; }
       const double dWeight = tukey_sqrt_weight(v.ms_err2[i], sigma2);
-      v.ms_eps[2 * i] *= dWeight; v.ms_eps[2 * i + 1] *= dWeight;
+      const double ew0 = MS(ms_eps, 0, i) * dWeight, ew1 = MS(ms_eps, 1, i) * dWeight;
+      MS(ms_eps, 0, i) = ew0; MS(ms_eps, 1, i) = ew1;
       if (dWeight == 0) { v.ms_state[i] = MS_BAD; cur += 1.0; continue; }
       cur += tukey_objective(v.ms_err2[i], sigma2);
       const int c = v.ms_c[i];
-      const double* dd = v.ms_derivs + 4 * i;
+      const double dd[4] = {MS(ms_derivs, 0, i), MS(ms_derivs, 1, i), MS(ms_derivs, 2, i), MS(ms_derivs, 3, i)};
       const double sn = v.ms_sin[i];
       const double d0 = sn * (dWeight * dd[0]), d1 = sn * (dWeight * dd[1]), d2 = sn * (dWeight * dd[2]), d3 = sn * (dWeight * dd[3]);
-      const double* cm = v.ms_cam + 3 * i;
+      const double cm[3] = {MS(ms_cam, 0, i), MS(ms_cam, 1, i), MS(ms_cam, 2, i)};
       const double ooz = 1.0 / cm[2];
-      double* A = v.ms_A + 12 * i; double* B = v.ms_B + 6 * i; double* W = v.ms_W + 18 * i;
+      double A[12], B[6];
       const bool fixed = v.cam_fixed[c] != 0;
-      if (fixed) { for (int k = 0; k < 12; k++) A[k] = 0.0; }
-      else
+      if (fixed) { _Pragma("unroll") for (int k = 0; k < 12; k++) A[k] = 0.0; }
+      else {
+        const double cc[3] = {cm[0], cm[1], cm[2]};
+#pragma unroll
         for (int k = 0; k < 6; k++) {
-          double mot[3];
-          generator_field(k, cm, mot);
-          const double f0 = (mot[0] - cm[0] * mot[2] * ooz) * ooz, f1 = (mot[1] - cm[1] * mot[2] * ooz) * ooz;
+          double f0, f1;
+          se3_generator_motion(k, cc, ooz, f0, f1);
           A[k] = d0 * f0 + d1 * f1; A[6 + k] = d2 * f0 + d3 * f1;
         }
+      }
       const Pose& cp = v.cam_pose[c];
-      for (int k = 0; k < 3; k++) {
+      _Pragma("unroll") for (int k = 0; k < 3; k++) {
         const double m0 = cp.R[k], m1 = cp.R[3 + k], m2 = cp.R[6 + k];
         const double f0 = (m0 - cm[0] * m2 * ooz) * ooz, f1 = (m1 - cm[1] * m2 * ooz) * ooz;
         B[k] = d0 * f0 + d1 * f1; B[3 + k] = d2 * f0 + d3 * f1;
       }
-      if (fixed) { for (int k = 0; k < 18; k++) W[k] = 0.0; }
-      else for (int r = 0; r < 6; r++) for (int q = 0; q < 3; q++) W[r * 3 + q] = A[r] * B[q] + A[6 + r] * B[3 + q];
+      _Pragma("unroll") for (int k = 0; k < 12; k++) MS(ms_A, k, i) = A[k];
+      _Pragma("unroll") for (int k = 0; k < 6; k++) MS(ms_B, k, i) = B[k];
+      _Pragma("unroll") for (int r = 0; r < 6; r++) _Pragma("unroll") for (int q = 0; q < 3; q++)
+        MS(ms_W, r * 3 + q, i) = fixed ? 0.0 : A[r] * B[q] + A[6 + r] * B[3 + q];
     }
     cur = ba_block_sum(cur, red);
     if (threadIdx.x == 0) sh_cur_err = cur;
     __syncthreads();
+    BA_STAMP(3);
     // V, epsilon_b per point: one lane per point, cameras in id order
     for (int p = threadIdx.x; p < np; p += BA_THREADS) {
       double V[6] = {0, 0, 0, 0, 0, 0}, eb[3] = {0, 0, 0};
       for (int c = 0; c < nc; c++) {
         const int i = v.lut[(size_t)c * v.max_pts + p];
         if (i < 0 || v.ms_state[i] != MS_OK) continue;
-        const double* B = v.ms_B + 6 * i; const double* e = v.ms_eps + 2 * i;
+        double B[6]; _Pragma("unroll") for (int k = 0; k < 6; k++) B[k] = MS(ms_B, k, i);
+        const double e[2] = {MS(ms_eps, 0, i), MS(ms_eps, 1, i)};
         int q = 0;
-        for (int r = 0; r < 3; r++) for (int cc = 0; cc <= r; cc++) V[q++] += B[r] * B[cc] + B[3 + r] * B[3 + cc];   // :49-56 LL triangle
-        for (int r = 0; r < 3; r++) eb[r] += B[r] * e[0] + B[3 + r] * e[1];
+        _Pragma("unroll") for (int r = 0; r < 3; r++) for (int cc = 0; cc <= r; cc++) V[q++] += B[r] * B[cc] + B[3 + r] * B[3 + cc];   // :49-56 LL triangle
+        _Pragma("unroll") for (int r = 0; r < 3; r++) eb[r] += B[r] * e[0] + B[3 + r] * e[1];
       }
-      double* Vp = v.pt_V + 9 * p;
-      Vp[0] = V[0]; Vp[3] = V[1]; Vp[4] = V[2]; Vp[6] = V[3]; Vp[7] = V[4]; Vp[8] = V[5]; Vp[1] = Vp[2] = Vp[5] = 0.0;
-      v.pt_eb[3 * p] = eb[0]; v.pt_eb[3 * p + 1] = eb[1]; v.pt_eb[3 * p + 2] = eb[2];
+      // lower triangle of V: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) -> components 0..5
+      _Pragma("unroll") for (int k = 0; k < 6; k++) PT(pt_V, k, p) = V[k];
+      PT(pt_eb, 0, p) = eb[0]; PT(pt_eb, 1, p) = eb[1]; PT(pt_eb, 2, p) = eb[2];
     }
+    BA_STAMP(4);
     // U, epsilon_a per adjustable camera: one wavefront per camera (segmented wave reduction)
     for (int f = wave; f < nfree; f += BA_WAVES) {
       const int j = v.free_cams[f];
       double acc[27];
-      for (int k = 0; k < 27; k++) acc[k] = 0.0;
+      _Pragma("unroll") for (int k = 0; k < 27; k++) acc[k] = 0.0;
       for (int p = lane; p < np; p += 64) {
         const int i = v.lut[(size_t)j * v.max_pts + p];
         if (i < 0 || v.ms_state[i] != MS_OK) continue;
-        const double* A = v.ms_A + 12 * i; const double* e = v.ms_eps + 2 * i;
+        double A[12]; _Pragma("unroll") for (int k = 0; k < 12; k++) A[k] = MS(ms_A, k, i);
+        const double e[2] = {MS(ms_eps, 0, i), MS(ms_eps, 1, i)};
         int q = 0;
-        for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) acc[q++] += A[r] * A[c] + A[6 + r] * A[6 + c];       // :40-47
-        for (int r = 0; r < 6; r++) acc[21 + r] += A[r] * e[0] + A[6 + r] * e[1];
+        _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) acc[q++] += A[r] * A[c] + A[6 + r] * A[6 + c];       // :40-47
+        _Pragma("unroll") for (int r = 0; r < 6; r++) acc[21 + r] += A[r] * e[0] + A[6 + r] * e[1];
       }
-      for (int k = 0; k < 27; k++) acc[k] = ba_wave_sum(acc[k]);
+      _Pragma("unroll") for (int k = 0; k < 27; k++) acc[k] = ba_wave_sum(acc[k]);
       if (lane == 0) {
         double* U = v.cam_U + 36 * j;
         int q = 0;
-        for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) U[r * 6 + c] = acc[q++];
-        for (int r = 0; r < 6; r++) v.cam_ea[6 * j + r] = acc[21 + r];
+        _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) U[r * 6 + c] = acc[q++];
+        _Pragma("unroll") for (int r = 0; r < 6; r++) v.cam_ea[6 * j + r] = acc[21 + r];
       }
     }
     __syncthreads();
 
+    __syncthreads();
+    BA_STAMP(5);
     // ---- inner loop over lambda (:326-501) ----
     if (threadIdx.x == 0) sh_new_err = sh_cur_err + 9999;
     __syncthreads();
     while (sh_new_err > sh_cur_err && !sh_converged && !sh_hitmax && !sh_error) {
       const double lambda = sh_lambda;
       for (int p = threadIdx.x; p < np; p += BA_THREADS) {           // V*^-1 (:329-347)
-        const double* Vp = v.pt_V + 9 * p;
-        double* Vi = v.pt_Vinv + 9 * p;
-        if (Vp[0] * Vp[4] * Vp[8] == 0) { for (int k = 0; k < 9; k++) Vi[k] = 0.0; continue; }
-        double Vs[9] = {Vp[0], Vp[3], Vp[6], Vp[3], Vp[4], Vp[7], Vp[6], Vp[7], Vp[8]};
-        for (int k = 0; k < 3; k++) Vs[k * 3 + k] *= (1.0 + lambda);
-        inv3(Vs, Vi);
+        const double v00 = PT(pt_V, 0, p), v10 = PT(pt_V, 1, p), v11 = PT(pt_V, 2, p), v20 = PT(pt_V, 3, p), v21 = PT(pt_V, 4, p), v22 = PT(pt_V, 5, p);
+        double Vi[9];
+        if (v00 * v11 * v22 == 0) { _Pragma("unroll") for (int k = 0; k < 9; k++) Vi[k] = 0.0; }
+        else {
+          const double Vs[9] = {v00 * (1.0 + lambda), v10, v20, v10, v11 * (1.0 + lambda), v21, v20, v21, v22 * (1.0 + lambda)};
+          inv3(Vs, Vi);
+        }
+        _Pragma("unroll") for (int k = 0; k < 9; k++) PT(pt_Vinv, k, p) = Vi[k];
       }
       for (int t = threadIdx.x; t < nS * nS; t += BA_THREADS) v.S[t] = 0.0;
       __syncthreads();
+      BA_STAMP(6);
       // S: diagonal blocks + E (:362-396) and off-diagonal blocks (:400-426); one wavefront per block
       const int ntask = nfree + nfree * (nfree - 1) / 2;
       for (int task = wave; task < ntask; task += BA_WAVES) {
         if (task < nfree) {
           const int j = v.free_cams[task], row = v.cam_row[j];
           double acc[27];
-          for (int k = 0; k < 27; k++) acc[k] = 0.0;
+          _Pragma("unroll") for (int k = 0; k < 27; k++) acc[k] = 0.0;
           for (int p = lane; p < np; p += 64) {
             const int i = v.lut[(size_t)j * v.max_pts + p];
             if (i < 0 || v.ms_state[i] != MS_OK) continue;
-            const double* W = v.ms_W + 18 * i; const double* Vi = v.pt_Vinv + 9 * p; const double* eb = v.pt_eb + 3 * p;
+            double W[18], Vi[9]; _Pragma("unroll") for (int k = 0; k < 18; k++) W[k] = MS(ms_W, k, i);
+            _Pragma("unroll") for (int k = 0; k < 9; k++) Vi[k] = PT(pt_Vinv, k, p);
+            const double eb[3] = {PT(pt_eb, 0, p), PT(pt_eb, 1, p), PT(pt_eb, 2, p)};
             double Y[18];
-            for (int r = 0; r < 6; r++) for (int c = 0; c < 3; c++) Y[r * 3 + c] = W[r * 3] * Vi[c] + W[r * 3 + 1] * Vi[3 + c] + W[r * 3 + 2] * Vi[6 + c];
+            _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c < 3; c++) Y[r * 3 + c] = W[r * 3] * Vi[c] + W[r * 3 + 1] * Vi[3 + c] + W[r * 3 + 2] * Vi[6 + c];
             int q = 0;
-            for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) acc[q++] += Y[r * 3] * W[c * 3] + Y[r * 3 + 1] * W[c * 3 + 1] + Y[r * 3 + 2] * W[c * 3 + 2];
+            _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) acc[q++] += Y[r * 3] * W[c * 3] + Y[r * 3 + 1] * W[c * 3 + 1] + Y[r * 3 + 2] * W[c * 3 + 2];
             double ve[3];
-            for (int r = 0; r < 3; r++) ve[r] = Vi[r * 3] * eb[0] + Vi[r * 3 + 1] * eb[1] + Vi[r * 3 + 2] * eb[2];
-            for (int r = 0; r < 6; r++) acc[21 + r] += W[r * 3] * ve[0] + W[r * 3 + 1] * ve[1] + W[r * 3 + 2] * ve[2];
+            _Pragma("unroll") for (int r = 0; r < 3; r++) ve[r] = Vi[r * 3] * eb[0] + Vi[r * 3 + 1] * eb[1] + Vi[r * 3 + 2] * eb[2];
+            _Pragma("unroll") for (int r = 0; r < 6; r++) acc[21 + r] += W[r * 3] * ve[0] + W[r * 3 + 1] * ve[1] + W[r * 3 + 2] * ve[2];
           }
-          for (int k = 0; k < 27; k++) acc[k] = ba_wave_sum(acc[k]);
+          _Pragma("unroll") for (int k = 0; k < 27; k++) acc[k] = ba_wave_sum(acc[k]);
           if (lane == 0) {
             const double* U = v.cam_U + 36 * j;
             int q = 0;
-            for (int r = 0; r < 6; r++)
+            _Pragma("unroll") for (int r = 0; r < 6; r++)
               for (int c = 0; c <= r; c++) {
                 double u = U[r * 6 + c];
                 if (r == c) u *= (1.0 + lambda);
                 const double val = u - acc[q++];
                 v.S[(size_t)(row + r) * nS + row + c] = val; v.S[(size_t)(row + c) * nS + row + r] = val;   // mirrored :431-434
               }
-            for (int r = 0; r < 6; r++) v.E[row + r] = v.cam_ea[6 * j + r] - acc[21 + r];
+            _Pragma("unroll") for (int r = 0; r < 6; r++) v.E[row + r] = v.cam_ea[6 * j + r] - acc[21 + r];
           }
         } else {
           int t = task - nfree, fj = 1;
@@ -327,27 +385,31 @@ DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
           const int j = v.free_cams[fj], k = v.free_cams[fk];
           const int jrow = v.cam_row[j], krow = v.cam_row[k];
           double acc[36];
-          for (int q = 0; q < 36; q++) acc[q] = 0.0;
+          _Pragma("unroll") for (int q = 0; q < 36; q++) acc[q] = 0.0;
           for (int p = lane; p < np; p += 64) {
             const int ij = v.lut[(size_t)j * v.max_pts + p], ik = v.lut[(size_t)k * v.max_pts + p];
             if (ij < 0 || ik < 0 || v.ms_state[ij] != MS_OK || v.ms_state[ik] != MS_OK) continue;
-            const double* Wj = v.ms_W + 18 * ij; const double* Wk = v.ms_W + 18 * ik; const double* Vi = v.pt_Vinv + 9 * p;
+            double Wj[18], Wk[18], Vi[9];
+            _Pragma("unroll") for (int q = 0; q < 18; q++) { Wj[q] = MS(ms_W, q, ij); Wk[q] = MS(ms_W, q, ik); }
+            _Pragma("unroll") for (int q = 0; q < 9; q++) Vi[q] = PT(pt_Vinv, q, p);
             double Y[18];
-            for (int r = 0; r < 6; r++) for (int c = 0; c < 3; c++) Y[r * 3 + c] = Wj[r * 3] * Vi[c] + Wj[r * 3 + 1] * Vi[3 + c] + Wj[r * 3 + 2] * Vi[6 + c];
-            for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) acc[r * 6 + c] += Y[r * 3] * Wk[c * 3] + Y[r * 3 + 1] * Wk[c * 3 + 1] + Y[r * 3 + 2] * Wk[c * 3 + 2];
+            _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c < 3; c++) Y[r * 3 + c] = Wj[r * 3] * Vi[c] + Wj[r * 3 + 1] * Vi[3 + c] + Wj[r * 3 + 2] * Vi[6 + c];
+            _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) acc[r * 6 + c] += Y[r * 3] * Wk[c * 3] + Y[r * 3 + 1] * Wk[c * 3 + 1] + Y[r * 3 + 2] * Wk[c * 3 + 2];
           }
-          for (int q = 0; q < 36; q++) acc[q] = ba_wave_sum(acc[q]);
+          _Pragma("unroll") for (int q = 0; q < 36; q++) acc[q] = ba_wave_sum(acc[q]);
           if (lane == 0)
-            for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) {
+            _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) {
               v.S[(size_t)(jrow + r) * nS + krow + c] = -acc[r * 6 + c];
               v.S[(size_t)(krow + c) * nS + jrow + r] = -acc[r * 6 + c];
             }
         }
       }
       __syncthreads();
-      if (nS > 0 && !ba_block_solve(v.S, v.E, nS, ired)) { if (threadIdx.x == 0) sh_error = 1; __syncthreads(); break; }
+      BA_STAMP(7);
+      if (nS > 0 && !(nS <= BA_LDS_N ? ba_block_solve_lds(v.S, v.E, nS, lds_A, ired) : ba_block_solve(v.S, v.E, nS, ired))) { if (threadIdx.x == 0) sh_error = 1; __syncthreads(); break; }
       for (int t = threadIdx.x; t < nS; t += BA_THREADS) v.cam_up[t] = v.E[t];
       __syncthreads();
+      BA_STAMP(8);
       // map updates (:440-462)
       double ssq = 0.0;
       for (int p = threadIdx.x; p < np; p += BA_THREADS) {
@@ -356,14 +418,16 @@ DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
           const int j = v.free_cams[f];
           const int i = v.lut[(size_t)j * v.max_pts + p];
           if (i < 0 || v.ms_state[i] != MS_OK) continue;
-          const double* W = v.ms_W + 18 * i; const double* cu = v.cam_up + v.cam_row[j];
-          for (int c = 0; c < 3; c++) { double s = 0; for (int r = 0; r < 6; r++) s += W[r * 3 + c] * cu[r]; sum[c] += s; }
+          double W[18]; _Pragma("unroll") for (int k = 0; k < 18; k++) W[k] = MS(ms_W, k, i);
+          const double* cu = v.cam_up + v.cam_row[j];
+          _Pragma("unroll") for (int c = 0; c < 3; c++) { double s = 0; for (int r = 0; r < 6; r++) s += W[r * 3 + c] * cu[r]; sum[c] += s; }
         }
-        const double* eb = v.pt_eb + 3 * p; const double* Vi = v.pt_Vinv + 9 * p;
+        const double eb[3] = {PT(pt_eb, 0, p), PT(pt_eb, 1, p), PT(pt_eb, 2, p)};
+        double Vi[9]; _Pragma("unroll") for (int k = 0; k < 9; k++) Vi[k] = PT(pt_Vinv, k, p);
         const double x[3] = {eb[0] - sum[0], eb[1] - sum[1], eb[2] - sum[2]};
-        for (int r = 0; r < 3; r++) {
+        _Pragma("unroll") for (int r = 0; r < 3; r++) {
           const double u = Vi[r * 3] * x[0] + Vi[r * 3 + 1] * x[1] + Vi[r * 3 + 2] * x[2];
-          v.map_up[3 * p + r] = u; ssq += u * u;
+          ssq += u * u;
           v.pt_new[3 * p + r] = v.pt_pos[3 * p + r] + u;               // :484
         }
       }
@@ -374,6 +438,7 @@ DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
         else v.cam_new[j] = pose_mul(se3_exp(v.cam_up + v.cam_row[j]), v.cam_pose[j]);
       }
       __syncthreads();
+      BA_STAMP(9);
       // FindNewError (:537-561)
       double ne = 0.0;
       for (int i = threadIdx.x; i < nm; i += BA_THREADS) {
@@ -383,10 +448,11 @@ DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
         if (c[2] <= 0) { ne += 1.0; continue; }
         const CamProj pr = cam_project(cfg.cam, c[0] / c[2], c[1] / c[2]);
         const double sn = v.ms_sin[i];
-        const double e0 = (v.ms_found[2 * i] - pr.im[0]) * sn, e1 = (v.ms_found[2 * i + 1] - pr.im[1]) * sn;
+        const double e0 = (MS(ms_found, 0, i) - pr.im[0]) * sn, e1 = (MS(ms_found, 1, i) - pr.im[1]) * sn;
         ne += tukey_objective(e0 * e0 + e1 * e1, sigma2);
       }
       ne = ba_block_sum(ne, red);
+      BA_STAMP(10);
       if (threadIdx.x == 0) {
         if (ssq < cfg.convergence_limit) sh_converged = 1;
         sh_new_err = ne;
@@ -403,6 +469,7 @@ DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
       if (threadIdx.x == 0) { sh_factor = 2.0; sh_lambda *= 0.3; sh_accepted++; }   // ModifyLambda_GoodStep :609-612
     }
     __syncthreads();
+    BA_STAMP(11);
     // erase the outliers in list order (:517-528): ordered compaction of the (p, c) pairs
     {
       int base = sh_nout;
@@ -428,6 +495,7 @@ DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
       if (threadIdx.x == 0) sh_nout = base;
       __syncthreads();
     }
+    BA_STAMP(12);
   }
   if (threadIdx.x == 0) {
     R->accepted = sh_error ? -1 : sh_accepted;                         // :170-177

@@ -136,6 +136,24 @@ HDFN void generator_field(int i, const double pos[3], double out[3]) {
   out[(i + 2) % 3] = pos[(i + 1) % 3];
 }
 
+// Image-plane motion (z = 1 plane) of camera-frame point c under generator k of the left-multiplied se3 update:
+// (mot.xy - c.xy * mot.z / c.z) / c.z with mot = generator_field(k, c) (jni/TrackerData.h:112-118, jni/Bundle.cc:279-288).
+// Same expression tree as the reference for every k; written per generator so nothing is indexed dynamically
+// (a dynamically indexed local array lives in scratch memory on the GPU).
+HDFN void se3_generator_motion(int k, const double c[3], double ooz, double& f0, double& f1) {
+  double m0, m1, m2;
+  switch (k) {
+    case 0: m0 = 1.0; m1 = 0.0; m2 = 0.0; break;
+    case 1: m0 = 0.0; m1 = 1.0; m2 = 0.0; break;
+    case 2: m0 = 0.0; m1 = 0.0; m2 = 1.0; break;
+    case 3: m0 = 0.0; m1 = -c[2]; m2 = c[1]; break;
+    case 4: m0 = c[2]; m1 = 0.0; m2 = -c[0]; break;
+    default: m0 = -c[1]; m1 = c[0]; m2 = 0.0; break;
+  }
+  f0 = (m0 - c[0] * m2 * ooz) * ooz;
+  f1 = (m1 - c[1] * m2 * ooz) * ooz;
+}
+
 // ---- camera -------------------------------------------------------------------------------------------------
 HDFN double cam_rtrans_factor(const CamModel& c, double r) {              // jni/ATANCamera.h:136-142
   if (r < 0.001 || c.w == 0.0) return 1.0;
@@ -200,6 +218,41 @@ HDFN bool lu_solve_n(double* A, double* b, int n) {
   return true;
 }
 
+// 6 x 6 version of lu_solve_n with every index a compile-time constant after unrolling, so A and b stay in registers
+// (a dynamically indexed local array lives in scratch memory: ~1 us per dependent access on one lane).  Same pivot rule.
+HDFN bool lu_solve6(double A[36], double b[6]) {
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    int piv = k; double best = fabs(A[k * 6 + k]);
+#pragma unroll
+    for (int r = k + 1; r < 6; r++) { const double a = fabs(A[r * 6 + k]); if (a > best) { best = a; piv = r; } }
+    if (best == 0.0) return false;
+#pragma unroll
+    for (int r = k + 1; r < 6; r++) {
+      const bool sw = (r == piv);
+#pragma unroll
+      for (int c = 0; c < 6; c++) { const double x = A[k * 6 + c], y = A[r * 6 + c]; A[k * 6 + c] = sw ? y : x; A[r * 6 + c] = sw ? x : y; }
+      const double x = b[k], y = b[r]; b[k] = sw ? y : x; b[r] = sw ? x : y;
+    }
+    const double inv = 1.0 / A[k * 6 + k];
+#pragma unroll
+    for (int r = k + 1; r < 6; r++) {
+      const double f = A[r * 6 + k] * inv;
+#pragma unroll
+      for (int c = k + 1; c < 6; c++) A[r * 6 + c] -= f * A[k * 6 + c];
+      b[r] -= f * b[k];
+    }
+  }
+#pragma unroll
+  for (int k = 5; k >= 0; k--) {
+    double s = b[k];
+#pragma unroll
+    for (int c = k + 1; c < 6; c++) s -= A[k * 6 + c] * b[c];
+    b[k] = s / A[k * 6 + k];
+  }
+  return true;
+}
+
 HDFN void inv3(const double m[9], double o[9]) {   // cofactor inverse (Eigen fixed 3x3)
   const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
   const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
@@ -212,6 +265,49 @@ HDFN void inv2(const double m[4], double o[4]) {
   const double id = 1.0 / (m[0] * m[3] - m[1] * m[2]);
   o[0] = m[3] * id; o[1] = -m[1] * id; o[2] = -m[2] * id; o[3] = m[0] * id;
 }
+
+#ifdef __HIPCC__
+// k-th smallest (0-based) of n non-negative doubles in global memory or LDS (bit patterns order like the values):
+// MSB-first radix select, 8 bits per pass, histogram in LDS.  hist: LDS [256] ints, sel: LDS [2] u64.
+DEVFN double block_radix_select(const double* v, int n, int k, int* hist, unsigned long long* sel) {
+  unsigned long long prefix = 0, mask = 0;
+  int kk = k;
+  for (int pass = 0; pass < 8; pass++) {
+    const int shift = 56 - 8 * pass;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const unsigned long long b = (unsigned long long)__double_as_longlong(v[i]);
+      if ((b & mask) == prefix) atomicAdd(&hist[(b >> shift) & 255], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {                                     // wave 0: 4 bins per lane, shuffle prefix sum
+      const int l = threadIdx.x;
+      const int h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
+      const int tot = h0 + h1 + h2 + h3;
+      int inc = tot;
+      for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (l >= d) inc += t; }
+      const unsigned long long bm = __ballot(inc > kk);            // first lane whose inclusive prefix passes kk
+      const int L = __ffsll((long long)bm) - 1;
+      if (l == L) {
+        int acc = inc - tot, bin = 4 * l;
+        if (acc + h0 > kk) { }
+        else if (acc + h0 + h1 > kk) { acc += h0; bin += 1; }
+        else if (acc + h0 + h1 + h2 > kk) { acc += h0 + h1; bin += 2; }
+        else { acc += h0 + h1 + h2; bin += 3; }
+        sel[0] = prefix | ((unsigned long long)bin << shift);
+        sel[1] = (unsigned long long)(kk - acc);
+      }
+    }
+    __syncthreads();
+    prefix = sel[0]; kk = (int)sel[1];
+    mask |= 255ull << shift;
+    __syncthreads();
+  }
+  return __longlong_as_double((long long)prefix);
+}
+
+#endif
 
 HDFN double level_zero_pos(double p, int l) { return (p + 0.5) * (1 << l) - 0.5; }   // jni/LevelHelpers.h:23-25
 HDFN double level_n_pos(double p, int l) { return (p + 0.5) / (1 << l) - 0.5; }      // jni/LevelHelpers.h:37-39

@@ -120,6 +120,32 @@ extern "C" int vslam_map_add_measurements(vslam_system* sys, int s, int n, const
   return VSLAM_OK;
 }
 
+// bulk form of vslam_map_add_point: n points at once (arrays of n; pos/right/down 3n doubles, ir 2n ints)
+extern "C" int vslam_map_add_points(vslam_system* sys, int s, int n, const double* pos, const int* src_keyframe, const int* src_level,
+                                    const int* ir_xy, const double* right, const double* down) {
+  CHK_STREAM(sys, s);
+  TrackerState st;
+  int r = get_state(sys, s, &st); if (r) return r;
+  const int P = sys->p.max_points;
+  if (n < 0 || st.n_points + n > P) { vslam_set_error("map point capacity %d reached", P); return VSLAM_E_CAPACITY; }
+  if (n == 0) return st.n_points;
+  std::vector<MapPointDev> mp(n);
+  std::vector<TrackData> td(n);
+  memset(mp.data(), 0, sizeof(MapPointDev) * n);
+  memset(td.data(), 0, sizeof(TrackData) * n);
+  for (int i = 0; i < n; i++) {
+    if (src_keyframe[i] < 0 || src_keyframe[i] >= st.n_kf || src_level[i] < 0 || src_level[i] >= NLEV) { vslam_set_error("map_add_points: bad entry %d", i); return VSLAM_E_INVALID; }
+    for (int q = 0; q < 3; q++) { mp[i].pos[q] = pos[3 * i + q]; mp[i].right[q] = right[3 * i + q]; mp[i].down[q] = down[3 * i + q]; }
+    mp[i].src_kf = src_keyframe[i]; mp[i].src_level = src_level[i]; mp[i].irx = ir_xy[2 * i]; mp[i].iry = ir_xy[2 * i + 1];
+    td[i].last_warp[0] = 9999.9; td[i].last_warp[3] = 9999.9; td[i].level = -1;   // jni/PatchFinder.cc:23
+  }
+  HIPCHK(hipMemcpy(sys->map.pts + (size_t)s * P + st.n_points, mp.data(), sizeof(MapPointDev) * n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(sys->map.td + (size_t)s * P + st.n_points, td.data(), sizeof(TrackData) * n, hipMemcpyHostToDevice));
+  st.n_points += n;
+  r = put_state(sys, s, &st); if (r) return r;
+  return st.n_points;
+}
+
 extern "C" int vslam_map_set_good(vslam_system* sys, int s) {
   CHK_STREAM(sys, s);
   TrackerState st;

@@ -46,13 +46,14 @@ DEVFN void td_project_and_derivs(TrackData& td, const MapPointDev& p, const Pose
 // TrackerData::CalcJacobian (:107-122)
 DEVFN void td_calc_jacobian(TrackData& td) {
   const double ooz = 1.0 / td.cam[2];
+  const double c[3] = {td.cam[0], td.cam[1], td.cam[2]};
+  const double d0 = td.derivs[0], d1 = td.derivs[1], d2 = td.derivs[2], d3 = td.derivs[3];
+#pragma unroll
   for (int m = 0; m < 6; m++) {
-    double mot[3];
-    generator_field(m, td.cam, mot);
-    const double f0 = (mot[0] - td.cam[0] * mot[2] * ooz) * ooz;
-    const double f1 = (mot[1] - td.cam[1] * mot[2] * ooz) * ooz;
-    td.jac[m] = td.derivs[0] * f0 + td.derivs[1] * f1;
-    td.jac[6 + m] = td.derivs[2] * f0 + td.derivs[3] * f1;
+    double f0, f1;
+    se3_generator_motion(m, c, ooz, f0, f1);
+    td.jac[m] = d0 * f0 + d1 * f1;
+    td.jac[6 + m] = d2 * f0 + d3 * f1;
   }
 }
 
@@ -255,7 +256,9 @@ __global__ __launch_bounds__(64) void k_search(MapDev m, TrackParams tp, SearchA
     double px = (double)p.irx - (m2[0] * HALF + m2[1] * HALF), py = (double)p.iry - (m2[2] * HALF + m2[3] * HALF);
     const double cr[2] = {down[0] - PS * across[0], down[1] - PS * across[1]};
     double myx[2] = {0, 0}, myy[2] = {0, 0};
+#pragma unroll 1
     for (int i = 0; i < PS; i++) {
+#pragma unroll 1
       for (int j = 0; j < PS; j++) {
         const int k = i * PS + j;
         if ((k & 63) == lane) { myx[k >> 6] = px; myy[k >> 6] = py; }
@@ -445,46 +448,31 @@ __global__ __launch_bounds__(64) void k_search(MapDev m, TrackParams tp, SearchA
 
 // ---------------------------------------------------------------------------------------------------------------
 // Block-wide helpers for k_pose
-DEVFN void bitonic_sort_lds(double* buf, int npad) {
-  for (int k = 2; k <= npad; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < npad; i += TRK_THREADS) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const double x = buf[i], y = buf[ixj];
-          const bool up = (i & k) == 0;
-          if ((x > y) == up) { buf[i] = y; buf[ixj] = x; }
-        }
-      }
-      __syncthreads();
-    }
-}
+#define POSE_THREADS 512
+#define POSE_WAVES (POSE_THREADS / 64)
 
 // CalcPoseUpdate, jni/Tracker.cc:683-774 (Tukey).  All threads of the workgroup call it; result in up[6] (LDS).
 DEVFN void calc_pose_update(TrackData* td, MapPointDev* pts, const int* ilist, int n, const TrackParams& tp,
-                            double dOverrideSigma, bool bMarkOutliers, double* sortbuf, double* red /* [4][28] */,
-                            double* up /* [6] */, int* icnt) {
+                            double dOverrideSigma, bool bMarkOutliers, double* sortbuf, double* red /* [waves][28] */,
+                            double* up /* [6] */, int* icnt, int* hist /* [256] */, unsigned long long* sel /* [2] */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int npad = 64;
-  while (npad < n) npad <<= 1;
   int nvalid = 0;
-  for (int e = threadIdx.x; e < npad; e += TRK_THREADS) {
+  for (int e = threadIdx.x; e < n; e += POSE_THREADS) {
     double e2 = __builtin_huge_val();
-    if (e < n) {
-      TrackData& t = td[ilist[e]];
-      if (t.flags & TDF_FOUND) {
-        t.err[0] = (t.vfound[0] - t.image[0]) * t.sqrt_inv_noise;   // :707
-        t.err[1] = (t.vfound[1] - t.image[1]) * t.sqrt_inv_noise;
-        e2 = t.err[0] * t.err[0] + t.err[1] * t.err[1];
-        nvalid++;
-      }
+    TrackData& t = td[ilist[e]];
+    if (t.flags & TDF_FOUND) {
+      t.err[0] = (t.vfound[0] - t.image[0]) * t.sqrt_inv_noise;     // :707
+      t.err[1] = (t.vfound[1] - t.image[1]) * t.sqrt_inv_noise;
+      e2 = t.err[0] * t.err[0] + t.err[1] * t.err[1];
+      nvalid++;
     }
     sortbuf[e] = e2;
   }
   nvalid = wave_sum_i(nvalid);
   if (lane == 0) icnt[wave] = nvalid;
   __syncthreads();
-  nvalid = icnt[0] + icnt[1] + icnt[2] + icnt[3];
+  nvalid = 0;
+  for (int w = 0; w < POSE_WAVES; w++) nvalid += icnt[w];
   if (nvalid == 0) {                                                // :712-716
     if (threadIdx.x < 6) up[threadIdx.x] = 0.0;
     __syncthreads();
@@ -492,14 +480,14 @@ DEVFN void calc_pose_update(TrackData* td, MapPointDev* pts, const int* ilist, i
   }
   double sigma2;
   if (dOverrideSigma > 0) sigma2 = dOverrideSigma;                  // :720-721
-  else {
-    bitonic_sort_lds(sortbuf, npad);                                // Tukey::FindSigmaSquared, jni/MEstimator.h:67-77
-    sigma2 = tukey_sigma_squared(sortbuf[nvalid / 2], (unsigned long)nvalid);
+  else {                                                            // Tukey::FindSigmaSquared, jni/MEstimator.h:67-77
+    const double med = block_radix_select(sortbuf, n, nvalid / 2, hist, sel);   // same order statistic as sort + [n/2]
+    sigma2 = tukey_sigma_squared(med, (unsigned long)nvalid);
   }
   const bool qint = (tp.quirks & VSLAM_Q_POSE_INT_RESIDUAL) != 0;
   double acc[27];
   for (int i = 0; i < 27; i++) acc[i] = 0.0;
-  for (int e = threadIdx.x; e < n; e += TRK_THREADS) {
+  for (int e = threadIdx.x; e < n; e += POSE_THREADS) {
     const int idx = ilist[e];
     TrackData& t = td[idx];
     if (!(t.flags & TDF_FOUND)) continue;
@@ -526,11 +514,17 @@ DEVFN void calc_pose_update(TrackData* td, MapPointDev* pts, const int* ilist, i
     int q = 0;
     for (int r = 0; r < 6; r++)
       for (int c = r; c < 6; c++) {
-        const double x = ((red[q] + red[28 + q]) + red[56 + q]) + red[84 + q];
+        double x = 0.0;
+        for (int w = 0; w < POSE_WAVES; w++) x += red[w * 28 + q];          // fixed order: deterministic
         C[r * 6 + c] = x; C[c * 6 + r] = x; q++;
       }
-    for (int r = 0; r < 6; r++) { C[r * 6 + r] += tp.wls_prior; v[r] = ((red[21 + r] + red[28 + 21 + r]) + red[56 + 21 + r]) + red[84 + 21 + r]; }   // add_prior(100), :734
-    if (!lu_solve_n(C, v, 6)) for (int r = 0; r < 6; r++) v[r] = 0.0;
+    for (int r = 0; r < 6; r++) {
+      C[r * 6 + r] += tp.wls_prior;                                        // add_prior(100), :734
+      double x = 0.0;
+      for (int w = 0; w < POSE_WAVES; w++) x += red[w * 28 + 21 + r];
+      v[r] = x;
+    }
+    if (!lu_solve6(C, v)) for (int r = 0; r < 6; r++) v[r] = 0.0;
     for (int r = 0; r < 6; r++) up[r] = v[r];
   }
   __syncthreads();
@@ -544,7 +538,7 @@ DEVFN double kf_linear_dist(const Pose& a, const Pose& b) {
 }
 
 // stage 0: coarse GN iterations (:463-490); stage 1: fine GN iterations + end of TrackMap/TrackFrame.
-__global__ __launch_bounds__(TRK_THREADS) void k_pose(MapDev m, TrackParams tp, int stage) {
+__global__ __launch_bounds__(POSE_THREADS) void k_pose(MapDev m, TrackParams tp, int stage) {
   const int s = blockIdx.x;
   TrackerState* st = &m.st[s];
   if (!(st->map_good && st->lost_frames < 3)) return;
@@ -553,9 +547,11 @@ __global__ __launch_bounds__(TRK_THREADS) void k_pose(MapDev m, TrackParams tp, 
   MapPointDev* pts = m.pts + (size_t)s * P;
   const int* ilist = m.iter_list + (size_t)s * P;
   __shared__ double sortbuf[SORT_CAP];
-  __shared__ double red[4 * 28];
+  __shared__ double red[POSE_WAVES * 28 + 2];
   __shared__ double up[6], last_up[6];
-  __shared__ int icnt[4];
+  __shared__ int icnt[POSE_WAVES];
+  __shared__ int hist[256];
+  __shared__ unsigned long long sel[2];
   __shared__ Pose pose;
   if (threadIdx.x == 0) pose = st->pose_cur;
   __syncthreads();
@@ -565,14 +561,14 @@ __global__ __launch_bounds__(TRK_THREADS) void k_pose(MapDev m, TrackParams tp, 
     const int nFound = st->found[0] + st->found[1] + st->found[2] + st->found[3];
     if (nFound < tp.coarse_min) return;                              // :465
     for (int iter = 0; iter < 10; iter++) {
-      for (int e = threadIdx.x; e < n; e += TRK_THREADS) {
+      for (int e = threadIdx.x; e < n; e += POSE_THREADS) {
         TrackData& t = td[ilist[e]];
         if (!(t.flags & TDF_FOUND)) continue;
         if (iter != 0) td_project_and_derivs(t, pts[ilist[e]], pose, tp.cam);
         td_calc_jacobian(t);
       }
       __syncthreads();
-      calc_pose_update(td, pts, ilist, n, tp, iter > 5 ? 1.0 : 0.0, false, sortbuf, red, up, icnt);
+      calc_pose_update(td, pts, ilist, n, tp, iter > 5 ? 1.0 : 0.0, false, sortbuf, red, up, icnt, hist, sel);
       if (threadIdx.x == 0) pose = pose_mul(se3_exp(up), pose);      // :487
       __syncthreads();
     }
@@ -584,7 +580,7 @@ __global__ __launch_bounds__(TRK_THREADS) void k_pose(MapDev m, TrackParams tp, 
   __syncthreads();
   for (int iter = 0; iter < 10; iter++) {                            // :543-577
     const bool nonlinear = (iter == 0 || iter == 4 || iter == 9);
-    for (int e = threadIdx.x; e < n; e += TRK_THREADS) {
+    for (int e = threadIdx.x; e < n; e += POSE_THREADS) {
       TrackData& t = td[ilist[e]];
       if (!(t.flags & TDF_FOUND)) continue;
       if (iter != 0) {
@@ -598,17 +594,17 @@ __global__ __launch_bounds__(TRK_THREADS) void k_pose(MapDev m, TrackParams tp, 
       if (nonlinear) td_calc_jacobian(t);
     }
     __syncthreads();
-    calc_pose_update(td, pts, ilist, n, tp, iter > 5 ? 16.0 : 0.0, iter == 9, sortbuf, red, up, icnt);
+    calc_pose_update(td, pts, ilist, n, tp, iter > 5 ? 16.0 : 0.0, iter == 9, sortbuf, red, up, icnt, hist, sel);
     if (threadIdx.x == 0) pose = pose_mul(se3_exp(up), pose);
     if (threadIdx.x < 6) last_up[threadIdx.x] = up[threadIdx.x];
     __syncthreads();
   }
   // ---- measurement export (:594-607) and scene depth (:610-625) ----
   MeasDev* cm = m.cur_meas + (size_t)s * P;
-  for (int i = threadIdx.x; i < st->n_points; i += TRK_THREADS) cm[i].valid = 0;
+  for (int i = threadIdx.x; i < st->n_points; i += POSE_THREADS) cm[i].valid = 0;
   __syncthreads();
   double dSum = 0, dSumSq = 0; int nNum = 0;
-  for (int e = threadIdx.x; e < n; e += TRK_THREADS) {
+  for (int e = threadIdx.x; e < n; e += POSE_THREADS) {
     const int idx = ilist[e];
     const TrackData& t = td[idx];
     if (!(t.flags & TDF_FOUND)) continue;
@@ -624,9 +620,8 @@ __global__ __launch_bounds__(TRK_THREADS) void k_pose(MapDev m, TrackParams tp, 
   if (lane == 0) { red[wave * 28] = dSum; red[wave * 28 + 1] = dSumSq; icnt[wave] = nNum; }
   __syncthreads();
   if (threadIdx.x != 0) return;
-  dSum = ((red[0] + red[28]) + red[56]) + red[84];
-  dSumSq = ((red[1] + red[29]) + red[57]) + red[85];
-  nNum = icnt[0] + icnt[1] + icnt[2] + icnt[3];
+  dSum = 0; dSumSq = 0; nNum = 0;
+  for (int w = 0; w < POSE_WAVES; w++) { dSum += red[w * 28]; dSumSq += red[w * 28 + 1]; nNum += icnt[w]; }
   if (nNum > 20) {
     st->depth_mean = dSum / nNum;
     st->depth_sigma = sqrt((dSumSq / nNum) - (st->depth_mean) * (st->depth_mean));
@@ -758,7 +753,7 @@ int trk_track_map(vslam_system* sys) {
     if (tp.P == 8) hipLaunchKernelGGL(k_search<8>, dim3(nc, S), dim3(64), 0, sys->stream, m, tp, a, 0);
     else hipLaunchKernelGGL(k_search<11>, dim3(nc, S), dim3(64), 0, sys->stream, m, tp, a, 0);
     prof_mark(sys, 6);
-    hipLaunchKernelGGL(k_pose, dim3(S), dim3(TRK_THREADS), 0, sys->stream, m, tp, 0);
+    hipLaunchKernelGGL(k_pose, dim3(S), dim3(POSE_THREADS), 0, sys->stream, m, tp, 0);
   } else prof_mark(sys, 6);
   prof_mark(sys, 7);
   hipLaunchKernelGGL(k_plan, dim3(S), dim3(TRK_THREADS), 0, sys->stream, m, tp, 1);
@@ -766,7 +761,7 @@ int trk_track_map(vslam_system* sys) {
   if (tp.P == 8) hipLaunchKernelGGL(k_search<8>, dim3(maxSearch, S), dim3(64), 0, sys->stream, m, tp, a, 1);
   else hipLaunchKernelGGL(k_search<11>, dim3(maxSearch, S), dim3(64), 0, sys->stream, m, tp, a, 1);
   prof_mark(sys, 9);
-  hipLaunchKernelGGL(k_pose, dim3(S), dim3(TRK_THREADS), 0, sys->stream, m, tp, 1);
+  hipLaunchKernelGGL(k_pose, dim3(S), dim3(POSE_THREADS), 0, sys->stream, m, tp, 1);
   HIPCHK(hipGetLastError());
   return VSLAM_OK;
 }

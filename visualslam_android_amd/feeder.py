@@ -97,8 +97,26 @@ def se3_perturb(pose12, rng, trans_sigma, rot_sigma):
     return np.concatenate([(dR @ R).ravel(), dR @ t + dt])
 
 
+def _unproject_np(cam, w, h, ix, iy):
+    """ATANCamera::UnProject (jni/ATANCamera.cc:149-164) vectorised (host harness code)."""
+    fx, fy, cx, cy, ww = w * cam[0], h * cam[1], w * cam[2] - 0.5, h * cam[3] - 0.5, cam[4]
+    dx, dy = (ix - cx) / fx, (iy - cy) / fy
+    dr = np.hypot(dx, dy)
+    r = dr if ww == 0.0 else np.tan(dr * ww) / (2.0 * np.tan(ww / 2.0))
+    f = np.where(dr > 0.01, r / np.maximum(dr, 1e-300), 1.0)
+    return dx * f, dy * f
+
+
+def _project_np(cam, w, h, x, y):
+    """ATANCamera::Project (jni/ATANCamera.cc:133-145) vectorised."""
+    fx, fy, cx, cy, ww = w * cam[0], h * cam[1], w * cam[2] - 0.5, h * cam[3] - 0.5, cam[4]
+    r = np.hypot(x, y)
+    fac = np.where((r < 0.001) | (ww == 0.0), 1.0, np.arctan(r * 2.0 * np.tan(ww / 2.0)) / ww / np.maximum(r, 1e-300))
+    return cx + fx * x * fac, cy + fy * y * fac
+
+
 def build_map(feeder, corner_fn, n_keyframes=8, kf_spacing=20, per_level=(260, 90, 32, 12), patch_border=10,
-              point_noise=0.0, pose_noise=(0.0, 0.0), seed=7):
+              point_noise=0.0, pose_noise=(0.0, 0.0), seed=7, cam=REF_CAM):
     """Ground-truth initial map from `n_keyframes` source keyframes at frames -spacing*n .. -spacing.
 
     corner_fn(gray) -> list of 4 arrays of packed (x | y<<16) maximal FAST corners per level (from the HIP
@@ -106,62 +124,87 @@ def build_map(feeder, corner_fn, n_keyframes=8, kf_spacing=20, per_level=(260, 9
       keyframes: list of {pose, fixed, image, depth_mean, depth_sigma}
       points:    list of {pos, src_kf, level, irx, iry, right, down}
       meas:      list of (kf, point, level, root_x, root_y, subpix, source)
-    Points are thinned on a grid per level so no two share a cell; measurements of a point in the other
-    keyframes are its exact projections (the bootstrap that would produce them is out of scope).
+    Points are thinned on a grid per level (first corner of each cell in raster order); a corner is back-projected onto
+    the plane z = 0 and given the patch vectors of MapMaker::AddPointEpipolar (jni/MapMaker.cc:652-684) +
+    MapPoint::RefreshPixelVectors (jni/MapPoint.cc:4-29); its measurements in the other keyframes are its exact
+    projections (the bootstrap that would produce them is out of scope).
     """
     rng = np.random.default_rng(seed)
+    W, H = feeder.w, feeder.h
     times = [-kf_spacing * (n_keyframes - k) for k in range(n_keyframes)]
     kfs, points, meas = [], [], []
-    true_poses = []
-    for k, t in enumerate(times):
-        pose = feeder.pose(t)
-        img = feeder.render_pose(pose, key=1000 + k)
-        true_poses.append(pose)
-        kfs.append({"pose": pose.copy(), "fixed": k == 0, "image": img, "depth_mean": 1.0, "depth_sigma": 0.1})
+    poses = [feeder.pose(t) for t in times]
+    Rs = [p[:9].reshape(3, 3) for p in poses]
+    ts = [p[9:] for p in poses]
+    for k in range(n_keyframes):
+        img = feeder.render_pose(poses[k], key=1000 + k)
+        kfs.append({"pose": poses[k].copy(), "fixed": k == 0, "image": img, "depth_mean": 1.0, "depth_sigma": 0.1})
+    depth_acc = [[] for _ in range(n_keyframes)]
     for k in range(n_keyframes):
         corners = corner_fn(kfs[k]["image"])
+        R, t = Rs[k], ts[k]
+        C = -R.T @ t
         for level in range(4):
             c = np.asarray(corners[level], np.uint32)
             if len(c) == 0:
                 continue
             xs = (c & 0xFFFF).astype(np.int64)
             ys = (c >> 16).astype(np.int64)
-            lw, lh = feeder.w >> level, feeder.h >> level
+            lw, lh = W >> level, H >> level
             ok = (xs >= patch_border) & (ys >= patch_border) & (xs < lw - patch_border) & (ys < lh - patch_border)
             xs, ys = xs[ok], ys[ok]
-            # one corner per grid cell, cells visited in raster order -> deterministic thinning
             cell = max(4, int(np.sqrt(lw * lh / max(1, per_level[level] * 2))))
-            seen = set()
-            n_added = 0
-            for x, y in zip(xs, ys):
-                key = (x // cell, y // cell)
-                if key in seen:
+            key = (ys // cell) * 100000 + (xs // cell)
+            _u, first = np.unique(key, return_index=True)       # first corner of every cell, raster order kept below
+            first = np.sort(first)[:per_level[level]]
+            xs, ys = xs[first], ys[first]
+            if len(xs) == 0:
+                continue
+            s = 1 << level
+            rx, ry = (xs + 0.5) * s - 0.5, (ys + 0.5) * s - 0.5  # LevelZeroPos
+            cx, cy = _unproject_np(cam, W, H, rx, ry)
+            d = np.stack([cx, cy, np.ones_like(cx)], 1) @ R      # R^T applied to rays (row vectors)
+            good = d[:, 2] > 1e-9
+            lam = -C[2] / np.where(good, d[:, 2], 1.0)
+            pos = C[None, :] + lam[:, None] * d
+            pos[:, 2] = 0.0
+            # patch vectors
+            def unit(ix, iy):
+                ux, uy = _unproject_np(cam, W, H, ix, iy)
+                v = np.stack([ux, uy, np.ones_like(ux)], 1)
+                return v / np.linalg.norm(v, axis=1, keepdims=True)
+            cen, rgt, dwn = unit(rx, ry), unit(rx + s, ry), unit(rx, ry + s)
+            pc = pos @ R.T + t[None, :]
+            camh = np.abs(pc[:, 2])                               # |v3PlanePoint_C . (0,0,-1)|
+            cop = cen * (camh / np.abs(cen[:, 2]))[:, None]
+            rop = rgt * (camh / np.abs(rgt[:, 2]))[:, None]
+            dop = dwn * (camh / np.abs(dwn[:, 2]))[:, None]
+            right_w = (rop - cop) @ R                             # R^T * v for row vectors
+            down_w = (dop - cop) @ R
+            base = len(points)
+            idx = np.flatnonzero(good)
+            for j in idx:
+                points.append({"pos": pos[j].copy(), "src_kf": k, "level": level, "irx": int(xs[j]), "iry": int(ys[j]),
+                               "right": right_w[j].copy(), "down": down_w[j].copy()})
+            pid = base + np.arange(len(idx))
+            for j, q in zip(idx, pid):
+                meas.append((k, int(q), level, float(rx[j]), float(ry[j]), 1, 2))   # SRC_ROOT
+            depth_acc[k].extend(pc[idx, 2].tolist())
+            for k2 in range(n_keyframes):
+                if k2 == k:
                     continue
-                seen.add(key)
-                mp = feeder.make_point(true_poses[k], level, x, y)
-                if mp is None:
-                    continue
-                pos, right, down = mp
-                pid = len(points)
-                points.append({"pos": pos, "src_kf": k, "level": level, "irx": int(x), "iry": int(y), "right": right, "down": down})
-                s = 1 << level
-                meas.append((k, pid, level, (x + 0.5) * s - 0.5, (y + 0.5) * s - 0.5, 1, 2))   # SRC_ROOT
-                for k2 in range(n_keyframes):
-                    if k2 == k:
-                        continue
-                    inside, im, _ = feeder.project(true_poses[k2], pos, border=12 * s)
-                    if inside:
-                        meas.append((k2, pid, level, float(im[0]), float(im[1]), 1, 0))     # SRC_TRACKER
-                n_added += 1
-                if n_added >= per_level[level]:
-                    break
+                pc2 = pos[idx] @ Rs[k2].T + ts[k2][None, :]
+                z = pc2[:, 2]
+                zz = np.where(z > 0.001, z, 1.0)
+                u, v = _project_np(cam, W, H, pc2[:, 0] / zz, pc2[:, 1] / zz)
+                b = 12 * s
+                ins = (z > 0.001) & (u >= b) & (v >= b) & (u < W - b) & (v < H - b)
+                for q, uu, vv, zq in zip(pid[ins], u[ins], v[ins], z[ins]):
+                    meas.append((k2, int(q), level, float(uu), float(vv), 1, 0))    # SRC_TRACKER
+                depth_acc[k2].extend(z[ins].tolist())
     # scene depth per keyframe (MapMaker::RefreshSceneDepth, jni/MapMaker.cc:1236-1252)
     for k in range(n_keyframes):
-        zs = []
-        for (kk, pid, *_r) in meas:
-            if kk == k:
-                zs.append(feeder.project(true_poses[k], points[pid]["pos"])[2])
-        zs = np.array(zs)
+        zs = np.array(depth_acc[k])
         kfs[k]["depth_mean"] = float(zs.mean())
         kfs[k]["depth_sigma"] = float(np.sqrt(max(0.0, (zs ** 2).mean() - zs.mean() ** 2)))
     if point_noise > 0:
