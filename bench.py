@@ -68,7 +68,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("VSLAM_BENCH_STREAMS", 64)), help="sequences per GPU")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("VSLAM_BENCH_STREAMS", 256)), help="sequences per GPU")
+    ap.add_argument("--systems", type=int, default=int(os.environ.get("VSLAM_BENCH_SYSTEMS", 1)),
+                    help="split the streams over this many vslam_system handles (one HIP stream each) so their kernels overlap")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--patch", type=int, default=8, help="PatchFinder template side (BASELINE configs: 8; reference default 11)")
@@ -106,10 +108,19 @@ def main():
 
     maps = [feeder.build_map(f, corner_fn) for f in feeders]
     fe.close()
-    sysm = capi.System(vp)
+    NS = max(1, min(args.systems, S))
+    assert S % NS == 0, "--streams must be a multiple of --systems"
+    Sk = S // NS
+    vpk = capi.default_params(W, H, Sk, patch_size=args.patch, device=local_rank)
+    systems = [capi.System(vpk) for _ in range(NS)]
+
+    def sys_of(s):
+        return systems[s // Sk], s % Sk
+
     for s in range(S):
-        sysm.load_map(s, maps[s])
-        sysm.set_pose(s, feeders[s].pose(-1))
+        sy, ls = sys_of(s)
+        sy.load_map(ls, maps[s])
+        sy.set_pose(ls, feeders[s].pose(-1))
     frames_dev = torch.empty((T, S, H, W), dtype=torch.uint8, device="cuda")
     host_frames0 = None
     with ThreadPoolExecutor(max(1, nthreads // 4)) as ex:
@@ -123,28 +134,44 @@ def main():
     fstride = S * H * W
 
     def step(t):
-        sysm.track_frame_device(base + t * fstride, W, H * W)
+        for k, sy in enumerate(systems):
+            sy.track_frame_device(base + t * fstride + k * Sk * H * W, W, H * W)
+
+    def sync_all():
+        for sy in systems:
+            sy.synchronize()
+
+    def state(s):
+        sy, ls = sys_of(s)
+        return sy.state(ls)
 
     # ---- warm-up, then the timed region ---------------------------------------------------------------------------------
     for t in range(Wm):
         step(t)
-    sysm.synchronize()
-    st0 = [sysm.state(s) for s in range(S)]
+    sync_all()
+    st0 = [state(s) for s in range(S)]
     if not args.no_events:
-        sysm.profile_begin(K)
+        for sy in systems:
+            sy.profile_begin(K)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for t in range(Wm, T):
         step(t)
-    sysm.synchronize()
+    sync_all()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
-    stage_ms, nprof = ({}, 0) if args.no_events else sysm.profile_end()
-    st1 = [sysm.state(s) for s in range(S)]
+    stage_ms, nprof = {}, 0
+    if not args.no_events:
+        for sy in systems:                      # per-launch durations: summed over systems, averaged below over launches
+            ms, n = sy.profile_end()
+            nprof += n
+            for k_, v_ in ms.items():
+                stage_ms[k_] = stage_ms.get(k_, 0.0) + v_
+    st1 = [state(s) for s in range(S)]
 
     # ---- per-stream workload statistics (for the algorithmic-byte formulas) ---------------------------------------------
     zm = float(np.mean([(b.n_zmssd - a.n_zmssd) / K for a, b in zip(st0, st1)]))
@@ -153,8 +180,8 @@ def main():
     kf_adds = float(np.mean([b.n_keyframes - a.n_keyframes for a, b in zip(st0, st1)]))
     ba_trials = float(np.mean([b.n_ba_trials - a.n_ba_trials for a, b in zip(st0, st1)]))
     good = int(sum(1 for b in st1 if b.quality == 2))
-    ncorn = float(len(sysm.read_corners(0, 0)))
-    km = sysm.keyframe_meas(0, st1[0].n_keyframes - 1)
+    ncorn = float(len(systems[0].read_corners(0, 0)))
+    km = systems[0].keyframe_meas(0, st1[0].n_keyframes - 1)
     ba_meas = float(len(km["pt"])) * 5 + 0.0
     per_stream = {"corners": ncorn, "patches": att, "zmssd": zm, "found": fnd, "ba_meas": ba_meas, "ba_cams": 5.0,
                   "ba_pts": float(len(km["pt"])), "ba_trials_per_launch": ba_trials / K}
@@ -171,16 +198,16 @@ def main():
         if stage_ms:
             for name, ms in stage_ms.items():
                 per_launch_ms = ms / max(1, nprof)
-                ab = algorithmic_bytes(name, S, W, H, args.patch, per_stream)
+                ab = algorithmic_bytes(name, Sk, W, H, args.patch, per_stream)
                 stages[name] = {"ms_per_launch": round(per_launch_ms, 5), "algorithmic_GBps": round(ab / (per_launch_ms * 1e-3) / 1e9, 3) if per_launch_ms > 0 and ab > 0 else None}
-            dom = max((n for n in stage_ms if algorithmic_bytes(n, S, W, H, args.patch, per_stream) > 0), key=lambda n: stage_ms[n])
+            dom = max((n for n in stage_ms if algorithmic_bytes(n, Sk, W, H, args.patch, per_stream) > 0), key=lambda n: stage_ms[n])
             dms = stage_ms[dom] / max(1, nprof)
-            ach = algorithmic_bytes(dom, S, W, H, args.patch, per_stream) / (dms * 1e-3) / 1e9
+            ach = algorithmic_bytes(dom, Sk, W, H, args.patch, per_stream) / (dms * 1e-3) / 1e9
             roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None, "ms_per_launch": round(dms, 5)}
         # ---- CPU baseline: the oracle's TrackFrame + BA on one core over a bounded sample of the same frames -------------
         from oracle import binding as orc
-        o = orc.OracleSystem(orc.params_from_vslam(vp))
+        o = orc.OracleSystem(orc.params_from_vslam(vpk))
         o.load_map(maps[0])
         o.set_pose(feeders[0].pose(-1))
         tc = time.perf_counter()
@@ -200,7 +227,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: %dx%d 4-level FAST-10 + %dx%d PatchFinder ZMSSD search, TrackMap pose update, "
                                    "AddKeyFrame + BundleAdjustRecent on keyframe frames" % (W, H, args.patch, args.patch),
-                       "streams_per_gpu": S, "patch_size": args.patch, "corners_l0_per_frame": ncorn,
+                       "streams_per_gpu": S, "systems_per_gpu": NS, "patch_size": args.patch, "corners_l0_per_frame": ncorn,
                        "patches_attempted_per_frame": round(att, 1), "patches_found_per_frame": round(fnd, 1),
                        "zmssd_evals_per_frame": round(zm, 1), "keyframes_added_per_stream": kf_adds,
                        "ba_trials_per_stream": ba_trials, "streams_tracking_good": good, "setup_seconds": round(setup_s, 1)},

@@ -4,12 +4,13 @@
 // Kernels (all HBM-bound byte/integer work; one pass over each level image):
 //   k_pyr_fast0   one workgroup per 16-row band of level 0: the band (+3-row halo) is staged in LDS
 //                 with 16-B coalesced loads, levels 1..3 of the band are produced from LDS
-//                 ((a+b+c+d+2)>>2) and written, and FAST-10 runs on the staged rows; one wave tests 64
-//                 consecutive pixels, __ballot gives the 64-bit corner-mask word and the row count.
+//                 ((a+b+c+d+2)>>2) and written, and FAST-10 runs on the staged rows in two phases: a 5-read
+//                 quick reject on every pixel, then the full segment test on the compacted survivors, which
+//                 set bits of the band's 64-bit corner-mask words in LDS.
 //   k_fast_lvl    the same FAST band sweep for levels 1..3 (their rows come back from L2/MALL).
-//   k_compact     per (stream, level): exclusive scan of the row counts = the reference's row LUT
-//                 (jni/KeyFrame.cc:43-49); each wave expands mask words into the raster-ordered corner
-//                 list at lut[y] + popcount prefix -> bit-exact order without ordered atomics.
+//   k_compact     per (stream, level): block scan over the popcounts of the mask words (raster order); every
+//                 thread expands its words at its scanned offset -> bit-exact raster-ordered corner list
+//                 and row LUT (jni/KeyFrame.cc:43-49) without ordered atomics.
 //   k_score / k_nonmax   compute_fast_score_old + nonmax_suppression, one lane per corner.
 #include "vslam_internal.h"
 
@@ -39,14 +40,20 @@ __device__ __forceinline__ bool ring_run10(unsigned m16) {
   return (r10 & 0xFFFFu) != 0;
 }
 
-// FAST-10 segment test at LDS pixel p (row pitch lp): >=10 contiguous ring pixels all > c+t or all < c-t
-// (cvfast.cpp:6088-9241; equivalence with the decision tree is pinned in tests/golden/fast10_tree_pin.json).
-__device__ __forceinline__ bool fast10_at(const uint8_t* p, int lp, int t) {
+// FAST-10 segment test (cvfast.cpp:6088-9241; equivalence with the decision tree is pinned in
+// tests/golden/fast10_tree_pin.json), split in two so the expensive part runs on densely packed lanes:
+//   fast10_quick: an arc of 10 contiguous ring pixels contains at least one pixel of every opposite pair, so a corner
+//                 needs (p0 or p8) AND (p4 or p12) outside [c-t, c+t] -- 5 LDS byte reads, rejects most pixels;
+//   fast10_full : the 16-pixel brighter/darker masks and the run-of-10 test.
+__device__ __forceinline__ bool fast10_quick(const uint8_t* p, int lp, int t) {
   const int c = p[0], cb = c + t, c_b = c - t;
   const int p0 = p[3 * lp], p8 = p[-3 * lp];
-  if (!(p0 > cb || p0 < c_b || p8 > cb || p8 < c_b)) return false;   // an arc of 10 holds one of each opposite pair
+  if (!(p0 > cb || p0 < c_b || p8 > cb || p8 < c_b)) return false;
   const int p4 = p[3], p12 = p[-3];
-  if (!(p4 > cb || p4 < c_b || p12 > cb || p12 < c_b)) return false;
+  return p4 > cb || p4 < c_b || p12 > cb || p12 < c_b;
+}
+__device__ __forceinline__ bool fast10_full(const uint8_t* p, int lp, int t) {
+  const int c = p[0], cb = c + t, c_b = c - t;
   unsigned mb = 0, md = 0;
 #define RINGPIX(k, dx, dy) { const int v = p[(dx) + (dy) * lp]; mb |= (unsigned)(v > cb) << (k); md |= (unsigned)(v < c_b) << (k); }
   RINGPIX(0, 0, 3) RINGPIX(1, 1, 3) RINGPIX(2, 2, 2) RINGPIX(3, 3, 1) RINGPIX(4, 3, 0) RINGPIX(5, 3, -1)
@@ -76,27 +83,47 @@ __device__ __forceinline__ void stage_rows(uint8_t* tile, int lp, const uint8_t*
 }
 
 // FAST over nrows image rows starting at y0; tile row 0 holds image row y0 - HALO.
+// Per group of FB_ROWS rows: (A) every pixel runs the quick reject, survivors are appended (wave-aggregated) to an LDS
+// candidate list; (B) the full test runs over the dense list and sets bits of the band's corner mask in LDS.
+// Finally the mask words and the row counts go to global memory with coalesced stores.
+#define FB_ROWS 4
 __device__ __forceinline__ void fast_band(const uint8_t* tile, int lp, int y0, int nrows, int w, int h, int thr,
                                           int nchunk, unsigned long long* cmask /* [h][nchunk] */,
-                                          int* rowcnt /* [h] */, int* cnt_lds /* [BAND] */) {
+                                          int* rowcnt /* [h] */, unsigned long long* mask_lds, unsigned short* cand, int* ncand) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
-  if (threadIdx.x < BAND) cnt_lds[threadIdx.x] = 0;
-  __syncthreads();
-  const int items = nrows * nchunk;
-  for (int it = wave; it < items; it += nwave) {
-    const int r = it / nchunk, c = it - r * nchunk;
-    const int y = y0 + r, x = (c << 6) + lane;
-    bool flag = false;
-    if (y >= HALO && y < h - HALO && x >= HALO && x < w - HALO)      // cvfast.cpp:6113-6117
-      flag = fast10_at(tile + (r + HALO) * lp + x, lp, thr);
-    const unsigned long long m = __ballot(flag);
-    if (lane == 0) {
-      cmask[(size_t)y * nchunk + c] = m;
-      if (m) atomicAdd(&cnt_lds[r], __popcll(m));
+  for (int i = threadIdx.x; i < nrows * nchunk; i += blockDim.x) mask_lds[i] = 0ull;
+  for (int r0 = 0; r0 < nrows; r0 += FB_ROWS) {
+    if (threadIdx.x == 0) *ncand = 0;
+    __syncthreads();
+    const int gr = min(FB_ROWS, nrows - r0);
+    for (int it = wave; it < gr * nchunk; it += nwave) {             // (A) quick reject
+      const int r = r0 + it / nchunk, c = it % nchunk;
+      const int y = y0 + r, x = (c << 6) + lane;
+      bool pass = false;
+      if (y >= HALO && y < h - HALO && x >= HALO && x < w - HALO)    // cvfast.cpp:6113-6117
+        pass = fast10_quick(tile + (r + HALO) * lp + x, lp, thr);
+      const unsigned long long bm = __ballot(pass);
+      if (bm) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(ncand, __popcll(bm));
+        base = __shfl(base, 0);
+        if (pass) cand[base + __popcll(bm & ((1ull << lane) - 1ull))] = (unsigned short)((r << 12) | x);
+      }
     }
+    __syncthreads();
+    const int n = *ncand;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {               // (B) full segment test on packed lanes
+      const int r = cand[i] >> 12, x = cand[i] & 4095;
+      if (fast10_full(tile + (r + HALO) * lp + x, lp, thr)) atomicOr(&mask_lds[r * nchunk + (x >> 6)], 1ull << (x & 63));
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  if ((int)threadIdx.x < nrows) rowcnt[y0 + threadIdx.x] = cnt_lds[threadIdx.x];
+  for (int i = threadIdx.x; i < nrows * nchunk; i += blockDim.x) cmask[(size_t)y0 * nchunk + i] = mask_lds[i];
+  if ((int)threadIdx.x < nrows) {
+    int c = 0;
+    for (int k = 0; k < nchunk; k++) c += __popcll(mask_lds[threadIdx.x * nchunk + k]);
+    rowcnt[y0 + threadIdx.x] = c;
+  }
 }
 
 // 2x2 box mean of nrows_out output rows: src rows (2j, 2j+1) of an LDS tile -> LDS tile + global.
@@ -130,7 +157,9 @@ __global__ __launch_bounds__(FE_THREADS) void k_pyr_fast0(FeArgs a, int lp0, int
   uint8_t* t0 = lds;                               // (BAND + 2*HALO) rows of level 0
   uint8_t* t1 = t0 + (BAND + 2 * HALO) * lp0;      // BAND/2 rows of level 1
   uint8_t* t2 = t1 + (BAND / 2) * lp1;             // BAND/4 rows of level 2
-  int* cnt = (int*)(t2 + (BAND / 4) * lp2);
+  unsigned long long* mask_lds = (unsigned long long*)(((uintptr_t)(t2 + (BAND / 4) * lp2) + 15) & ~(uintptr_t)15);
+  unsigned short* cand = (unsigned short*)(mask_lds + BAND * a.nchunk[0]);
+  int* ncand = (int*)(cand + FB_ROWS * lp0);
   const int b = blockIdx.x, s = blockIdx.y;
   const uint8_t* in = a.in + (size_t)s * a.in_sstride;
   const int y0 = b * BAND;
@@ -148,7 +177,7 @@ __global__ __launch_bounds__(FE_THREADS) void k_pyr_fast0(FeArgs a, int lp0, int
   // FAST-10 on the level-0 rows of the band
   const int nrows = min(BAND, a.h[0] - y0);
   fast_band(t0, lp0, y0, nrows, a.w[0], a.h[0], a.thr[0], a.nchunk[0],
-            a.cmask[0] + (size_t)s * a.h[0] * a.nchunk[0], a.rowcnt[0] + (size_t)s * a.h[0], cnt);
+            a.cmask[0] + (size_t)s * a.h[0] * a.nchunk[0], a.rowcnt[0] + (size_t)s * a.h[0], mask_lds, cand, ncand);
 }
 
 __global__ __launch_bounds__(FE_THREADS) void k_fast_lvl(FeArgs a) {
@@ -159,67 +188,57 @@ __global__ __launch_bounds__(FE_THREADS) void k_fast_lvl(FeArgs a) {
   const int b = blockIdx.x - a.band_first[l], s = blockIdx.y;
   const int lp = (a.w[l] + 15) & ~15;
   uint8_t* t = lds;
-  int* cnt = (int*)(t + (BAND + 2 * HALO) * lp);
+  unsigned long long* mask_lds = (unsigned long long*)(((uintptr_t)(t + (BAND + 2 * HALO) * lp) + 15) & ~(uintptr_t)15);
+  unsigned short* cand = (unsigned short*)(mask_lds + BAND * a.nchunk[l]);
+  int* ncand = (int*)(cand + FB_ROWS * lp);
   const int y0 = b * BAND;
   stage_rows(t, lp, a.lvl[l] + (size_t)s * a.lvl_sstride[l], a.lvl_pitch[l], a.w[l], a.h[l], y0 - HALO, BAND + 2 * HALO);
   __syncthreads();
   const int nrows = min(BAND, a.h[l] - y0);
   fast_band(t, lp, y0, nrows, a.w[l], a.h[l], a.thr[l], a.nchunk[l],
-            a.cmask[l] + (size_t)s * a.h[l] * a.nchunk[l], a.rowcnt[l] + (size_t)s * a.h[l], cnt);
+            a.cmask[l] + (size_t)s * a.h[l] * a.nchunk[l], a.rowcnt[l] + (size_t)s * a.h[l], mask_lds, cand, ncand);
 }
 
-// Block-wide exclusive scan of n ints (n <= 16*256) from global into LDS out[0..n]; out[n] = total.
-__device__ __forceinline__ void block_exscan(const int* in, int n, int* out, int* wsum /* [8] */) {
-  const int per = (n + FE_THREADS - 1) / FE_THREADS;
-  const int lo = min((int)threadIdx.x * per, n), hi = min(lo + per, n);
-  int sum = 0;
-  for (int i = lo; i < hi; i++) sum += in[i];
+// Raster-ordered corner lists + row LUT from the corner bit-masks: one workgroup per (level, stream).  Every thread owns
+// a contiguous run of mask words (word index = row * nchunk + chunk, i.e. raster order), a block-wide exclusive scan of
+// the popcounts gives its output offset, and it expands its bits in order -> the list is bit-exactly the reference's
+// push_back order (cvfast.cpp:9237-9238) with no ordered atomics; lut[y] is the offset of the first word of row y
+// (jni/KeyFrame.cc:43-49).
+#define COMPACT_THREADS 1024
+__global__ __launch_bounds__(COMPACT_THREADS) void k_compact(FeArgs a) {
+  __shared__ int wsum[COMPACT_THREADS / 64];
+  const int l = blockIdx.x, s = blockIdx.y;
+  const int h = a.h[l], nchunk = a.nchunk[l], cap = a.cap[l];
+  const int nw = h * nchunk;
+  const unsigned long long* cm = a.cmask[l] + (size_t)s * nw;
+  uint32_t* out = a.corners[l] + (size_t)s * cap;
+  int* lut = a.rowlut[l] + (size_t)s * (h + 1);
+  const int per = (nw + COMPACT_THREADS - 1) / COMPACT_THREADS;
+  const int lo = min((int)threadIdx.x * per, nw), hi = min(lo + per, nw);
+  int cnt = 0;
+  for (int i = lo; i < hi; i++) cnt += __popcll(cm[i]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int inc = sum;
+  int inc = cnt;
   for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(inc, d); if (lane >= d) inc += v; }
   if (lane == 63) wsum[wave] = inc;
   __syncthreads();
-  int base = 0;
-  for (int w = 0; w < wave; w++) base += wsum[w];
-  int run = base + inc - sum;
-  for (int i = lo; i < hi; i++) { out[i] = run; run += in[i]; }
-  if (threadIdx.x == FE_THREADS - 1) out[n] = run;
-  __syncthreads();
-}
-
-#define COMPACT_RB 8   // workgroups per (stream, level)
-__global__ __launch_bounds__(FE_THREADS) void k_compact(FeArgs a) {
-  __shared__ int lut[4096 + 1];
-  __shared__ int wsum[8];
-  const int l = blockIdx.y, s = blockIdx.z;
-  const int h = a.h[l], nchunk = a.nchunk[l], cap = a.cap[l];
-  const int* rowcnt = a.rowcnt[l] + (size_t)s * h;
-  block_exscan(rowcnt, h, lut, wsum);
-  if (blockIdx.x == 0) {
-    int* glut = a.rowlut[l] + (size_t)s * (h + 1);
-    for (int i = threadIdx.x; i <= h; i += FE_THREADS) glut[i] = min(lut[i], cap);
-    if (threadIdx.x == 0) {
-      a.ncorners[s * NLEV + l] = min(lut[h], cap);
-      if (lut[h] > cap) *a.overflow = 1;
+  int base = inc - cnt, total = 0;
+  for (int w = 0; w < COMPACT_THREADS / 64; w++) { if (w < wave) base += wsum[w]; total += wsum[w]; }
+  for (int i = lo; i < hi; i++) {
+    unsigned long long m = cm[i];
+    const int y = i / nchunk, c = i - y * nchunk;
+    if (c == 0) lut[y] = min(base, cap);
+    while (m) {
+      const int b = __ffsll((long long)m) - 1;
+      if (base < cap) out[base] = (uint32_t)((c << 6) + b) | ((uint32_t)y << 16);
+      base++;
+      m &= m - 1;
     }
   }
-  const unsigned long long* cm = a.cmask[l] + (size_t)s * h * nchunk;
-  uint32_t* out = a.corners[l] + (size_t)s * cap;
-  const int lane = threadIdx.x & 63;
-  const int gw = blockIdx.x * (FE_THREADS / 64) + (threadIdx.x >> 6), ngw = gridDim.x * (FE_THREADS / 64);
-  for (int y = gw; y < h; y += ngw) {
-    int base = lut[y];
-    if (lut[y + 1] == base) continue;
-    const unsigned long long mine = lane < nchunk ? cm[(size_t)y * nchunk + lane] : 0ull;
-    for (int c = 0; c < nchunk; c++) {
-      const unsigned long long m = __shfl(mine, c);
-      if (!m) continue;
-      if ((m >> lane) & 1ull) {
-        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (pos < cap) out[pos] = (uint32_t)((c << 6) + lane) | ((uint32_t)y << 16);
-      }
-      base += __popcll(m);
-    }
+  if (threadIdx.x == 0) {
+    lut[h] = min(total, cap);
+    a.ncorners[s * NLEV + l] = min(total, cap);
+    if (total > cap) *a.overflow = 1;
   }
 }
 
@@ -348,18 +367,18 @@ int fe_make_keyframe_lite(vslam_system* sys, const uint8_t* gray, size_t row_str
   for (int l = 1; l < NLEV; l++) { sys->fr.img[l] = a.lvl[l]; sys->fr.img_sstride[l] = a.lvl_sstride[l]; sys->fr.img_pitch[l] = a.lvl_pitch[l]; }
 
   const int lp0 = (g[0].w + 15) & ~15, lp1 = (g[1].w + 15) & ~15, lp2 = (g[2].w + 15) & ~15;
-  const size_t lds0 = (size_t)(BAND + 2 * HALO) * lp0 + (BAND / 2) * lp1 + (BAND / 4) * lp2 + BAND * sizeof(int);
+  const size_t lds0 = (size_t)(BAND + 2 * HALO) * lp0 + (BAND / 2) * lp1 + (BAND / 4) * lp2 + 16 + (size_t)BAND * g[0].nchunk * 8 + (size_t)FB_ROWS * lp0 * 2 + 16;
   const int nb0 = (g[0].h + BAND - 1) / BAND;
   prof_mark(sys, 0);
   hipLaunchKernelGGL(k_pyr_fast0, dim3(nb0, sys->S), dim3(FE_THREADS), lds0, sys->stream, a, lp0, lp1, lp2);
   int nb = 0;
   a.band_first[0] = 0;
   for (int l = 1; l < NLEV; l++) { a.band_first[l] = nb; nb += (g[l].h + BAND - 1) / BAND; }
-  const size_t lds1 = (size_t)(BAND + 2 * HALO) * lp1 + BAND * sizeof(int);
+  const size_t lds1 = (size_t)(BAND + 2 * HALO) * lp1 + 16 + (size_t)BAND * g[1].nchunk * 8 + (size_t)FB_ROWS * lp1 * 2 + 16;
   prof_mark(sys, 1);
   hipLaunchKernelGGL(k_fast_lvl, dim3(nb, sys->S), dim3(FE_THREADS), lds1, sys->stream, a);
   prof_mark(sys, 2);
-  hipLaunchKernelGGL(k_compact, dim3(COMPACT_RB, NLEV, sys->S), dim3(FE_THREADS), 0, sys->stream, a);
+  hipLaunchKernelGGL(k_compact, dim3(NLEV, sys->S), dim3(COMPACT_THREADS), 0, sys->stream, a);
   HIPCHK(hipGetLastError());
   sys->have_frame = true;
   return VSLAM_OK;
