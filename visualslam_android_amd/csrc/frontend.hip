@@ -352,6 +352,13 @@ int fe_make_keyframe_lite(vslam_system* sys, const uint8_t* gray, size_t row_str
                           int on_device) {
   const LevelGeom* g = sys->geom;
   if (!gray || (int)row_stride < g[0].w) { vslam_set_error("make_keyframe_lite: bad image arguments"); return VSLAM_E_INVALID; }
+  // next front-end buffer; it may be rebuilt once the tracking that last read it (two frames ago) has finished
+  const int b = sys->fr_idx ^ 1;
+  sys->fr_idx = b;
+  sys->fr = sys->frbuf[b];
+  for (int l = 0; l < NLEV; l++) sys->d_lvl[l] = sys->d_lvl_buf[b][l];
+  hipStream_t fs = sys->fe_stream;
+  HIPCHK(hipStreamWaitEvent(fs, sys->ev_track_done[b], 0));
   FeArgs a;
   fill_fe_args(sys, a);
   if (on_device) {
@@ -360,26 +367,30 @@ int fe_make_keyframe_lite(vslam_system* sys, const uint8_t* gray, size_t row_str
     // host input: copy into the owned level-0 image (TrackFrame copies its input too, jni/KeyFrame.cc:12)
     for (int s = 0; s < sys->S; s++)
       HIPCHK(hipMemcpy2DAsync(sys->d_lvl[0] + (size_t)s * a.lvl_sstride[0], g[0].pitch, gray + (size_t)s * stream_stride,
-                              row_stride, g[0].w, g[0].h, hipMemcpyHostToDevice, sys->stream));
+                              row_stride, g[0].w, g[0].h, hipMemcpyHostToDevice, fs));
     a.in = sys->d_lvl[0]; a.in_sstride = a.lvl_sstride[0]; a.in_pitch = g[0].pitch;
   }
   sys->fr.img[0] = a.in; sys->fr.img_sstride[0] = a.in_sstride; sys->fr.img_pitch[0] = a.in_pitch;
   for (int l = 1; l < NLEV; l++) { sys->fr.img[l] = a.lvl[l]; sys->fr.img_sstride[l] = a.lvl_sstride[l]; sys->fr.img_pitch[l] = a.lvl_pitch[l]; }
+  sys->frbuf[b] = sys->fr;
 
   const int lp0 = (g[0].w + 15) & ~15, lp1 = (g[1].w + 15) & ~15, lp2 = (g[2].w + 15) & ~15;
   const size_t lds0 = (size_t)(BAND + 2 * HALO) * lp0 + (BAND / 2) * lp1 + (BAND / 4) * lp2 + 16 + (size_t)BAND * g[0].nchunk * 8 + (size_t)FB_ROWS * lp0 * 2 + 16;
   const int nb0 = (g[0].h + BAND - 1) / BAND;
   prof_mark(sys, 0);
-  hipLaunchKernelGGL(k_pyr_fast0, dim3(nb0, sys->S), dim3(FE_THREADS), lds0, sys->stream, a, lp0, lp1, lp2);
+  hipLaunchKernelGGL(k_pyr_fast0, dim3(nb0, sys->S), dim3(FE_THREADS), lds0, fs, a, lp0, lp1, lp2);
   int nb = 0;
   a.band_first[0] = 0;
   for (int l = 1; l < NLEV; l++) { a.band_first[l] = nb; nb += (g[l].h + BAND - 1) / BAND; }
   const size_t lds1 = (size_t)(BAND + 2 * HALO) * lp1 + 16 + (size_t)BAND * g[1].nchunk * 8 + (size_t)FB_ROWS * lp1 * 2 + 16;
   prof_mark(sys, 1);
-  hipLaunchKernelGGL(k_fast_lvl, dim3(nb, sys->S), dim3(FE_THREADS), lds1, sys->stream, a);
+  hipLaunchKernelGGL(k_fast_lvl, dim3(nb, sys->S), dim3(FE_THREADS), lds1, fs, a);
   prof_mark(sys, 2);
-  hipLaunchKernelGGL(k_compact, dim3(NLEV, sys->S), dim3(COMPACT_THREADS), 0, sys->stream, a);
+  hipLaunchKernelGGL(k_compact, dim3(NLEV, sys->S), dim3(COMPACT_THREADS), 0, fs, a);
+  prof_mark(sys, PROF_FE_END);
   HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(sys->ev_fe_done[b], fs));
+  HIPCHK(hipStreamWaitEvent(sys->stream, sys->ev_fe_done[b], 0));   // everything on the main stream sees the new frame
   sys->have_frame = true;
   return VSLAM_OK;
 }

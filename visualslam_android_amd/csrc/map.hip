@@ -210,6 +210,7 @@ extern "C" int vslam_track_frame(vslam_system* sys, const uint8_t* gray, size_t 
   r = ba_add_keyframe_and_adjust(sys);                                               // :128-132 -> MapMaker::AddKeyFrame
   prof_mark(sys, VSLAM_N_STAGES);
   if (sys->prof_on && sys->prof_frame < sys->prof_cap) sys->prof_frame++;
+  if (!r) HIPCHK(hipEventRecord(sys->ev_track_done[sys->fr_idx], sys->stream));   // the front-end may now reuse this buffer
   return r;
 }
 
@@ -227,13 +228,15 @@ extern "C" int vslam_profile_begin(vslam_system* sys, int max_frames) {
 
 extern "C" int vslam_profile_end(vslam_system* sys, double* stage_ms, int* n_frames) {
   if (!sys || !stage_ms) return VSLAM_E_INVALID;
+  HIPCHK(hipStreamSynchronize(sys->fe_stream));
   HIPCHK(hipStreamSynchronize(sys->stream));
   sys->prof_on = false;
   for (int k = 0; k < VSLAM_N_STAGES; k++) stage_ms[k] = 0.0;
   for (int f = 0; f < sys->prof_frame; f++)
     for (int k = 0; k < VSLAM_N_STAGES; k++) {
       float ms = 0.f;
-      HIPCHK(hipEventElapsedTime(&ms, sys->prof_ev[(size_t)f * PROF_MARKS + k], sys->prof_ev[(size_t)f * PROF_MARKS + k + 1]));
+      const int end = k == 2 ? PROF_FE_END : k + 1;   // stages 0..2 run on the front-end stream
+      HIPCHK(hipEventElapsedTime(&ms, sys->prof_ev[(size_t)f * PROF_MARKS + k], sys->prof_ev[(size_t)f * PROF_MARKS + end]));
       stage_ms[k] += ms;
     }
   if (n_frames) *n_frames = sys->prof_frame;

@@ -81,6 +81,11 @@ extern "C" int vslam_create(const vslam_params* p, vslam_system** out) {
     vslam_set_error("create: hipStreamCreate failed"); delete sys; return VSLAM_E_HIP;
   }
   const int S = sys->S;
+  if (hipStreamCreateWithFlags(&sys->fe_stream, hipStreamNonBlocking) != hipSuccess) { vslam_set_error("create: hipStreamCreate failed"); vslam_destroy(sys); return VSLAM_E_HIP; }
+  for (int b = 0; b < 2; b++) {
+    if (hipEventCreateWithFlags(&sys->ev_fe_done[b], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sys->ev_track_done[b], hipEventDisableTiming) != hipSuccess) { vslam_set_error("create: hipEventCreate failed"); vslam_destroy(sys); return VSLAM_E_HIP; }
+  }
   for (int l = 0; l < NLEV; l++) {
     LevelGeom& g = sys->geom[l];
     g.w = p->width >> l; g.h = p->height >> l;
@@ -88,20 +93,29 @@ extern "C" int vslam_create(const vslam_params* p, vslam_system** out) {
     g.nchunk = (g.w + 63) >> 6;
     g.cap = p->max_corners[l];
     g.thr = p->fast_threshold[l];
-    ALLOC(sys->d_lvl[l], (size_t)S * g.pitch * g.h);
-    ALLOC(sys->fr.cmask[l], (size_t)S * g.h * g.nchunk);
-    ALLOC(sys->fr.rowcnt[l], (size_t)S * g.h);
-    ALLOC(sys->fr.rowlut[l], (size_t)S * (g.h + 1));
-    ALLOC(sys->fr.corners[l], (size_t)S * g.cap);
-    ALLOC(sys->fr.scores[l], (size_t)S * g.cap);
-    ALLOC(sys->fr.maxcorners[l], (size_t)S * g.cap);
-    sys->fr.img[l] = sys->d_lvl[l];
-    sys->fr.img_sstride[l] = (size_t)g.pitch * g.h;
-    sys->fr.img_pitch[l] = g.pitch;
   }
-  ALLOC(sys->fr.ncorners, (size_t)S * NLEV);
-  ALLOC(sys->fr.nmax, (size_t)S * NLEV);
-  ALLOC(sys->fr.overflow, 1);
+  for (int b = 0; b < 2; b++) {
+    FrameDev& fr = sys->frbuf[b];
+    for (int l = 0; l < NLEV; l++) {
+      const LevelGeom& g = sys->geom[l];
+      ALLOC(sys->d_lvl_buf[b][l], (size_t)S * g.pitch * g.h);
+      ALLOC(fr.cmask[l], (size_t)S * g.h * g.nchunk);
+      ALLOC(fr.rowcnt[l], (size_t)S * g.h);
+      ALLOC(fr.rowlut[l], (size_t)S * (g.h + 1));
+      ALLOC(fr.corners[l], (size_t)S * g.cap);
+      ALLOC(fr.scores[l], (size_t)S * g.cap);
+      ALLOC(fr.maxcorners[l], (size_t)S * g.cap);
+      fr.img[l] = sys->d_lvl_buf[b][l];
+      fr.img_sstride[l] = (size_t)g.pitch * g.h;
+      fr.img_pitch[l] = g.pitch;
+    }
+    ALLOC(fr.ncorners, (size_t)S * NLEV);
+    ALLOC(fr.nmax, (size_t)S * NLEV);
+    ALLOC(fr.overflow, 1);
+  }
+  sys->fr_idx = 0;
+  sys->fr = sys->frbuf[0];
+  for (int l = 0; l < NLEV; l++) sys->d_lvl[l] = sys->d_lvl_buf[0][l];
   sys->ba_ws = nullptr;
   {
     int r = trk_alloc(sys);
@@ -117,8 +131,12 @@ extern "C" int vslam_create(const vslam_params* p, vslam_system** out) {
 
 extern "C" int vslam_destroy(vslam_system* sys) {
   if (!sys) return VSLAM_OK;
+  if (sys->fe_stream) (void)hipStreamSynchronize(sys->fe_stream);
   if (sys->stream) (void)hipStreamSynchronize(sys->stream);
   for (void* p : sys->allocs) (void)hipFree(p);
+  for (hipEvent_t e : sys->prof_ev) (void)hipEventDestroy(e);
+  for (int b = 0; b < 2; b++) { if (sys->ev_fe_done[b]) (void)hipEventDestroy(sys->ev_fe_done[b]); if (sys->ev_track_done[b]) (void)hipEventDestroy(sys->ev_track_done[b]); }
+  if (sys->fe_stream) (void)hipStreamDestroy(sys->fe_stream);
   if (sys->stream) (void)hipStreamDestroy(sys->stream);
   delete sys;
   return VSLAM_OK;

@@ -126,8 +126,15 @@ struct vslam_system {
   int S;
   hipStream_t stream;
   LevelGeom geom[NLEV];
-  FrameDev fr;                 // device pointers (host copy of the view)
-  uint8_t* d_lvl[NLEV];        // owned level images (level 0 = staging copy for host input)
+  FrameDev fr;                 // view of the CURRENT frame's front-end products (= frbuf[fr_idx])
+  uint8_t* d_lvl[NLEV];        // owned level images of the current buffer (level 0 = staging copy for host input)
+  // Front-end products are double-buffered and built on their own HIP stream so MakeKeyFrame_Lite of frame t+1
+  // overlaps TrackMap / pose / bundle adjustment of frame t (which are latency-bound and leave the CUs mostly idle).
+  FrameDev frbuf[2];
+  uint8_t* d_lvl_buf[2][NLEV];
+  int fr_idx = 0;
+  hipStream_t fe_stream = nullptr;
+  hipEvent_t ev_fe_done[2] = {nullptr, nullptr}, ev_track_done[2] = {nullptr, nullptr};
   std::vector<void*> allocs;   // everything to hipFree
   bool have_frame;
   TrackParams tp;
@@ -139,9 +146,11 @@ struct vslam_system {
   bool prof_on = false;
 };
 
-#define PROF_MARKS (VSLAM_N_STAGES + 1)
+#define PROF_MARKS (VSLAM_N_STAGES + 2)   // marks 0..2 + PROF_FE_END on the front-end stream, 3..VSLAM_N_STAGES on the main stream
+#define PROF_FE_END (VSLAM_N_STAGES + 1)
 static inline void prof_mark(vslam_system* sys, int k) {
-  if (sys->prof_on && sys->prof_frame < sys->prof_cap) (void)hipEventRecord(sys->prof_ev[(size_t)sys->prof_frame * PROF_MARKS + k], sys->stream);
+  if (sys->prof_on && sys->prof_frame < sys->prof_cap)
+    (void)hipEventRecord(sys->prof_ev[(size_t)sys->prof_frame * PROF_MARKS + k], (k < 3 || k == PROF_FE_END) ? sys->fe_stream : sys->stream);
 }
 
 // frontend.hip
