@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--patch", type=int, default=8, help="PatchFinder template side (BASELINE configs: 8; reference default 11)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
+    ap.add_argument("--ba-delay", type=int, default=int(os.environ.get("VSLAM_BENCH_BA_DELAY", 0)),
+                    help="vslam_params.ba_delay_frames: 0 = synchronous map-maker; D > 0 = Bundle::Compute on its own HIP stream, applied D frames later")
     ap.add_argument("--no-events", action="store_true", help="skip the per-stage HIP events in the timed region")
     args = ap.parse_args()
     rank, world, local_rank = dist_env()
@@ -111,7 +113,7 @@ def main():
     NS = max(1, min(args.systems, S))
     assert S % NS == 0, "--streams must be a multiple of --systems"
     Sk = S // NS
-    vpk = capi.default_params(W, H, Sk, patch_size=args.patch, device=local_rank)
+    vpk = capi.default_params(W, H, Sk, patch_size=args.patch, device=local_rank, ba_delay_frames=args.ba_delay)
     systems = [capi.System(vpk) for _ in range(NS)]
 
     def sys_of(s):
@@ -227,7 +229,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: %dx%d 4-level FAST-10 + %dx%d PatchFinder ZMSSD search, TrackMap pose update, "
                                    "AddKeyFrame + BundleAdjustRecent on keyframe frames" % (W, H, args.patch, args.patch),
-                       "streams_per_gpu": S, "systems_per_gpu": NS, "patch_size": args.patch, "corners_l0_per_frame": ncorn,
+                       "streams_per_gpu": S, "systems_per_gpu": NS, "ba_delay_frames": args.ba_delay, "patch_size": args.patch, "corners_l0_per_frame": ncorn,
                        "patches_attempted_per_frame": round(att, 1), "patches_found_per_frame": round(fnd, 1),
                        "zmssd_evals_per_frame": round(zm, 1), "keyframes_added_per_stream": kf_adds,
                        "ba_trials_per_stream": ba_trials, "streams_tracking_good": good, "setup_seconds": round(setup_s, 1)},

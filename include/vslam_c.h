@@ -72,6 +72,10 @@ typedef struct vslam_params {
   double cam[5];                   /* jni/ATANCamera.cc:20-24 normalised fx fy cx cy w */
   int quirks;                      /* VSLAM_Q_* bit set */
   int device;                      /* HIP device ordinal */
+  int ba_delay_frames;             /* 0: a keyframe's bundle adjustment is finished before the next frame (synchronous
+                                      map-maker); D > 0: it runs on its own HIP stream beside the next frames and its results
+                                      are applied at the start of the D-th following frame (the reference's map-maker is a
+                                      second thread whose results also arrive "a few frames later", jni/MapMaker.cc:80-123) */
 } vslam_params;
 
 const char* vslam_last_error(void);

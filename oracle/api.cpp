@@ -21,6 +21,7 @@ void* orc_sys_create(const orc_params* q) {
   p.ba_min_tukey_sigma = q->ba_min_tukey_sigma; p.ba_window = q->ba_window; p.ba_min_keyframes = q->ba_min_keyframes;
   for (int i = 0; i < 5; i++) p.cam[i] = q->cam[i];
   p.quirks = q->quirks;
+  p.ba_delay_frames = q->ba_delay_frames;
   return new System(p);
 }
 void orc_sys_destroy(void* s) { delete (System*)s; }

@@ -122,7 +122,8 @@ class OrcParams(C.Structure):
                 ("coarse_min_vel", C.c_double), ("fine_subpix_its", C.c_int), ("wls_prior", C.c_double),
                 ("min_frames_between_kf", C.c_int), ("max_kf_dist_wiggle_mult", C.c_double), ("wiggle_scale", C.c_double),
                 ("ba_max_iterations", C.c_int), ("ba_convergence_limit", C.c_double), ("ba_min_tukey_sigma", C.c_double),
-                ("ba_window", C.c_int), ("ba_min_keyframes", C.c_int), ("cam", C.c_double * 5), ("quirks", C.c_int)]
+                ("ba_window", C.c_int), ("ba_min_keyframes", C.c_int), ("cam", C.c_double * 5), ("quirks", C.c_int),
+                ("ba_delay_frames", C.c_int)]
 
 
 class TrackState(C.Structure):
@@ -143,7 +144,8 @@ def params_from_vslam(vp):
     p.max_patches = vp.max_patches_per_frame
     for f in ("coarse_min", "coarse_max", "coarse_range", "coarse_subpix_its", "coarse_disabled", "coarse_min_vel",
               "fine_subpix_its", "wls_prior", "min_frames_between_kf", "max_kf_dist_wiggle_mult", "wiggle_scale",
-              "ba_max_iterations", "ba_convergence_limit", "ba_min_tukey_sigma", "ba_window", "ba_min_keyframes", "quirks"):
+              "ba_max_iterations", "ba_convergence_limit", "ba_min_tukey_sigma", "ba_window", "ba_min_keyframes", "quirks",
+              "ba_delay_frames"):
         setattr(p, f, getattr(vp, f))
     for i in range(5):
         p.cam[i] = vp.cam[i]

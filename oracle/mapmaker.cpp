@@ -34,8 +34,10 @@ void System::AddKeyFrame() {
   // ReFindInSingleKeyFrame / AddSomeMapPoints: "next" rows
   ba_converged_full = false; ba_converged_recent = false;                                                   // :504-505
   // MapMaker::run :98-99: local bundle adjustment takes priority once the queue is empty
-  last_ba_accepted = BundleAdjustRecent();
-  HandleBadPoints();                                                                                          // run() :117
+  defer_ba = true;
+  const int r = BundleAdjustRecent();
+  defer_ba = false;
+  if (!pending) { last_ba_accepted = r; HandleBadPoints(); }                                                  // run() :117
 }
 
 void System::HandleBadPoints() {
@@ -77,15 +79,17 @@ int System::BundleAdjustRecent() {
 }
 
 int System::BundleAdjust(const std::vector<int>& adj, const std::vector<int>& fixed, const std::vector<int>& points, bool recent) {
-  // :854-960
-  Bundle b;
+  // :854-960.  The Bundle is assembled from the map and computed now; its results are written back by ApplyBundle --
+  // immediately, or (defer_ba, tracker-driven keyframes with ba_delay_frames = D > 0) at the start of the D-th following
+  // frame, which models the reference's map-maker thread finishing a little later than the tracker (jni/MapMaker.cc:80-123).
+  PendingBA* pb = new PendingBA;
+  Bundle& b = pb->b;
   b.camera = camera;
   b.max_iterations = p.ba_max_iterations; b.convergence_limit = p.ba_convergence_limit; b.min_sigma = p.ba_min_tukey_sigma;
   std::map<int, int> view_id, point_id;
-  std::vector<int> id_view, id_point;
-  for (int k : adj) { view_id[k] = b.AddCamera(kfs[k]->pose, kfs[k]->fixed); id_view.push_back(k); }
-  for (int k : fixed) { view_id[k] = b.AddCamera(kfs[k]->pose, true); id_view.push_back(k); }
-  for (int q : points) { point_id[q] = b.AddPoint(pts[q]->pos); id_point.push_back(q); }
+  for (int k : adj) { view_id[k] = b.AddCamera(kfs[k]->pose, kfs[k]->fixed); pb->id_view.push_back(k); }
+  for (int k : fixed) { view_id[k] = b.AddCamera(kfs[k]->pose, true); pb->id_view.push_back(k); }
+  for (int q : points) { point_id[q] = b.AddPoint(pts[q]->pos); pb->id_point.push_back(q); }
   for (int k = 0; k < (int)kfs.size(); k++) {                                                      // :888-902
     if (!view_id.count(k)) continue;
     for (auto& it : kfs[k]->meas) {
@@ -95,18 +99,31 @@ int System::BundleAdjust(const std::vector<int>& adj, const std::vector<int>& fi
     }
   }
   abort_flag = false;
-  const int nAccepted = b.Compute(&abort_flag);
+  pb->recent = recent;
+  pb->accepted = b.Compute(&abort_flag);
+  const int acc = pb->accepted;
+  if (defer_ba && p.ba_delay_frames > 0) { pb->countdown = p.ba_delay_frames; delete pending; pending = pb; return acc; }
+  ApplyBundle(*pb);
+  delete pb;
+  return acc;
+}
+
+void System::ApplyBundle(PendingBA& pb) {
+  Bundle& b = pb.b;
+  const int nAccepted = pb.accepted;
+  const bool recent = pb.recent;
   n_ba_trials += b.n_trials;
-  if (nAccepted < 0) return nAccepted;   // reference: mbResetRequested (:913); here surfaced to the caller
+  last_ba_accepted = nAccepted;
+  if (nAccepted < 0) return;             // reference: mbResetRequested (:913); here surfaced to the caller
   if (nAccepted > 0) {                   // :918-929
-    for (auto& it : point_id) pts[it.first]->pos = b.pts[it.second].pos;
-    for (auto& it : view_id) kfs[it.first]->pose = b.cams[it.second].pose;
+    for (size_t i = 0; i < pb.id_point.size(); i++) pts[pb.id_point[i]]->pos = b.pts[i].pos;
+    for (size_t i = 0; i < pb.id_view.size(); i++) kfs[pb.id_view[i]]->pose = b.cams[i].pose;
     if (recent) ba_converged_recent = false;
     ba_converged_full = false;
   }
   if (b.converged) { ba_converged_recent = true; if (!recent) ba_converged_full = true; }   // :931-935
   for (auto& pc : b.outlier_meas) {                                                                 // :941-959
-    const int pp = id_point[pc.first], pk = id_view[pc.second];
+    const int pp = pb.id_point[pc.first], pk = pb.id_view[pc.second];
     Measurement& m = kfs[pk]->meas[pp];
     if ((int)pts[pp]->meas_kfs.size() <= 2 || m.source == SRC_ROOT) pts[pp]->bad = true;
     else {
@@ -116,7 +133,6 @@ int System::BundleAdjust(const std::vector<int>& adj, const std::vector<int>& fi
       pts[pp]->meas_kfs.erase(pk);
     }
   }
-  return nAccepted;
 }
 
 }  // namespace orc

@@ -83,6 +83,7 @@ typedef struct orc_params {           /* mirrors the hot-path fields of vslam_pa
   int min_frames_between_kf; double max_kf_dist_wiggle_mult, wiggle_scale;
   int ba_max_iterations; double ba_convergence_limit, ba_min_tukey_sigma; int ba_window, ba_min_keyframes;
   double cam[5]; int quirks;
+  int ba_delay_frames;
 } orc_params;
 
 typedef struct orc_track_state {      /* same fields as vslam_track_state */

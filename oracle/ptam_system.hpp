@@ -71,6 +71,7 @@ struct Params {
   int min_frames_between_kf; double max_kf_dist_wiggle_mult, wiggle_scale;
   int ba_max_iterations; double ba_convergence_limit, ba_min_tukey_sigma; int ba_window, ba_min_keyframes;
   double cam[5]; int quirks;
+  int ba_delay_frames = 0;   // 0: results applied at once; D > 0: applied at the start of the D-th following frame
 };
 
 // ---- Bundle (jni/Bundle.{h,cc}) --------------------------------------------------------------------------------
@@ -136,6 +137,11 @@ struct System {
   double KeyFrameLinearDist(const SE3& a, const SE3& b);
   int BundleAdjustRecent(); int BundleAdjustAll(); void HandleBadPoints();
   int BundleAdjust(const std::vector<int>& adj, const std::vector<int>& fixed, const std::vector<int>& points, bool recent);
+  // a finished Bundle whose results are still to be written to the map (asynchronous map-maker model, see mapmaker.cpp)
+  struct PendingBA { Bundle b; std::vector<int> id_view, id_point; bool recent = true; int accepted = 0; int countdown = -1; };
+  PendingBA* pending = nullptr;
+  void ApplyBundle(PendingBA& pb);
+  bool defer_ba = false;
   bool abort_flag = false;
 };
 

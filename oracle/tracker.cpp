@@ -39,7 +39,7 @@ System::System(const Params& pp) : p(pp) {
   for (int i = 0; i < 4; i++) attempted[i] = found[i] = 0;
   cur.depth_mean = 1.0; cur.depth_sigma = 1.0;   // jni/Tracker.cc:53-54
 }
-System::~System() { for (auto k : kfs) delete k; for (auto q : pts) delete q; }
+System::~System() { for (auto k : kfs) delete k; for (auto q : pts) delete q; delete pending; }
 
 int System::AddKeyFrameRaw(const double pose12[12], bool fixed, const uint8_t* gray, int stride, double dmean, double dsigma) {
   KeyFrame* k = new KeyFrame;
@@ -127,6 +127,7 @@ static void td_linear_update(MapPoint& td, const double v6[6]) {
 void System::TrackFrame(const uint8_t* gray, int stride) {
   // jni/Tracker.cc:76-146
   kf_added_this_frame = false;
+  if (pending && --pending->countdown == 0) { ApplyBundle(*pending); delete pending; pending = nullptr; HandleBadPoints(); }   // deferred map-maker results
   cur.meas.clear();
   make_keyframe_lite(cur, gray, p.width, p.height, stride, p.thr);
   frame++;

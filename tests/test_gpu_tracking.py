@@ -22,8 +22,9 @@ class Drift:
         self.seen = False
 
 
-def compare_frame(o, g, s, tag, drift=None):
+def compare_frame(o, g, s, tag, drift=None, tight=None):
     drift = drift or Drift()
+    tight = tight or TIGHT
     so, sg = o.state(), g.state(s)
     to, tg = o.point_tracks(), g.point_tracks(s)
     f = (to["found"] == 1) & (tg["found"] == 1) & (tg["level"] >= 0)      # bFound is stale for points outside this frame's PVS
@@ -40,14 +41,14 @@ def compare_frame(o, g, s, tag, drift=None):
         assert d < 1e-5 and np.abs(np.array(so.found[:]) - np.array(sg.found[:])).max() <= 3, (tag, d)
         assert f.sum() == 0 or np.abs(to["vfound"][f] - tg["vfound"][f]).max() < 0.1, tag
         return
-    assert d < TIGHT, (tag, d)
+    assert d < tight, (tag, d)
     assert list(so.found) == list(sg.found), tag
     assert so.n_zmssd == sg.n_zmssd and so.ba_accepted == sg.ba_accepted and so.n_ba_trials == sg.n_ba_trials, tag
     assert np.array_equal(to["searched"], tg["searched"]), tag
     assert np.array_equal(to["level"][f], tg["level"][f]) and np.array_equal(to["subpix"][f], tg["subpix"][f]), tag
     coarse = f & (to["subpix"] == 0)
     assert np.array_equal(to["vfound"][coarse], tg["vfound"][coarse]), tag              # FAST-corner positions: exact
-    assert np.abs(np.array(so.velocity[:]) - np.array(sg.velocity[:])).max() < TIGHT
+    assert np.abs(np.array(so.velocity[:]) - np.array(sg.velocity[:])).max() < tight
 
 
 @pytest.mark.parametrize("w,h,patch,n_frames", [(640, 480, 11, 24), (640, 480, 8, 6), (320, 240, 11, 6)])
@@ -87,6 +88,32 @@ def test_track_frame_sequence_matches_oracle(w, h, patch, n_frames):
         nflip += int(dt.sum())
     assert nflip <= 2
     assert "Tracking Map, quality good." in g.message(0)
+    g.close()
+
+
+def test_asynchronous_mapmaker_delay():
+    # ba_delay_frames = D: Bundle::Compute runs on its own HIP stream beside the next frames; results land at frame t + D
+    w, h, D = 320, 240, 3
+    f, m, frames = make_scene(w, h, seed=1234, n_frames=26, per_level=(120, 50, 20, 8))
+    vp = capi.default_params(w, h, 1, ba_delay_frames=D)
+    o = make_oracle(vp, m, f.pose(-1))
+    g = capi.System(vp)
+    g.load_map(0, m)
+    g.set_pose(0, f.pose(-1))
+    drift = Drift()
+    seen_pending = False
+    for i in range(26):
+        o.track_frame(frames[i])
+        g.track_frame(frames[i][None])
+        # a local BA run for 12+ undamped LM steps amplifies reduction-order round-off (see test_gpu_bundle.py): 1e-5 after it lands
+        compare_frame(o, g, 0, "frame %d" % i, drift, tight=1e-5 if i >= 21 + D else TIGHT)
+        if i in (0, 1, 21, 22):
+            assert g.state(0).ba_accepted == o.state().ba_accepted       # still the previous value while the BA is in flight
+            seen_pending = True
+    assert seen_pending and g.state(0).n_keyframes == len(m["keyframes"]) + 2
+    assert g.state(0).n_ba_trials == o.state().n_ba_trials > 0
+    for k in range(g.state(0).n_keyframes):
+        assert pose_err(o.keyframe_pose(k), g.keyframe_pose(0, k)) < 1e-5
     g.close()
 
 

@@ -30,7 +30,7 @@ class Params(C.Structure):
         ("use_sbi", C.c_int), ("min_frames_between_kf", C.c_int), ("max_kf_dist_wiggle_mult", C.c_double),
         ("wiggle_scale", C.c_double), ("ba_max_iterations", C.c_int), ("ba_convergence_limit", C.c_double),
         ("ba_min_tukey_sigma", C.c_double), ("ba_window", C.c_int), ("ba_min_keyframes", C.c_int),
-        ("cam", C.c_double * 5), ("quirks", C.c_int), ("device", C.c_int),
+        ("cam", C.c_double * 5), ("quirks", C.c_int), ("device", C.c_int), ("ba_delay_frames", C.c_int),
     ]
 
 

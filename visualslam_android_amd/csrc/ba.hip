@@ -37,8 +37,9 @@ __host__ __device__ inline BaView ba_view(const BaPool& b, int n) {
 
 __global__ __launch_bounds__(BA_THREADS) void k_ba_compute(BaPool pool, BaConfig cfg) {
   const BaView v = ba_view(pool, blockIdx.x);
-  if (!v.res->active) return;
+  if (!v.res->active || v.res->computed) return;
   ba_compute(v, cfg);
+  if (threadIdx.x == 0) v.res->computed = 1;
 }
 
 template <class T>
@@ -295,13 +296,14 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_assemble(MapDev m, TrackParam
   const MeasDev* kfm = m.kf_meas + (size_t)s * K * P;
   if (threadIdx.x == 0) {
     sh_go = 0;
-    R->active = 0;
+    const bool in_flight = st->ba_countdown > 0;     // asynchronous map-maker: the pool still belongs to the last keyframe
+    if (!in_flight) R->active = 0;
     if (mode == 0 && st->kf_pending) {
       st->n_kf++;                                                       // mMap.vpKeyFrames.push_back (:489)
       st->kf_added = 1;
       st->ba_converged_full = 0; st->ba_converged_recent = 0;           // :504-505
     }
-    const bool want = st->map_good && (mode != 0 || st->kf_pending);
+    const bool want = st->map_good && (mode != 0 || st->kf_pending) && !in_flight;
     const int nk = st->n_kf;
     for (int k = 0; k < 64; k++) view_of_kf[k] = -1;
     if (want && mode != 2) {
@@ -428,7 +430,10 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_assemble(MapDev m, TrackParam
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) { R->n_cams = ncam; R->n_pts = np; R->n_meas = nm; R->active = (ncam > 0 && np > 0 && nm > 0); R->accepted = 0; R->n_outlier_meas = 0; }
+  if (threadIdx.x == 0) {
+    R->n_cams = ncam; R->n_pts = np; R->n_meas = nm; R->active = (ncam > 0 && np > 0 && nm > 0); R->accepted = 0; R->n_outlier_meas = 0; R->computed = 0;
+    if (mode == 0 && tp.ba_delay > 0) st->ba_countdown = tp.ba_delay;   // results are applied ba_delay frames from now
+  }
 }
 
 // BundleAdjust tail (:904-959) + HandleBadPoints (:140-164)
@@ -440,7 +445,18 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_writeback(MapDev m, TrackPara
   const int P = tp.max_points, K = tp.max_keyframes;
   MapPointDev* pts = m.pts + (size_t)s * P;
   MeasDev* kfm = m.kf_meas + (size_t)s * K * P;
-  if (R->active) {
+  __shared__ int sh_due;
+  if (mode >= 3) {                         // asynchronous map-maker: is this stream's pending result due?
+    if (threadIdx.x == 0) {
+      int due = 0;
+      if (st->ba_countdown > 0) { if (mode == 4) st->ba_countdown = 1; if (--st->ba_countdown == 0) { due = 1; st->ba_countdown = -1; } }
+      sh_due = due;
+    }
+    __syncthreads();
+    if (!sh_due) return;
+  }
+  const bool deferred = mode == 0 && tp.ba_delay > 0;   // the results of this keyframe's BA are written back ba_delay frames later
+  if (R->active && !deferred) {
     const int* idp = pool.id_point + (size_t)s * pool.max_pts;
     const int* idv = pool.id_view + (size_t)s * pool.max_cams;
     const int acc = R->accepted;
@@ -467,6 +483,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_writeback(MapDev m, TrackPara
     __syncthreads();
   }
   if (!(st->map_good && (mode != 0 || st->kf_pending))) return;
+  if (mode == 0 && tp.ba_delay > 0 && st->ba_countdown > 0) return;   // deferred: HandleBadPoints runs with the delayed write-back
   // HandleBadPoints :140-164
   const int nk = st->n_kf;
   for (int i = threadIdx.x; i < st->n_points; i += BA_THREADS) {
@@ -497,10 +514,36 @@ static void fill_kfcopy(vslam_system* sys, KfCopyArgs& a) {
   }
 }
 
+// Asynchronous map-maker (ba_delay_frames = D > 0): make the main stream wait for the bundle adjustment launched D frames
+// ago and apply whatever is due (k_ba_writeback decides per stream with its countdown).
+int ba_frame_start(vslam_system* sys) {
+  const int D = sys->tp.ba_delay;
+  if (D <= 0) return VSLAM_OK;
+  BaSystemWs* ws = (BaSystemWs*)sys->ba_ws;
+  const int R = (int)sys->ev_ba.size();
+  prof_mark(sys, 13);
+  if (sys->frame_no >= D) HIPCHK(hipStreamWaitEvent(sys->stream, sys->ev_ba[(sys->frame_no - D) % R], 0));
+  hipLaunchKernelGGL(k_ba_writeback, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, 3);
+  HIPCHK(hipGetLastError());
+  return VSLAM_OK;
+}
+
+// explicit (host-driven) map-maker calls first collect a bundle adjustment that is still in flight
+static int ba_drain(vslam_system* sys) {
+  if (sys->tp.ba_delay <= 0) return VSLAM_OK;
+  BaSystemWs* ws = (BaSystemWs*)sys->ba_ws;
+  HIPCHK(hipStreamSynchronize(sys->ba_stream));
+  hipLaunchKernelGGL(k_ba_writeback, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, 4);
+  HIPCHK(hipGetLastError());
+  return VSLAM_OK;
+}
+
 // mode 0: tracker-driven AddKeyFrame + BundleAdjustRecent; 1: BundleAdjustRecent; 2: BundleAdjustAll
 int ba_run(vslam_system* sys, int mode) {
   BaSystemWs* ws = (BaSystemWs*)sys->ba_ws;
   const BaConfig cfg = make_cfg(sys->tp);
+  const bool async = mode == 0 && sys->tp.ba_delay > 0;
+  if (mode != 0) { int r = ba_drain(sys); if (r) return r; }
   if (mode == 0) {
     KfCopyArgs a; fill_kfcopy(sys, a);
     prof_mark(sys, 10);
@@ -508,6 +551,19 @@ int ba_run(vslam_system* sys, int mode) {
   }
   if (mode == 0) prof_mark(sys, 11);
   hipLaunchKernelGGL(k_ba_assemble, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, mode);
+  if (async) {
+    // Bundle::Compute on the BA stream, beside the next frames; its write-back is launched by ba_frame_start D frames later
+    const int R = (int)sys->ev_ba.size(), slot = (int)(sys->frame_no % R);
+    HIPCHK(hipEventRecord(sys->ev_asm[slot], sys->stream));
+    HIPCHK(hipStreamWaitEvent(sys->ba_stream, sys->ev_asm[slot], 0));
+    prof_mark(sys, 12);
+    hipLaunchKernelGGL(k_ba_compute, dim3(sys->S), dim3(BA_THREADS), 0, sys->ba_stream, ws->pool, cfg);
+    prof_mark(sys, PROF_BA_END);
+    HIPCHK(hipEventRecord(sys->ev_ba[slot], sys->ba_stream));
+    hipLaunchKernelGGL(k_ba_writeback, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, 0);   // HandleBadPoints of streams without a pending BA
+    HIPCHK(hipGetLastError());
+    return VSLAM_OK;
+  }
   if (mode == 0) prof_mark(sys, 12);
   hipLaunchKernelGGL(k_ba_compute, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, ws->pool, cfg);
   if (mode == 0) prof_mark(sys, 13);

@@ -21,6 +21,7 @@
 
 struct BaResult {
   int active;           // 0: nothing to do for this problem
+  int computed;         // set by Bundle::Compute: an assembled problem is solved exactly once (the gated kernel is launched every frame)
   int n_cams, n_pts, n_meas, n_free;
   int accepted;         // Compute() return value (negative on error)
   int converged, hit_max;

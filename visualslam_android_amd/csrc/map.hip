@@ -161,7 +161,7 @@ extern "C" int vslam_map_set_good(vslam_system* sys, int s) {
 
 static void reset_tracker_fields(TrackerState& st) {   // Tracker::Reset, jni/Tracker.cc:45-62 (first call for a stream)
   if (st.frame == 0 && st.last_kf_dropped == 0 && st.depth_mean == 0.0) {
-    st.quality = 2; st.last_kf_dropped = -20; st.depth_mean = 1.0; st.depth_sigma = 1.0; st.ba_accepted = -2;
+    st.quality = 2; st.last_kf_dropped = -20; st.depth_mean = 1.0; st.depth_sigma = 1.0; st.ba_accepted = -2; st.ba_countdown = -1;
     for (int i = 0; i < 9; i++) st.pose_final.R[i] = (i % 4 == 0) ? 1.0 : 0.0;
     st.pose_cur = st.pose_final; st.start_pose = st.pose_final;
   }
@@ -205,12 +205,15 @@ extern "C" int vslam_track_frame(vslam_system* sys, const uint8_t* gray, size_t 
   if (!sys) return VSLAM_E_INVALID;
   int r = fe_make_keyframe_lite(sys, gray, row_stride, stream_stride, on_device);   // jni/Tracker.cc:85
   if (r) return r;
+  r = ba_frame_start(sys);                                                           // deferred map-maker results that are due now
+  if (r) return r;
   r = trk_track_map(sys);                                                            // :103-124
   if (r) return r;
   r = ba_add_keyframe_and_adjust(sys);                                               // :128-132 -> MapMaker::AddKeyFrame
   prof_mark(sys, VSLAM_N_STAGES);
   if (sys->prof_on && sys->prof_frame < sys->prof_cap) sys->prof_frame++;
   if (!r) HIPCHK(hipEventRecord(sys->ev_track_done[sys->fr_idx], sys->stream));   // the front-end may now reuse this buffer
+  sys->frame_no++;
   return r;
 }
 
@@ -230,12 +233,14 @@ extern "C" int vslam_profile_end(vslam_system* sys, double* stage_ms, int* n_fra
   if (!sys || !stage_ms) return VSLAM_E_INVALID;
   HIPCHK(hipStreamSynchronize(sys->fe_stream));
   HIPCHK(hipStreamSynchronize(sys->stream));
+  if (sys->ba_stream) HIPCHK(hipStreamSynchronize(sys->ba_stream));
   sys->prof_on = false;
   for (int k = 0; k < VSLAM_N_STAGES; k++) stage_ms[k] = 0.0;
   for (int f = 0; f < sys->prof_frame; f++)
     for (int k = 0; k < VSLAM_N_STAGES; k++) {
       float ms = 0.f;
-      const int end = k == 2 ? PROF_FE_END : k + 1;   // stages 0..2 run on the front-end stream
+      int end = k == 2 ? PROF_FE_END : k + 1;   // stages 0..2 run on the front-end stream
+      if (sys->tp.ba_delay > 0) { if (k == 11) end = VSLAM_N_STAGES; else if (k == 12) end = PROF_BA_END; else if (k == 13) end = 3; }
       HIPCHK(hipEventElapsedTime(&ms, sys->prof_ev[(size_t)f * PROF_MARKS + k], sys->prof_ev[(size_t)f * PROF_MARKS + end]));
       stage_ms[k] += ms;
     }

@@ -45,6 +45,7 @@ extern "C" int vslam_default_params(vslam_params* p, int width, int height, int 
   p->cam[0] = 0.841906; p->cam[1] = 1.10893; p->cam[2] = 0.505171; p->cam[3] = 0.470265; p->cam[4] = -0.0133843;
   p->quirks = 0;
   p->device = 0;
+  p->ba_delay_frames = 0;
   return VSLAM_OK;
 }
 
@@ -62,7 +63,8 @@ static int dev_alloc(vslam_system* sys, T** out, size_t count) {
 extern "C" int vslam_create(const vslam_params* p, vslam_system** out) {
   if (!p || !out) { vslam_set_error("create: null argument"); return VSLAM_E_INVALID; }
   if (p->width < 48 || p->height < 48 || p->width > 4096 || p->height > 4096 || p->n_streams < 1 ||
-      (p->patch_size != 8 && p->patch_size != 11)) {
+      (p->patch_size != 8 && p->patch_size != 11) || p->ba_delay_frames < 0 || p->ba_delay_frames >= 20 ||
+      (p->ba_delay_frames > 0 && p->ba_delay_frames >= p->min_frames_between_kf)) {
     vslam_set_error("create: unsupported size %dx%d streams %d patch %d", p->width, p->height, p->n_streams, p->patch_size);
     return VSLAM_E_INVALID;
   }
@@ -113,6 +115,14 @@ extern "C" int vslam_create(const vslam_params* p, vslam_system** out) {
     ALLOC(fr.nmax, (size_t)S * NLEV);
     ALLOC(fr.overflow, 1);
   }
+  if (p->ba_delay_frames > 0) {
+    if (hipStreamCreateWithFlags(&sys->ba_stream, hipStreamNonBlocking) != hipSuccess) { vslam_set_error("create: hipStreamCreate failed"); vslam_destroy(sys); return VSLAM_E_HIP; }
+    for (int i = 0; i < p->ba_delay_frames + 2; i++) {
+      hipEvent_t a = nullptr, b = nullptr;
+      if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) { vslam_set_error("create: hipEventCreate failed"); vslam_destroy(sys); return VSLAM_E_HIP; }
+      sys->ev_asm.push_back(a); sys->ev_ba.push_back(b);
+    }
+  }
   sys->fr_idx = 0;
   sys->fr = sys->frbuf[0];
   for (int l = 0; l < NLEV; l++) sys->d_lvl[l] = sys->d_lvl_buf[0][l];
@@ -132,7 +142,11 @@ extern "C" int vslam_create(const vslam_params* p, vslam_system** out) {
 extern "C" int vslam_destroy(vslam_system* sys) {
   if (!sys) return VSLAM_OK;
   if (sys->fe_stream) (void)hipStreamSynchronize(sys->fe_stream);
+  if (sys->ba_stream) (void)hipStreamSynchronize(sys->ba_stream);
   if (sys->stream) (void)hipStreamSynchronize(sys->stream);
+  for (hipEvent_t e : sys->ev_asm) (void)hipEventDestroy(e);
+  for (hipEvent_t e : sys->ev_ba) (void)hipEventDestroy(e);
+  if (sys->ba_stream) (void)hipStreamDestroy(sys->ba_stream);
   for (void* p : sys->allocs) (void)hipFree(p);
   for (hipEvent_t e : sys->prof_ev) (void)hipEventDestroy(e);
   for (int b = 0; b < 2; b++) { if (sys->ev_fe_done[b]) (void)hipEventDestroy(sys->ev_fe_done[b]); if (sys->ev_track_done[b]) (void)hipEventDestroy(sys->ev_track_done[b]); }
@@ -145,6 +159,7 @@ extern "C" int vslam_destroy(vslam_system* sys) {
 extern "C" int vslam_synchronize(vslam_system* sys) {
   if (!sys) return VSLAM_E_INVALID;
   HIPCHK(hipStreamSynchronize(sys->stream));
+  if (sys->ba_stream) HIPCHK(hipStreamSynchronize(sys->ba_stream));
   return VSLAM_OK;
 }
 

@@ -726,7 +726,7 @@ void trk_fill_params(const vslam_params& p, TrackParams& t) {
   t.min_frames_between_kf = p.min_frames_between_kf; t.max_kf_dist_wiggle_mult = p.max_kf_dist_wiggle_mult; t.wiggle_scale = p.wiggle_scale;
   t.ba_max_iterations = p.ba_max_iterations; t.ba_convergence_limit = p.ba_convergence_limit;
   t.ba_min_sigma2 = p.ba_min_tukey_sigma * p.ba_min_tukey_sigma; t.ba_window = p.ba_window; t.ba_min_keyframes = p.ba_min_keyframes;
-  t.quirks = p.quirks; t.max_points = p.max_points; t.max_keyframes = p.max_keyframes;
+  t.quirks = p.quirks; t.max_points = p.max_points; t.max_keyframes = p.max_keyframes; t.ba_delay = p.ba_delay_frames;
 
 }
 

@@ -90,6 +90,7 @@ struct TrackerState {       // Tracker members, jni/Tracker.h:77-150 (+ MapMaker
   int n_coarse, n_search, n_iter, n_l3;
   int coarse_range, fine_range, coarse_found;
   int ba_accepted, kf_added, ba_converged_recent, ba_converged_full;
+  int ba_countdown;         // > 0: a bundle adjustment is in flight, its results are applied when this reaches 0
   unsigned long long n_zmssd, n_ba_trials;
 };
 
@@ -103,6 +104,7 @@ struct TrackParams {        // device copy of the tunables the kernels read
   int ba_max_iterations; double ba_convergence_limit, ba_min_sigma2; int ba_window, ba_min_keyframes;
   int quirks;
   int max_points, max_keyframes;
+  int ba_delay;             // vslam_params.ba_delay_frames
 };
 
 struct MapDev {             // device pointers of the map + tracker of all streams
@@ -135,6 +137,10 @@ struct vslam_system {
   int fr_idx = 0;
   hipStream_t fe_stream = nullptr;
   hipEvent_t ev_fe_done[2] = {nullptr, nullptr}, ev_track_done[2] = {nullptr, nullptr};
+  // asynchronous map-maker (ba_delay_frames > 0): Bundle::Compute runs on ba_stream beside the following frames
+  hipStream_t ba_stream = nullptr;
+  std::vector<hipEvent_t> ev_asm, ev_ba;   // rings of ba_delay + 2 events, indexed by frame number
+  long frame_no = 0;
   std::vector<void*> allocs;   // everything to hipFree
   bool have_frame;
   TrackParams tp;
@@ -146,11 +152,15 @@ struct vslam_system {
   bool prof_on = false;
 };
 
-#define PROF_MARKS (VSLAM_N_STAGES + 2)   // marks 0..2 + PROF_FE_END on the front-end stream, 3..VSLAM_N_STAGES on the main stream
+#define PROF_MARKS (VSLAM_N_STAGES + 3)   // marks 0..2 + PROF_FE_END on the front-end stream, 3..VSLAM_N_STAGES on the main stream
 #define PROF_FE_END (VSLAM_N_STAGES + 1)
+#define PROF_BA_END (VSLAM_N_STAGES + 2)  // asynchronous map-maker: marks 12 and PROF_BA_END live on the BA stream
 static inline void prof_mark(vslam_system* sys, int k) {
-  if (sys->prof_on && sys->prof_frame < sys->prof_cap)
-    (void)hipEventRecord(sys->prof_ev[(size_t)sys->prof_frame * PROF_MARKS + k], (k < 3 || k == PROF_FE_END) ? sys->fe_stream : sys->stream);
+  if (!(sys->prof_on && sys->prof_frame < sys->prof_cap)) return;
+  hipStream_t st = sys->stream;
+  if (k < 3 || k == PROF_FE_END) st = sys->fe_stream;
+  else if (sys->tp.ba_delay > 0 && (k == 12 || k == PROF_BA_END)) st = sys->ba_stream;
+  (void)hipEventRecord(sys->prof_ev[(size_t)sys->prof_frame * PROF_MARKS + k], st);
 }
 
 // frontend.hip
@@ -165,6 +175,7 @@ int trk_track_map(vslam_system* sys);
 int ba_alloc(vslam_system* sys);
 int ba_add_keyframe_and_adjust(vslam_system* sys);
 int ba_run(vslam_system* sys, int mode);
+int ba_frame_start(vslam_system* sys);   // asynchronous map-maker: apply the results that are due at this frame
 // map.hip
 int map_init_states(vslam_system* sys);
 
