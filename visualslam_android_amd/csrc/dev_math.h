@@ -268,7 +268,8 @@ HDFN void inv2(const double m[4], double o[4]) {
 
 #ifdef __HIPCC__
 // k-th smallest (0-based) of n non-negative doubles in global memory or LDS (bit patterns order like the values):
-// MSB-first radix select, 8 bits per pass, histogram in LDS.  hist: LDS [256] ints, sel: LDS [2] u64.
+// MSB-first radix select, 8 bits per pass, histogram in LDS; stops as soon as the selected bin holds a single
+// value (the usual case after 3-4 passes).  hist: LDS [256] ints, sel: LDS [3] u64.
 DEVFN double block_radix_select(const double* v, int n, int k, int* hist, unsigned long long* sel) {
   unsigned long long prefix = 0, mask = 0;
   int kk = k;
@@ -290,19 +291,31 @@ DEVFN double block_radix_select(const double* v, int n, int k, int* hist, unsign
       const unsigned long long bm = __ballot(inc > kk);            // first lane whose inclusive prefix passes kk
       const int L = __ffsll((long long)bm) - 1;
       if (l == L) {
-        int acc = inc - tot, bin = 4 * l;
+        int acc = inc - tot, bin = 4 * l, cnt = h0;
         if (acc + h0 > kk) { }
-        else if (acc + h0 + h1 > kk) { acc += h0; bin += 1; }
-        else if (acc + h0 + h1 + h2 > kk) { acc += h0 + h1; bin += 2; }
-        else { acc += h0 + h1 + h2; bin += 3; }
+        else if (acc + h0 + h1 > kk) { acc += h0; bin += 1; cnt = h1; }
+        else if (acc + h0 + h1 + h2 > kk) { acc += h0 + h1; bin += 2; cnt = h2; }
+        else { acc += h0 + h1 + h2; bin += 3; cnt = h3; }
         sel[0] = prefix | ((unsigned long long)bin << shift);
         sel[1] = (unsigned long long)(kk - acc);
+        sel[2] = (unsigned long long)cnt;
       }
     }
     __syncthreads();
     prefix = sel[0]; kk = (int)sel[1];
+    const bool unique = sel[2] == 1ull;
     mask |= 255ull << shift;
     __syncthreads();
+    if (unique && pass < 7) {                                    // one value left under the prefix: fetch it whole
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v[i]);
+        if ((b & mask) == prefix) sel[0] = b;
+      }
+      __syncthreads();
+      prefix = sel[0];
+      __syncthreads();
+      break;
+    }
   }
   return __longlong_as_double((long long)prefix);
 }

@@ -19,15 +19,16 @@
 
 // ---------------------------------------------------------------------------------------------------------------
 // TrackerData::Project (jni/TrackerData.h:69-87).  Returns true when Cam.Project ran (pr valid).
-DEVFN bool td_project(TrackData& td, const MapPointDev& p, const Pose& pose, const CamModel& cam, CamProj& pr) {
+template <class T>
+DEVFN bool td_project(T& td, const double* pos, const Pose& pose, const CamModel& cam, CamProj& pr) {
   td.flags &= ~TDF_IN_IMAGE;
   double c[3];
-  pose_xform(pose, p.pos, c);
+  pose_xform(pose, pos, c);
   td.cam[0] = c[0]; td.cam[1] = c[1]; td.cam[2] = c[2];
   if (c[2] < 0.001) return false;
-  td.implane[0] = c[0] / c[2]; td.implane[1] = c[1] / c[2];
-  if (td.implane[0] * td.implane[0] + td.implane[1] * td.implane[1] > cam.largest_radius * cam.largest_radius) return false;
-  pr = cam_project(cam, td.implane[0], td.implane[1]);
+  const double implane[2] = {c[0] / c[2], c[1] / c[2]};
+  if (implane[0] * implane[0] + implane[1] * implane[1] > cam.largest_radius * cam.largest_radius) return false;
+  pr = cam_project(cam, implane[0], implane[1]);
   td.image[0] = pr.im[0]; td.image[1] = pr.im[1];
   if (pr.invalid) return true;
   if (td.image[0] < 0 || td.image[1] < 0 || td.image[0] > cam.size[0] || td.image[1] > cam.size[1]) return true;
@@ -37,14 +38,16 @@ DEVFN bool td_project(TrackData& td, const MapPointDev& p, const Pose& pose, con
 
 // TrackerData::ProjectAndDerivs (:98-102); derivatives refreshed only for found points whose projection ran
 // (see oracle/tracker.cpp td_project_and_derivs for the one deliberate deviation).
-DEVFN void td_project_and_derivs(TrackData& td, const MapPointDev& p, const Pose& pose, const CamModel& cam) {
+template <class T>
+DEVFN void td_project_and_derivs(T& td, const double* pos, const Pose& pose, const CamModel& cam) {
   CamProj pr;
-  const bool projected = td_project(td, p, pose, cam, pr);
+  const bool projected = td_project(td, pos, pose, cam, pr);
   if ((td.flags & TDF_FOUND) && projected) cam_derivs(cam, pr, td.derivs);
 }
 
 // TrackerData::CalcJacobian (:107-122)
-DEVFN void td_calc_jacobian(TrackData& td) {
+template <class T>
+DEVFN void td_calc_jacobian(const T& td, double* jac) {
   const double ooz = 1.0 / td.cam[2];
   const double c[3] = {td.cam[0], td.cam[1], td.cam[2]};
   const double d0 = td.derivs[0], d1 = td.derivs[1], d2 = td.derivs[2], d3 = td.derivs[3];
@@ -52,8 +55,8 @@ DEVFN void td_calc_jacobian(TrackData& td) {
   for (int m = 0; m < 6; m++) {
     double f0, f1;
     se3_generator_motion(m, c, ooz, f0, f1);
-    td.jac[m] = d0 * f0 + d1 * f1;
-    td.jac[6 + m] = d2 * f0 + d3 * f1;
+    jac[m] = d0 * f0 + d1 * f1;
+    jac[6 + m] = d2 * f0 + d3 * f1;
   }
 }
 
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(TRK_THREADS) void k_pvs(MapDev m, TrackParams tp) {
   td.level = -1;
   if (p.bad) return;
   CamProj pr;
-  td_project(td, p, pred, tp.cam, pr);                             // :379-381
+  td_project(td, p.pos, pred, tp.cam, pr);                             // :379-381
   if (!(td.flags & TDF_IN_IMAGE)) return;
   cam_derivs(tp.cam, pr, td.derivs);                               // :384 GetDerivsUnsafe
   // CalcSearchLevelAndWarpMatrix, jni/PatchFinder.cc:31-68
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(TRK_THREADS) void k_plan(MapDev m, TrackParams tp, 
         else idx = pvs[0 * P + (k - r2 - r1)];
         its = 0;
       }
-      if (e < n3 || did_coarse) td_project_and_derivs(td[idx], pts[idx], pose, tp.cam);   // :503-504, :529-532
+      if (e < n3 || did_coarse) td_project_and_derivs(td[idx], pts[idx].pos, pose, tp.cam);   // :503-504, :529-532
       slist[e] = make_int2(idx, its);
       ilist[nit + e] = idx;
     }
@@ -447,27 +450,293 @@ __global__ __launch_bounds__(64) void k_search(MapDev m, TrackParams tp, SearchA
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Block-wide helpers for k_pose
+// 8x8 patches (the PTAM default): eight patches per wavefront, eight lanes per patch, lane r owns template row r as
+// two packed dwords.  Same arithmetic per pixel / per candidate as k_search<PS>; no LDS, 8x fewer wavefronts, and
+// the dependent global loads of eight patches overlap.  ZMSSD sums use v_dot4_u32_u8.
+DEVFN int grp_sum_i(int v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); return v; }
+DEVFN double grp_sum_d(double v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); return v; }
+DEVFN uint2 load_row8(const uint8_t* p) { uint2 v; __builtin_memcpy(&v, p, 8); return v; }
+DEVFN int row_byte(const uint2& r, int x) { return x < 4 ? (int)((r.x >> (8 * x)) & 255u) : (int)((r.y >> (8 * (x - 4))) & 255u); }
+DEVFN unsigned udot4(unsigned a, unsigned b, unsigned c) { return __builtin_amdgcn_udot4(a, b, c, false); }
+
+__global__ __launch_bounds__(64) void k_search8(MapDev m, TrackParams tp, SearchArgs a, int stage) {
+  constexpr int PS = 8, NPIX = 64, HALF = 4;
+  const int s = blockIdx.y;
+  TrackerState* st = &m.st[s];
+  if (!(st->map_good && st->lost_frames < 3)) return;
+  const int nsearch = st->n_search;
+  if ((int)blockIdx.x * 8 >= nsearch) return;
+  const int lane = threadIdx.x, grp = lane >> 3, sub = lane & 7;
+  const int e = blockIdx.x * 8 + grp;
+  bool act = e < nsearch;                                            // this lane group has a patch
+  const bool lead = sub == 0;
+  const int2 ent = act ? m.search_list[(size_t)s * tp.max_points + e] : make_int2(0, 0);
+  const int idx = ent.x, nSubPixIts = ent.y;
+  const int nRangeL0 = stage == 0 ? st->coarse_range : st->fine_range;
+  TrackData& td = m.td[(size_t)s * tp.max_points + idx];
+  const MapPointDev& p = m.pts[(size_t)s * tp.max_points + idx];
+  uint8_t* gtmpl = m.tmpl + ((size_t)s * tp.max_points + idx) * TMPL_PITCH;
+  const int level = act ? td.level : 0, scale = 1 << level;
+  int flags = td.flags;
+
+  // ---- MakeTemplateCoarseCont, jni/PatchFinder.cc:79-125 ----
+  double inv[4];
+  inv2(td.warp_inv, inv);
+  const double m2[4] = {inv[0] * scale, inv[1] * scale, inv[2] * scale, inv[3] * scale};
+  bool refresh = !(flags & TDF_HAVE_LAST);
+  for (int i = 0; !refresh && i < 2; i++) {
+    const double dx = m2[i] - td.last_warp[i], dy = m2[2 + i] - td.last_warp[2 + i];
+    if (dx * dx + dy * dy > 0.07 * 0.07) refresh = true;
+  }
+  refresh = refresh && act;
+  uint2 trow;                                                        // template row `sub`
+  int tsum, tsumsq;
+  if (__any(refresh)) {
+    // transform_image (jni/vision/ImageHandler.cpp:21-113): same accumulated stepping of the sample position
+    const int sl = p.src_level;
+    const uint8_t* src = m.kf_img[sl] + ((size_t)s * tp.max_keyframes + p.src_kf) * a.kf_stride[sl];
+    const int sp = a.kf_pitch[sl], iw = a.w[sl], ih = a.h[sl];
+    const double across[2] = {m2[0], m2[2]}, down[2] = {m2[1], m2[3]};
+    double px = (double)p.irx - (m2[0] * HALF + m2[1] * HALF), py = (double)p.iry - (m2[2] * HALF + m2[3] * HALF);
+    const double cr[2] = {down[0] - PS * across[0], down[1] - PS * across[1]};
+    double rx[PS], ry[PS];
+#pragma unroll
+    for (int j = 0; j < PS; j++) { rx[j] = 0; ry[j] = 0; }
+#pragma unroll 1
+    for (int i = 0; i < PS; i++) {
+#pragma unroll
+      for (int j = 0; j < PS; j++) {
+        if (i == sub) { rx[j] = px; ry[j] = py; }
+        px += across[0]; py += across[1];
+      }
+      px += cr[0]; py += cr[1];
+    }
+    if (refresh) {
+      int nOutside = 0, sum = 0, sumsq = 0;
+      const float x_bound = (float)(iw - 1), y_bound = (float)(ih - 1);
+      unsigned w0 = 0, w1 = 0;
+#pragma unroll
+      for (int j = 0; j < PS; j++) {
+        double x = rx[j], y = ry[j];
+        int v = 0;
+        if (0 <= x && 0 <= y && x < x_bound && y < y_bound) {
+          const int lx = (int)x, ly = (int)y;                        // sample(), ImageHandler.cpp:12-19
+          x -= lx; y -= ly;
+          const uint8_t* q0 = src + (size_t)ly * sp + lx;
+          v = (uint8_t)((1 - y) * ((1 - x) * q0[0] + x * q0[1]) + y * ((1 - x) * q0[sp] + x * q0[sp + 1]));
+        } else nOutside++;
+        if (j < 4) w0 |= (unsigned)v << (8 * j); else w1 |= (unsigned)v << (8 * (j - 4));
+        sum += v; sumsq += v * v;
+      }
+      trow = make_uint2(w0, w1);
+      *(uint2*)(gtmpl + sub * PS) = trow;
+      nOutside = grp_sum_i(nOutside);
+      tsum = grp_sum_i(sum); tsumsq = grp_sum_i(sumsq);              // MakeTemplateSums :152-164
+      flags = nOutside ? (flags | TDF_TMPL_BAD) : (flags & ~TDF_TMPL_BAD);
+      flags |= TDF_HAVE_LAST;
+      if (lead) { td.tsum = tsum; td.tsumsq = tsumsq; for (int i = 0; i < 4; i++) td.last_warp[i] = m2[i]; }
+    }
+  }
+  if (!refresh) {
+    trow = *(const uint2*)(gtmpl + sub * PS);
+    tsum = td.tsum; tsumsq = td.tsumsq;
+  }
+  if (act && (flags & TDF_TMPL_BAD)) {                               // jni/Tracker.cc:637-640
+    if (lead) td.flags = flags & ~(TDF_IN_IMAGE | TDF_FOUND);
+    act = false;
+  }
+  for (int l = 0; l < NLEV; l++) {                                   // manMeasAttempted[level]++ (:641), one atomic per wave
+    const int c = __popcll(__ballot(act && lead && level == l));
+    if (lane == 0 && c) atomicAdd(&st->attempted[l], c);
+  }
+
+  // ---- FindPatchCoarse, jni/PatchFinder.cc:170-235 ----
+  const double irx = td.image[0] / scale, iry = td.image[1] / scale;
+  const unsigned nRange = ((unsigned)nRangeL0 + scale - 1) / scale;
+  int nTop = (int)(iry - nRange);
+  const int nBottomPlusOne = (int)(iry + nRange + 1);
+  const int nLeft = (int)(irx - nRange), nRight = (int)(irx + nRange);
+  const int rows = a.h[level], cols = a.w[level];
+  if (nTop < 0) nTop = 0;
+  int nBestSSD = tp.max_ssd + 1;
+  int bestIdx = 0;
+  unsigned nEval = 0;
+  const uint32_t* corners = a.corners[level] + (size_t)s * a.cap[level];
+  const uint8_t* img = a.img[level] + (size_t)s * a.img_sstride[level];
+  const int ip = a.img_pitch[level];
+  int i0 = 0, i1 = 0;
+  if (act && !(nTop >= rows) && !(nBottomPlusOne <= 0)) {
+    const int* lut = a.rowlut[level] + (size_t)s * (rows + 1);
+    i0 = lut[nTop];
+    i1 = nBottomPlusOne >= rows ? a.ncorners[s * NLEV + level] : lut[nBottomPlusOne];
+  }
+  const double r2max = (double)(nRange * nRange);
+  const unsigned tl = trow.x, th = trow.y;
+  for (int base = i0; __any(base < i1); base += 8) {
+    // filter 8 corners of the row-LUT window at a time (:216-219); survivors are evaluated in raster order
+    const int ci = base + sub;
+    bool ok = false;
+    uint32_t cval = 0;
+    if (ci < i1) {
+      cval = corners[ci];
+      const int cx = cval & 0xFFFF, cy = cval >> 16;
+      if (!(cx < nLeft || cx > nRight)) {
+        const double dx = irx - cx, dy = iry - cy;
+        ok = !(dx * dx + dy * dy > r2max);
+      }
+    }
+    unsigned gm = (unsigned)(__ballot(ok) >> (grp * 8)) & 255u;
+    nEval += __popc(gm);
+    while (__any(gm != 0)) {
+      const bool has = gm != 0;
+      const int k = has ? __ffs(gm) - 1 : 0;
+      const uint32_t c = __shfl(cval, grp * 8 + k);
+      gm &= gm - 1;
+      // ZMSSDAtPoint (:352-380): one image row per lane
+      const int cx = c & 0xFFFF, cy = c >> 16;
+      const bool inside = has && cx >= HALF && cy >= HALF && cx < cols - HALF && cy < rows - HALF;   // in_image_with_border
+      unsigned sA = 0, sQ = 0, sX = 0;
+      if (inside) {
+        const uint2 n = load_row8(img + (size_t)(cy - HALF + sub) * ip + (cx - HALF));
+        sA = udot4(n.x, 0x01010101u, udot4(n.y, 0x01010101u, 0u));
+        sQ = udot4(n.x, n.x, udot4(n.y, n.y, 0u));
+        sX = udot4(n.x, tl, udot4(n.y, th, 0u));
+      }
+      sA = grp_sum_i(sA); sQ = grp_sum_i(sQ); sX = grp_sum_i(sX);
+      if (has) {
+        int ssd = tp.max_ssd + 1;
+        if (inside) {
+          const int SA = tsum, SB = (int)sA;
+          ssd = ((2 * SA * SB - SA * SA - SB * SB) / NPIX + (int)sQ + tsumsq - 2 * (int)sX);
+        }
+        if (ssd < nBestSSD) { nBestSSD = ssd; bestIdx = base + k; }    // first strict minimum in raster order (:223)
+      }
+    }
+  }
+  flags |= TDF_SEARCHED;                                             // :645
+  {
+    const int tot = wave_sum_i(act && lead ? (int)nEval : 0);
+    if (lane == 0 && tot) atomicAdd(&st->n_zmssd, (unsigned long long)tot);
+  }
+  bool found = act && nBestSSD < tp.max_ssd;
+  if (act && !found && lead) td.flags = flags & ~TDF_FOUND;          // :646-649
+  const uint32_t bc = found ? corners[bestIdx] : 0u;
+  const double coarse[2] = {level_zero_pos((double)(bc & 0xFFFF), level), level_zero_pos((double)(bc >> 16), level)};
+  if (found) flags |= TDF_FOUND;
+  const bool dosub = found && nSubPixIts > 0;
+  if (found && !dosub) {                                             // :668-671
+    flags &= ~TDF_SUBPIX;
+    if (lead) { td.flags = flags; td.sqrt_inv_noise = 1.0 / scale; td.vfound[0] = coarse[0]; td.vfound[1] = coarse[1]; }
+  }
+  if (__any(dosub)) {
+    // ---- MakeSubPixTemplate (:242-271) + IterateSubPixToConvergence (:273-350): lane y owns interior row y ----
+    const bool rowok = sub >= 1 && sub <= 6;
+    const uint2 rup = make_uint2(__shfl(trow.x, lane - 1), __shfl(trow.y, lane - 1));
+    const uint2 rdn = make_uint2(__shfl(trow.x, lane + 1), __shfl(trow.y, lane + 1));
+    double gx[6], gy[6];
+    double h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0;
+#pragma unroll
+    for (int x = 1; x <= 6; x++) {
+      gx[x - 1] = 0; gy[x - 1] = 0;
+      if (rowok) {
+        gx[x - 1] = 0.5 * (row_byte(trow, x + 1) - row_byte(trow, x - 1));
+        gy[x - 1] = 0.5 * (row_byte(rdn, x) - row_byte(rup, x));
+        h00 += gx[x - 1] * gx[x - 1]; h01 += gx[x - 1] * gy[x - 1]; h02 += gx[x - 1];
+        h11 += gy[x - 1] * gy[x - 1]; h12 += gy[x - 1]; h22 += 1.0;
+      }
+    }
+    h00 = grp_sum_d(h00); h01 = grp_sum_d(h01); h02 = grp_sum_d(h02);     // quarter-integers: exact in any order
+    h11 = grp_sum_d(h11); h12 = grp_sum_d(h12); h22 = grp_sum_d(h22);
+    const double H[9] = {h00, h01, h02, h01, h11, h12, h02, h12, h22};
+    double Hinv[9];
+    inv3(H, Hinv);
+    double sub0 = coarse[0], sub1 = coarse[1], meanDiff = 0.0;
+    bool running = dosub, converged = false;
+    for (int it = 0; __any(running); it++) {
+      if (it >= nSubPixIts) running = false;
+      double cx = 0, cy = 0;
+      if (running) {
+        cx = level_n_pos(sub0, level); cy = level_n_pos(sub1, level);
+        const int xb = (int)(cx > 0.0 ? cx + 0.5 : cx - 0.5), yb = (int)(cy > 0.0 ? cy + 0.5 : cy - 0.5);
+        const int b = HALF + 1;
+        if (!(xb >= b && yb >= b && xb < cols - b && yb < rows - b)) running = false;   // went off edge -> fail
+      }
+      double a0 = 0, a1 = 0, a2 = 0;
+      if (running && rowok) {
+        const double bx = cx - HALF, by = cy - HALF;
+        const double dX = bx - floor(bx), dY = by - floor(by);
+        const float fTL = (float)((1.0 - dX) * (1.0 - dY)), fTR = (float)((dX) * (1.0 - dY));
+        const float fBL = (float)((1.0 - dX) * (dY)), fBR = (float)((dX) * (dY));
+        const uint8_t* r0 = img + (size_t)((int)by + sub) * ip + (int)bx + 1;
+        const uint2 p0 = load_row8(r0), p1 = load_row8(r0 + ip);
+#pragma unroll
+        for (int x = 1; x <= 6; x++) {
+          const float fPixel = fTL * row_byte(p0, x - 1) + fTR * row_byte(p0, x) + fBL * row_byte(p1, x - 1) + fBR * row_byte(p1, x);
+          const double dDiff = (fPixel - (float)row_byte(trow, x)) + meanDiff;
+          a0 += dDiff * gx[x - 1]; a1 += dDiff * gy[x - 1]; a2 += dDiff;
+        }
+      }
+      a0 = grp_sum_d(a0); a1 = grp_sum_d(a1); a2 = grp_sum_d(a2);
+      if (running) {
+        const double u0 = Hinv[0] * a0 + Hinv[1] * a1 + Hinv[2] * a2;
+        const double u1 = Hinv[3] * a0 + Hinv[4] * a1 + Hinv[5] * a2;
+        const double u2 = Hinv[6] * a0 + Hinv[7] * a1 + Hinv[8] * a2;
+        sub0 -= u0 * scale; sub1 -= u1 * scale; meanDiff -= u2;
+        if (u0 * u0 + u1 * u1 < 0.03 * 0.03) { converged = true; running = false; }
+      }
+    }
+    if (dosub) {
+      flags |= TDF_SUBPIX;
+      if (!converged) { found = false; if (lead) td.flags = flags & ~TDF_FOUND; }   // :658-666 un-finds the point
+      else if (lead) { td.flags = flags; td.sqrt_inv_noise = 1.0 / scale; td.vfound[0] = sub0; td.vfound[1] = sub1; }
+    }
+  }
+  for (int l = 0; l < NLEV; l++) {                                   // manMeasFound[level]++ (:652)
+    const int c = __popcll(__ballot(found && lead && level == l));
+    if (lane == 0 && c) atomicAdd(&st->found[l], c);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_pose: one workgroup per stream.  The tracker data of the iteration set is gathered once into a component-major
+// working set indexed by iteration-set entry (coalesced, L2 resident) and scattered back after the ten iterations;
+// entry e is always handled by thread e % POSE_THREADS, so the working set needs no synchronisation.
 #define POSE_THREADS 512
 #define POSE_WAVES (POSE_THREADS / 64)
 
+struct PoseItem {            // TrackerData fields used by the pose iterations (jni/TrackerData.h:36-66)
+  double cam[3], image[2], derivs[4], vfound[2], sqrt_inv_noise;   // the 2x6 Jacobian is re-derived from cam + derivs where used
+  int flags, idx;
+};
+struct PoseWs { double* d; int* i; int P; };
+
+DEVFN void item_load(PoseItem& it, const PoseWs& w, int e) {
+  it.flags = w.i[e]; it.idx = w.i[w.P + e];
+#pragma unroll
+  for (int i = 0; i < 3; i++) it.cam[i] = w.d[(0 + i) * w.P + e];
+#pragma unroll
+  for (int i = 0; i < 2; i++) { it.image[i] = w.d[(3 + i) * w.P + e]; it.vfound[i] = w.d[(9 + i) * w.P + e]; }
+#pragma unroll
+  for (int i = 0; i < 4; i++) it.derivs[i] = w.d[(5 + i) * w.P + e];
+  it.sqrt_inv_noise = w.d[11 * w.P + e];
+}
+DEVFN void item_store(const PoseItem& it, const PoseWs& w, int e, bool all) {   // all: cam/derivs/flags changed too
+#pragma unroll
+  for (int i = 0; i < 2; i++) w.d[(3 + i) * w.P + e] = it.image[i];
+  if (!all) return;
+  w.i[e] = it.flags;
+#pragma unroll
+  for (int i = 0; i < 3; i++) w.d[(0 + i) * w.P + e] = it.cam[i];
+#pragma unroll
+  for (int i = 0; i < 4; i++) w.d[(5 + i) * w.P + e] = it.derivs[i];
+}
+
 // CalcPoseUpdate, jni/Tracker.cc:683-774 (Tukey).  All threads of the workgroup call it; result in up[6] (LDS).
-DEVFN void calc_pose_update(TrackData* td, MapPointDev* pts, const int* ilist, int n, const TrackParams& tp,
+DEVFN void calc_pose_update(const PoseWs& ws, MapPointDev* pts, int n, int nvalid_thread, const TrackParams& tp,
                             double dOverrideSigma, bool bMarkOutliers, double* sortbuf, double* red /* [waves][28] */,
-                            double* up /* [6] */, int* icnt, int* hist /* [256] */, unsigned long long* sel /* [2] */) {
+                            double* up /* [6] */, int* icnt, int* hist /* [256] */, unsigned long long* sel /* [3] */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int nvalid = 0;
-  for (int e = threadIdx.x; e < n; e += POSE_THREADS) {
-    double e2 = __builtin_huge_val();
-    TrackData& t = td[ilist[e]];
-    if (t.flags & TDF_FOUND) {
-      t.err[0] = (t.vfound[0] - t.image[0]) * t.sqrt_inv_noise;     // :707
-      t.err[1] = (t.vfound[1] - t.image[1]) * t.sqrt_inv_noise;
-      e2 = t.err[0] * t.err[0] + t.err[1] * t.err[1];
-      nvalid++;
-    }
-    sortbuf[e] = e2;
-  }
+  int nvalid = nvalid_thread;                                        // residuals are already in sortbuf (k_pose)
   nvalid = wave_sum_i(nvalid);
   if (lane == 0) icnt[wave] = nvalid;
   __syncthreads();
@@ -486,27 +755,36 @@ DEVFN void calc_pose_update(TrackData* td, MapPointDev* pts, const int* ilist, i
   }
   const bool qint = (tp.quirks & VSLAM_Q_POSE_INT_RESIDUAL) != 0;
   double acc[27];
+#pragma unroll
   for (int i = 0; i < 27; i++) acc[i] = 0.0;
   for (int e = threadIdx.x; e < n; e += POSE_THREADS) {
-    const int idx = ilist[e];
-    TrackData& t = td[idx];
-    if (!(t.flags & TDF_FOUND)) continue;
-    const double es = t.err[0] * t.err[0] + t.err[1] * t.err[1];
+    if (!(ws.i[e] & TDF_FOUND)) continue;
+    PoseItem t;
+    item_load(t, ws, e);
+    const double err[2] = {(t.vfound[0] - t.image[0]) * t.sqrt_inv_noise, (t.vfound[1] - t.image[1]) * t.sqrt_inv_noise};
+    const double es = err[0] * err[0] + err[1] * err[1];
     const double w = tukey_weight(es, sigma2);
-    if (w == 0.0) { if (bMarkOutliers) pts[idx].n_out++; continue; }   // :749-756
-    else if (bMarkOutliers) pts[idx].n_in++;
+    if (w == 0.0) { if (bMarkOutliers) pts[t.idx].n_out++; continue; }   // :749-756
+    else if (bMarkOutliers) pts[t.idx].n_in++;
+    double jac[12];
+    td_calc_jacobian(t, jac);                                        // CalcJacobian, jni/TrackerData.h:107-122
+#pragma unroll
     for (int row = 0; row < 2; row++) {                              // wls.add_mJ x2 (:766-767), jni/myWLS.h:39-50
-      const double mm = qint ? (double)(int)t.err[row] : t.err[row];
+      const double mm = qint ? (double)(int)err[row] : err[row];
       double J[6];
-      for (int k = 0; k < 6; k++) J[k] = t.sqrt_inv_noise * t.jac[row * 6 + k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) J[k] = t.sqrt_inv_noise * jac[row * 6 + k];
       int q = 0;
+#pragma unroll
       for (int r = 0; r < 6; r++) {
         const double Jw = w * J[r];
         acc[21 + r] += mm * Jw;
+#pragma unroll
         for (int c = r; c < 6; c++) acc[q++] += Jw * J[c];
       }
     }
   }
+#pragma unroll
   for (int i = 0; i < 27; i++) { const double v = wave_sum_d(acc[i]); if (lane == 0) red[wave * 28 + i] = v; }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -551,53 +829,69 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose(MapDev m, TrackParams tp,
   __shared__ double up[6], last_up[6];
   __shared__ int icnt[POSE_WAVES];
   __shared__ int hist[256];
-  __shared__ unsigned long long sel[2];
+  __shared__ unsigned long long sel[3];
   __shared__ Pose pose;
   if (threadIdx.x == 0) pose = st->pose_cur;
-  __syncthreads();
+  if (threadIdx.x < 6) last_up[threadIdx.x] = 0.0;
+  const int n = stage == 0 ? st->n_coarse : st->n_iter;
   if (stage == 0) {
-    const int n = st->n_coarse;
     if (n == 0) return;
     const int nFound = st->found[0] + st->found[1] + st->found[2] + st->found[3];
     if (nFound < tp.coarse_min) return;                              // :465
-    for (int iter = 0; iter < 10; iter++) {
-      for (int e = threadIdx.x; e < n; e += POSE_THREADS) {
-        TrackData& t = td[ilist[e]];
-        if (!(t.flags & TDF_FOUND)) continue;
-        if (iter != 0) td_project_and_derivs(t, pts[ilist[e]], pose, tp.cam);
-        td_calc_jacobian(t);
-      }
-      __syncthreads();
-      calc_pose_update(td, pts, ilist, n, tp, iter > 5 ? 1.0 : 0.0, false, sortbuf, red, up, icnt, hist, sel);
-      if (threadIdx.x == 0) pose = pose_mul(se3_exp(up), pose);      // :487
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) { st->pose_cur = pose; st->did_coarse = 1; }
-    return;
   }
-  const int n = st->n_iter;
-  if (threadIdx.x < 6) last_up[threadIdx.x] = 0.0;
+  const PoseWs ws = {m.pose_ws + (size_t)s * POSE_WS_COMPS * P, m.pose_wsi + (size_t)s * 2 * P, P};
+  for (int e = threadIdx.x; e < n; e += POSE_THREADS) {             // gather
+    const int idx = ilist[e];
+    const TrackData& t = td[idx];
+    ws.i[e] = t.flags; ws.i[P + e] = idx;
+    for (int i = 0; i < 3; i++) ws.d[(0 + i) * P + e] = t.cam[i];
+    for (int i = 0; i < 2; i++) { ws.d[(3 + i) * P + e] = t.image[i]; ws.d[(9 + i) * P + e] = t.vfound[i]; }
+    for (int i = 0; i < 4; i++) ws.d[(5 + i) * P + e] = t.derivs[i];
+    ws.d[11 * P + e] = t.sqrt_inv_noise;
+  }
   __syncthreads();
-  for (int iter = 0; iter < 10; iter++) {                            // :543-577
-    const bool nonlinear = (iter == 0 || iter == 4 || iter == 9);
+  for (int iter = 0; iter < 10; iter++) {                            // coarse :466-488, fine :543-577
+    const bool nonlinear = stage == 0 || iter == 0 || iter == 4 || iter == 9;
+    int nvalid = 0;
     for (int e = threadIdx.x; e < n; e += POSE_THREADS) {
-      TrackData& t = td[ilist[e]];
-      if (!(t.flags & TDF_FOUND)) continue;
-      if (iter != 0) {
-        if (nonlinear) td_project_and_derivs(t, pts[ilist[e]], pose, tp.cam);
-        else {                                                       // LinearUpdate, jni/TrackerData.h:125-131
-          double a = 0, b = 0;
-          for (int k = 0; k < 6; k++) { a += t.jac[k] * last_up[k]; b += t.jac[6 + k] * last_up[k]; }
-          t.image[0] += a; t.image[1] += b;
+      double e2 = __builtin_huge_val();
+      if (ws.i[e] & TDF_FOUND) {
+        PoseItem t;
+        item_load(t, ws, e);
+        if (iter != 0) {
+          if (nonlinear) td_project_and_derivs(t, pts[t.idx].pos, pose, tp.cam);
+          else {                                                     // LinearUpdate, jni/TrackerData.h:125-131
+            double jac[12], a = 0, b = 0;
+            td_calc_jacobian(t, jac);                                // m26Jacobian of the last non-linear iteration
+#pragma unroll
+            for (int k = 0; k < 6; k++) { a += jac[k] * last_up[k]; b += jac[6 + k] * last_up[k]; }
+            t.image[0] += a; t.image[1] += b;
+          }
+          item_store(t, ws, e, nonlinear);
         }
+        const double e0 = (t.vfound[0] - t.image[0]) * t.sqrt_inv_noise;   // v2Error_CovScaled, :707
+        const double e1 = (t.vfound[1] - t.image[1]) * t.sqrt_inv_noise;
+        e2 = e0 * e0 + e1 * e1;
+        nvalid++;
       }
-      if (nonlinear) td_calc_jacobian(t);
+      sortbuf[e] = e2;
     }
-    __syncthreads();
-    calc_pose_update(td, pts, ilist, n, tp, iter > 5 ? 16.0 : 0.0, iter == 9, sortbuf, red, up, icnt, hist, sel);
-    if (threadIdx.x == 0) pose = pose_mul(se3_exp(up), pose);
+    const double override_sigma = iter > 5 ? (stage == 0 ? 1.0 : 16.0) : 0.0;
+    calc_pose_update(ws, pts, n, nvalid, tp, override_sigma, stage == 1 && iter == 9, sortbuf, red, up, icnt, hist, sel);
+    if (threadIdx.x == 0) pose = pose_mul(se3_exp(up), pose);        // :487 / :573
     if (threadIdx.x < 6) last_up[threadIdx.x] = up[threadIdx.x];
     __syncthreads();
+  }
+  for (int e = threadIdx.x; e < n; e += POSE_THREADS) {             // scatter what the iterations changed
+    TrackData& t = td[ws.i[P + e]];
+    t.flags = ws.i[e];
+    for (int i = 0; i < 3; i++) t.cam[i] = ws.d[(0 + i) * P + e];
+    for (int i = 0; i < 2; i++) t.image[i] = ws.d[(3 + i) * P + e];
+    for (int i = 0; i < 4; i++) t.derivs[i] = ws.d[(5 + i) * P + e];
+  }
+  if (stage == 0) {
+    if (threadIdx.x == 0) { st->pose_cur = pose; st->did_coarse = 1; }
+    return;
   }
   // ---- measurement export (:594-607) and scene depth (:610-625) ----
   MeasDev* cm = m.cur_meas + (size_t)s * P;
@@ -690,6 +984,7 @@ int trk_alloc(vslam_system* sys) {
   TALLOC(m.kf_pose, S * K); TALLOC(m.kf_fixed, S * K); TALLOC(m.kf_depth, S * K * 2);
   for (int l = 0; l < NLEV; l++) TALLOC(m.kf_img[l], S * K * (size_t)sys->geom[l].pitch * sys->geom[l].h);
   TALLOC(m.st, S); TALLOC(m.pvs_list, S * NLEV * P); TALLOC(m.search_list, S * P); TALLOC(m.iter_list, S * P);
+  TALLOC(m.pose_ws, S * POSE_WS_COMPS * P); TALLOC(m.pose_wsi, S * 2 * P);
   trk_fill_params(p, sys->tp);
   return VSLAM_OK;
 }
@@ -750,7 +1045,7 @@ int trk_track_map(vslam_system* sys) {
   prof_mark(sys, 5);
   if (!tp.coarse_disabled) {
     const int nc = 2 * tp.coarse_max;
-    if (tp.P == 8) hipLaunchKernelGGL(k_search<8>, dim3(nc, S), dim3(64), 0, sys->stream, m, tp, a, 0);
+    if (tp.P == 8) hipLaunchKernelGGL(k_search8, dim3((nc + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 0);
     else hipLaunchKernelGGL(k_search<11>, dim3(nc, S), dim3(64), 0, sys->stream, m, tp, a, 0);
     prof_mark(sys, 6);
     hipLaunchKernelGGL(k_pose, dim3(S), dim3(POSE_THREADS), 0, sys->stream, m, tp, 0);
@@ -758,7 +1053,7 @@ int trk_track_map(vslam_system* sys) {
   prof_mark(sys, 7);
   hipLaunchKernelGGL(k_plan, dim3(S), dim3(TRK_THREADS), 0, sys->stream, m, tp, 1);
   prof_mark(sys, 8);
-  if (tp.P == 8) hipLaunchKernelGGL(k_search<8>, dim3(maxSearch, S), dim3(64), 0, sys->stream, m, tp, a, 1);
+  if (tp.P == 8) hipLaunchKernelGGL(k_search8, dim3((maxSearch + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 1);
   else hipLaunchKernelGGL(k_search<11>, dim3(maxSearch, S), dim3(64), 0, sys->stream, m, tp, a, 1);
   prof_mark(sys, 9);
   hipLaunchKernelGGL(k_pose, dim3(S), dim3(POSE_THREADS), 0, sys->stream, m, tp, 1);

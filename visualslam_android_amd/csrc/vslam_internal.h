@@ -50,6 +50,7 @@ struct FrameDev {
 
 
 // ---- map + tracker state (all device resident) -------------------------------------------------------------------
+#define POSE_WS_COMPS 12
 #define TMPL_PITCH 128      // bytes reserved per cached template (11 x 11 = 121)
 
 struct MapPointDev {        // MapPoint, jni/MapPoint.h:22-69
@@ -66,8 +67,8 @@ struct MapPointDev {        // MapPoint, jni/MapPoint.h:22-69
 #define TDF_HAVE_LAST 32
 
 struct TrackData {          // TrackerData (jni/TrackerData.h:36-66) + persistent PatchFinder state (jni/PatchFinder.h:96-128)
-  double cam[3], implane[2], image[2], derivs[4];
-  double vfound[2], sqrt_inv_noise, err[2], jac[12];
+  double cam[3], image[2], derivs[4];
+  double vfound[2], sqrt_inv_noise;      // the 2x6 Jacobian and the residual live in k_pose's registers only
   double warp_inv[4], last_warp[4];
   int level, flags, tsum, tsumsq;
 };
@@ -121,6 +122,8 @@ struct MapDev {             // device pointers of the map + tracker of all strea
   int* pvs_list;            // [S][NLEV][max_points]
   int2* search_list;        // [S][max_points]  (point index, sub-pixel iterations)
   int* iter_list;           // [S][max_points]  vIterationSet
+  double* pose_ws;          // [S][POSE_WS_COMPS][max_points]  k_pose working set, component-major, indexed by iteration-set entry
+  int* pose_wsi;            // [S][2][max_points]  flags, map point index
 };
 
 struct vslam_system {
