@@ -4,7 +4,10 @@
 // Data layout (per problem, struct-of-arrays in HBM, fp64):
 //   cameras: pose, trial pose, fixed flag, start row, U (6x6 lower), epsilon_a
 //   points : position, trial position, V (3x3 lower), epsilon_b, V*^-1
-//   measurements in AddMeas order: (p, c), found, sqrt-inv-noise, state, v3Cam, epsilon, A (2x6), B (2x3), W (6x3)
+//   measurements in AddMeas order: (p, c), found, sqrt-inv-noise, state, v3Cam, weighted camera derivatives, epsilon.
+//   The Jacobians A (2x6), B (2x3) and W = A^T B (6x3) are NOT stored: every consumer re-derives them from v3Cam, the
+//   weighted derivatives and the camera rotation (about 150 flops instead of 288 B written and up to 1 KB re-read per
+//   measurement and LM trial -- at 256 concurrent problems the kernel is HBM-bound, not flop-bound).
 //   lut[c][p] -> measurement index (GenerateMeasLUTs :566-575)
 // Reductions are deterministic: "segmented" per-camera / per-camera-pair sums are taken by one wavefront each
 // (lanes stride over the points, then __shfl_xor butterflies), per-point sums by one lane in camera order.
@@ -14,6 +17,9 @@
 #define BA_THREADS 512
 #define BA_LDS_N 60      // reduced camera systems up to 60 x 60 (10 adjustable cameras) are solved in LDS
 #define BA_WAVES (BA_THREADS / 64)
+#define BA_ILP_PROJ 1   // the two projection passes are bound by fp64 transcendental maths, not by latency: more in flight only spills
+#define BA_ILP_S 1      // Schur-complement tasks: 36 accumulators + two 6x3 blocks per lane leave no registers for a second point
+#define BA_ILP 4        // independent measurements per thread and loop trip: the loops are memory-latency bound at 2 waves/SIMD
 
 #define MS_OK 0
 #define MS_BAD 1      // bBad: z <= 0 or zero Tukey weight in this step
@@ -37,7 +43,7 @@ struct BaView {          // pointers already offset to one problem
   Pose* cam_pose; Pose* cam_new; int* cam_fixed; int* cam_row; double* cam_U; double* cam_ea;
   double* pt_pos; double* pt_new; double* pt_V; double* pt_eb; double* pt_Vinv; int* pt_nmeas; int* pt_nout;
   int* ms_p; int* ms_c; int* ms_state; double* ms_found; double* ms_sin; double* ms_cam; double* ms_eps; double* ms_err2;
-  double* ms_derivs; double* ms_A; double* ms_B; double* ms_W;
+  double* ms_derivs;
   int* lut;              // [max_cams][max_pts]
   double* S; double* E; double* cam_up; double* map_up;
   double* scratch;       // [max_meas]
@@ -85,23 +91,66 @@ DEVFN int ba_block_sum_i(int v, int* red) {
   return t;
 }
 
-// ProjectAndFindSquaredError, jni/Bundle.cc:181-199
-DEVFN void ba_project_meas(const BaView& v, const BaConfig& cfg, int i) {
-  const Pose& cam = v.cam_pose[v.ms_c[i]];
-  const double* X = v.pt_pos + 3 * v.ms_p[i];
+// ProjectAndFindSquaredError, jni/Bundle.cc:181-199, on operands already in registers (camera pose T, point X, found
+// position f, sqrt-inv-noise sn).  Stores v3Cam, state, derivatives, epsilon, error^2 of measurement i.
+DEVFN int ba_project_meas(const BaView& v, const BaConfig& cfg, int i, const Pose& T, const double X[3], double f0, double f1, double sn, double& e2) {
   double c[3];
-  pose_xform(cam, X, c);
+  pose_xform(T, X, c);
   MS(ms_cam, 0, i) = c[0]; MS(ms_cam, 1, i) = c[1]; MS(ms_cam, 2, i) = c[2];
-  if (c[2] <= 0) { v.ms_state[i] = MS_BAD; return; }
+  if (c[2] <= 0) { v.ms_state[i] = MS_BAD; return MS_BAD; }
   v.ms_state[i] = MS_OK;
   const CamProj pr = cam_project(cfg.cam, c[0] / c[2], c[1] / c[2]);
   double dd[4];
   cam_derivs(cfg.cam, pr, dd);
   MS(ms_derivs, 0, i) = dd[0]; MS(ms_derivs, 1, i) = dd[1]; MS(ms_derivs, 2, i) = dd[2]; MS(ms_derivs, 3, i) = dd[3];
-  const double sn = v.ms_sin[i];
-  const double e0 = (MS(ms_found, 0, i) - pr.im[0]) * sn, e1 = (MS(ms_found, 1, i) - pr.im[1]) * sn;
+  const double e0 = (f0 - pr.im[0]) * sn, e1 = (f1 - pr.im[1]) * sn;
   MS(ms_eps, 0, i) = e0; MS(ms_eps, 1, i) = e1;
-  v.ms_err2[i] = e0 * e0 + e1 * e1;
+  e2 = e0 * e0 + e1 * e1;
+  v.ms_err2[i] = e2;
+  return MS_OK;
+}
+
+// Jacobians of one measurement from its stored state (jni/Bundle.cc:262-300): cm = v3Cam, d = sqrt-inv-noise * weight *
+// camera derivatives (2x2 row-major), R = rotation of the camera.  Same expressions wherever they are re-derived.
+// The loops over measurements are memory-latency bound (one workgroup per problem, 2 waves per SIMD): each thread
+// first loads the operands of BA_ILP (or 2) independent measurements unconditionally -- index clamped, no branch
+// between the loads -- and only then computes, so the round trips overlap.  Accumulation order is unchanged.
+struct MeasState { double cm[3], d[4]; int st; };
+DEVFN void ba_load_state(const BaView& v, int i, MeasState& m) {      // i < 0: loads measurement 0, state forced to erased
+  const int ic = i < 0 ? 0 : i;
+  m.st = v.ms_state[ic];
+  m.cm[0] = MS(ms_cam, 0, ic); m.cm[1] = MS(ms_cam, 1, ic); m.cm[2] = MS(ms_cam, 2, ic);
+  m.d[0] = MS(ms_derivs, 0, ic); m.d[1] = MS(ms_derivs, 1, ic); m.d[2] = MS(ms_derivs, 2, ic); m.d[3] = MS(ms_derivs, 3, ic);
+  if (i < 0) m.st = MS_ERASED;
+}
+DEVFN void ba_jac_A(const double cm[3], const double d[4], double A[12]) {
+  const double ooz = 1.0 / cm[2];
+  const double cc[3] = {cm[0], cm[1], cm[2]};
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    double f0, f1;
+    se3_generator_motion(k, cc, ooz, f0, f1);
+    A[k] = d[0] * f0 + d[1] * f1; A[6 + k] = d[2] * f0 + d[3] * f1;
+  }
+}
+DEVFN void ba_jac_B(const double* R, const double cm[3], const double d[4], double B[6]) {
+  const double ooz = 1.0 / cm[2];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const double m0 = R[k], m1 = R[3 + k], m2 = R[6 + k];
+    const double f0 = (m0 - cm[0] * m2 * ooz) * ooz, f1 = (m1 - cm[1] * m2 * ooz) * ooz;
+    B[k] = d[0] * f0 + d[1] * f1; B[3 + k] = d[2] * f0 + d[3] * f1;
+  }
+}
+// W = A^T B (6x3, :302) of measurement i in adjustable camera with rotation R
+DEVFN void ba_jac_W(const MeasState& m, const double* R, double W[18]) {
+  double A[12], B[6];
+  ba_jac_A(m.cm, m.d, A);
+  ba_jac_B(R, m.cm, m.d, B);
+#pragma unroll
+  for (int r = 0; r < 6; r++)
+#pragma unroll
+    for (int q = 0; q < 3; q++) W[r * 3 + q] = A[r] * B[q] + A[6 + r] * B[3 + q];
 }
 
 // Parallel in-place solve S x = E (n x n, row-major in global memory) by Gaussian elimination with partial
@@ -188,6 +237,240 @@ DEVFN bool ba_block_solve_lds(const double* S, double* E, int n, double* A, int*
   return true;
 }
 
+// pass 1 of Do_LM_Step (jni/Bundle.cc:209-215): project every measurement still in the list; returns this thread's
+// count of valid ones.  Kept out of line (like FindNewError below): the fp64 atan / division sequences of the camera model
+// get their own register allocation instead of inheriting the pressure of the Schur-complement tasks.
+__device__ __attribute__((noinline)) int ba_pass1_project(const BaView& v, const BaConfig& cfg, int nm) {
+  int nvalid = 0;
+  for (int i0 = threadIdx.x; i0 < nm; i0 += BA_ILP_PROJ * BA_THREADS) {
+    int st[BA_ILP_PROJ], mc[BA_ILP_PROJ], mp[BA_ILP_PROJ]; double f0[BA_ILP_PROJ], f1[BA_ILP_PROJ], sn[BA_ILP_PROJ];
+    _Pragma("unroll") for (int u = 0; u < BA_ILP_PROJ; u++) {
+      const int i = i0 + u * BA_THREADS, ic = i < nm ? i : nm - 1;
+      st[u] = v.ms_state[ic]; mc[u] = v.ms_c[ic]; mp[u] = v.ms_p[ic];
+      f0[u] = MS(ms_found, 0, ic); f1[u] = MS(ms_found, 1, ic); sn[u] = v.ms_sin[ic];
+    }
+    Pose T[BA_ILP_PROJ]; double X[BA_ILP_PROJ][3];
+    _Pragma("unroll") for (int u = 0; u < BA_ILP_PROJ; u++) {
+      T[u] = v.cam_pose[mc[u]];
+      _Pragma("unroll") for (int k = 0; k < 3; k++) X[u][k] = v.pt_pos[3 * mp[u] + k];
+    }
+    _Pragma("unroll") for (int u = 0; u < BA_ILP_PROJ; u++) {
+      const int i = i0 + u * BA_THREADS;
+      if (i >= nm) continue;
+      double e2 = __builtin_huge_val(), e2p;
+      if (st[u] != MS_ERASED && ba_project_meas(v, cfg, i, T[u], X[u], f0[u], f1[u], sn[u], e2p) == MS_OK) { e2 = e2p; nvalid++; }
+      v.scratch[i] = e2;
+    }
+  }
+  return nvalid;
+}
+
+// FindNewError (jni/Bundle.cc:537-561): this thread's share of the objective at the trial state.
+__device__ __attribute__((noinline)) double ba_find_new_error(const BaView& v, const BaConfig& cfg, int nm, double sigma2) {
+  double ne = 0.0;
+  for (int i0 = threadIdx.x; i0 < nm; i0 += BA_ILP_PROJ * BA_THREADS) {
+    int st[BA_ILP_PROJ], mc[BA_ILP_PROJ], mp[BA_ILP_PROJ]; double f0[BA_ILP_PROJ], f1[BA_ILP_PROJ], sn[BA_ILP_PROJ];
+    _Pragma("unroll") for (int u = 0; u < BA_ILP_PROJ; u++) {
+      const int i = i0 + u * BA_THREADS, ic = i < nm ? i : nm - 1;
+      st[u] = i < nm ? v.ms_state[ic] : MS_ERASED; mc[u] = v.ms_c[ic]; mp[u] = v.ms_p[ic];
+      f0[u] = MS(ms_found, 0, ic); f1[u] = MS(ms_found, 1, ic); sn[u] = v.ms_sin[ic];
+    }
+    Pose T[BA_ILP_PROJ]; double X[BA_ILP_PROJ][3];
+    _Pragma("unroll") for (int u = 0; u < BA_ILP_PROJ; u++) {
+      T[u] = v.cam_new[mc[u]];
+      _Pragma("unroll") for (int k = 0; k < 3; k++) X[u][k] = v.pt_new[3 * mp[u] + k];
+    }
+    _Pragma("unroll") for (int u = 0; u < BA_ILP_PROJ; u++) {
+      if (st[u] == MS_ERASED) continue;
+      double c[3];
+      pose_xform(T[u], X[u], c);
+      if (c[2] <= 0) { ne += 1.0; continue; }
+      const CamProj pr = cam_project(cfg.cam, c[0] / c[2], c[1] / c[2]);
+      const double e0 = (f0[u] - pr.im[0]) * sn[u], e1 = (f1[u] - pr.im[1]) * sn[u];
+      ne += tukey_objective(e0 * e0 + e1 * e1, sigma2);
+    }
+  }
+  return ne;
+}
+
+// V, epsilon_b (jni/Bundle.cc:49-56, :312-316).  Each phase below is its own function so that it gets its own register
+// allocation (see ba_pass1_project).
+__device__ __attribute__((noinline)) void ba_accum_V(const BaView& v, int nc, int np) {
+  // V, epsilon_b per point: one lane per point, cameras in id order
+  for (int p = threadIdx.x; p < np; p += BA_THREADS) {
+    double V[6] = {0, 0, 0, 0, 0, 0}, eb[3] = {0, 0, 0};
+    for (int c0 = 0; c0 < nc; c0 += BA_ILP) {
+      int ii[BA_ILP]; MeasState ms[BA_ILP]; double e[BA_ILP][2];
+      _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) ii[u] = c0 + u < nc ? v.lut[(size_t)(c0 + u) * v.max_pts + p] : -1;
+      _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) {
+        ba_load_state(v, ii[u], ms[u]);
+        const int ic = ii[u] < 0 ? 0 : ii[u];
+        e[u][0] = MS(ms_eps, 0, ic); e[u][1] = MS(ms_eps, 1, ic);
+      }
+      _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) {
+        if (ms[u].st != MS_OK) continue;
+        double B[6];
+        ba_jac_B(v.cam_pose[c0 + u].R, ms[u].cm, ms[u].d, B);
+        int q = 0;
+        _Pragma("unroll") for (int r = 0; r < 3; r++) for (int cc = 0; cc <= r; cc++) V[q++] += B[r] * B[cc] + B[3 + r] * B[3 + cc];   // :49-56 LL triangle
+        _Pragma("unroll") for (int r = 0; r < 3; r++) eb[r] += B[r] * e[u][0] + B[3 + r] * e[u][1];
+      }
+    }
+    // lower triangle of V: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) -> components 0..5
+    _Pragma("unroll") for (int k = 0; k < 6; k++) PT(pt_V, k, p) = V[k];
+    PT(pt_eb, 0, p) = eb[0]; PT(pt_eb, 1, p) = eb[1]; PT(pt_eb, 2, p) = eb[2];
+  }
+}
+
+__device__ __attribute__((noinline)) void ba_accum_U(const BaView& v, int nfree, int np) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // U, epsilon_a per adjustable camera: one wavefront per camera (segmented wave reduction)
+  for (int f = wave; f < nfree; f += BA_WAVES) {
+    const int j = v.free_cams[f];
+    double acc[27];
+    _Pragma("unroll") for (int k = 0; k < 27; k++) acc[k] = 0.0;
+    for (int p0 = lane; p0 < np; p0 += 64 * BA_ILP) {
+      int ii[BA_ILP]; MeasState ms[BA_ILP]; double e[BA_ILP][2];
+      _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) ii[u] = p0 + 64 * u < np ? v.lut[(size_t)j * v.max_pts + p0 + 64 * u] : -1;
+      _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) {
+        ba_load_state(v, ii[u], ms[u]);
+        const int ic = ii[u] < 0 ? 0 : ii[u];
+        e[u][0] = MS(ms_eps, 0, ic); e[u][1] = MS(ms_eps, 1, ic);
+      }
+      _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) {
+        if (ms[u].st != MS_OK) continue;
+        double A[12];
+        ba_jac_A(ms[u].cm, ms[u].d, A);
+        int q = 0;
+        _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) acc[q++] += A[r] * A[c] + A[6 + r] * A[6 + c];       // :40-47
+        _Pragma("unroll") for (int r = 0; r < 6; r++) acc[21 + r] += A[r] * e[u][0] + A[6 + r] * e[u][1];
+      }
+    }
+    _Pragma("unroll") for (int k = 0; k < 27; k++) acc[k] = ba_wave_sum(acc[k]);
+    if (lane == 0) {
+      double* U = v.cam_U + 36 * j;
+      int q = 0;
+      _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) U[r * 6 + c] = acc[q++];
+      _Pragma("unroll") for (int r = 0; r < 6; r++) v.cam_ea[6 * j + r] = acc[21 + r];
+    }
+  }
+}
+
+// S diagonal block + E of one adjustable camera (jni/Bundle.cc:362-396); called by one wavefront.
+__device__ __attribute__((noinline)) void ba_task_diag(const BaView& v, int task, int np, int nS, double lambda) {
+  const int lane = threadIdx.x & 63;
+  const int j = v.free_cams[task], row = v.cam_row[j];
+  double acc[27];
+  _Pragma("unroll") for (int k = 0; k < 27; k++) acc[k] = 0.0;
+  for (int p0 = lane; p0 < np; p0 += 64 * BA_ILP_S) {
+    int ii[BA_ILP_S]; MeasState ms[BA_ILP_S]; double Vi[BA_ILP_S][9], eb[BA_ILP_S][3];
+    _Pragma("unroll") for (int u = 0; u < BA_ILP_S; u++) ii[u] = p0 + 64 * u < np ? v.lut[(size_t)j * v.max_pts + p0 + 64 * u] : -1;
+    _Pragma("unroll") for (int u = 0; u < BA_ILP_S; u++) {
+      const int p = p0 + 64 * u < np ? p0 + 64 * u : np - 1;
+      ba_load_state(v, ii[u], ms[u]);
+      _Pragma("unroll") for (int k = 0; k < 9; k++) Vi[u][k] = PT(pt_Vinv, k, p);
+      _Pragma("unroll") for (int k = 0; k < 3; k++) eb[u][k] = PT(pt_eb, k, p);
+    }
+    _Pragma("unroll") for (int u = 0; u < BA_ILP_S; u++) {
+      if (ms[u].st != MS_OK) continue;
+      double W[18], Y[18];
+      ba_jac_W(ms[u], v.cam_pose[j].R, W);
+      _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c < 3; c++) Y[r * 3 + c] = W[r * 3] * Vi[u][c] + W[r * 3 + 1] * Vi[u][3 + c] + W[r * 3 + 2] * Vi[u][6 + c];
+      int q = 0;
+      _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) acc[q++] += Y[r * 3] * W[c * 3] + Y[r * 3 + 1] * W[c * 3 + 1] + Y[r * 3 + 2] * W[c * 3 + 2];
+      double ve[3];
+      _Pragma("unroll") for (int r = 0; r < 3; r++) ve[r] = Vi[u][r * 3] * eb[u][0] + Vi[u][r * 3 + 1] * eb[u][1] + Vi[u][r * 3 + 2] * eb[u][2];
+      _Pragma("unroll") for (int r = 0; r < 6; r++) acc[21 + r] += W[r * 3] * ve[0] + W[r * 3 + 1] * ve[1] + W[r * 3 + 2] * ve[2];
+    }
+  }
+  _Pragma("unroll") for (int k = 0; k < 27; k++) acc[k] = ba_wave_sum(acc[k]);
+  if (lane == 0) {
+    const double* U = v.cam_U + 36 * j;
+    int q = 0;
+    _Pragma("unroll") for (int r = 0; r < 6; r++)
+      for (int c = 0; c <= r; c++) {
+        double u = U[r * 6 + c];
+        if (r == c) u *= (1.0 + lambda);
+        const double val = u - acc[q++];
+        v.S[(size_t)(row + r) * nS + row + c] = val; v.S[(size_t)(row + c) * nS + row + r] = val;   // mirrored :431-434
+      }
+    _Pragma("unroll") for (int r = 0; r < 6; r++) v.E[row + r] = v.cam_ea[6 * j + r] - acc[21 + r];
+  }
+}
+
+// S off-diagonal block of one pair of adjustable cameras (:400-426); called by one wavefront.
+__device__ __attribute__((noinline)) void ba_task_pair(const BaView& v, int task, int np, int nS) {
+  const int lane = threadIdx.x & 63;
+  int t = task, fj = 1;
+  while (t >= fj) { t -= fj; fj++; }                         // pair (fj > fk): free-camera ordinals
+  const int fk = t;
+  const int j = v.free_cams[fj], k = v.free_cams[fk];
+  const int jrow = v.cam_row[j], krow = v.cam_row[k];
+  double acc[36];
+  _Pragma("unroll") for (int q = 0; q < 36; q++) acc[q] = 0.0;
+  for (int p0 = lane; p0 < np; p0 += 64 * BA_ILP_S) {
+    int ij[BA_ILP_S], ik[BA_ILP_S]; MeasState mj[BA_ILP_S], mk[BA_ILP_S]; double Vi[BA_ILP_S][9];
+    _Pragma("unroll") for (int u = 0; u < BA_ILP_S; u++) {
+      const bool in = p0 + 64 * u < np;
+      ij[u] = in ? v.lut[(size_t)j * v.max_pts + p0 + 64 * u] : -1;
+      ik[u] = in ? v.lut[(size_t)k * v.max_pts + p0 + 64 * u] : -1;
+    }
+    _Pragma("unroll") for (int u = 0; u < BA_ILP_S; u++) {
+      const int p = p0 + 64 * u < np ? p0 + 64 * u : np - 1;
+      ba_load_state(v, ij[u], mj[u]);
+      ba_load_state(v, ik[u], mk[u]);
+      _Pragma("unroll") for (int q = 0; q < 9; q++) Vi[u][q] = PT(pt_Vinv, q, p);
+    }
+    _Pragma("unroll") for (int u = 0; u < BA_ILP_S; u++) {
+      if (mj[u].st != MS_OK || mk[u].st != MS_OK) continue;
+      double Y[18];
+      {
+        double Wj[18];
+        ba_jac_W(mj[u], v.cam_pose[j].R, Wj);
+        _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c < 3; c++) Y[r * 3 + c] = Wj[r * 3] * Vi[u][c] + Wj[r * 3 + 1] * Vi[u][3 + c] + Wj[r * 3 + 2] * Vi[u][6 + c];
+      }
+      double Wk[18];
+      ba_jac_W(mk[u], v.cam_pose[k].R, Wk);
+      _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) acc[r * 6 + c] += Y[r * 3] * Wk[c * 3] + Y[r * 3 + 1] * Wk[c * 3 + 1] + Y[r * 3 + 2] * Wk[c * 3 + 2];
+    }
+  }
+  _Pragma("unroll") for (int q = 0; q < 36; q++) acc[q] = ba_wave_sum(acc[q]);
+  if (lane == 0)
+    _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) {
+      v.S[(size_t)(jrow + r) * nS + krow + c] = -acc[r * 6 + c];
+      v.S[(size_t)(krow + c) * nS + jrow + r] = -acc[r * 6 + c];
+    }
+}
+
+// map updates (jni/Bundle.cc:440-462, :484): trial point positions; returns this thread's share of |update|^2.
+__device__ __attribute__((noinline)) double ba_map_update(const BaView& v, int nfree, int np) {
+  double ssq = 0.0;
+  for (int p = threadIdx.x; p < np; p += BA_THREADS) {
+    double sum[3] = {0, 0, 0};
+    for (int f0 = 0; f0 < nfree; f0 += BA_ILP) {
+      int jj[BA_ILP]; MeasState ms[BA_ILP];
+      _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) jj[u] = v.free_cams[f0 + u < nfree ? f0 + u : nfree - 1];
+      _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) ba_load_state(v, f0 + u < nfree ? v.lut[(size_t)jj[u] * v.max_pts + p] : -1, ms[u]);
+      _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) {
+        if (ms[u].st != MS_OK) continue;
+        double W[18];
+        ba_jac_W(ms[u], v.cam_pose[jj[u]].R, W);
+        const double* cu = v.cam_up + v.cam_row[jj[u]];
+        _Pragma("unroll") for (int c = 0; c < 3; c++) { double s = 0; for (int r = 0; r < 6; r++) s += W[r * 3 + c] * cu[r]; sum[c] += s; }
+      }
+    }
+    const double eb[3] = {PT(pt_eb, 0, p), PT(pt_eb, 1, p), PT(pt_eb, 2, p)};
+    double Vi[9]; _Pragma("unroll") for (int k = 0; k < 9; k++) Vi[k] = PT(pt_Vinv, k, p);
+    const double x[3] = {eb[0] - sum[0], eb[1] - sum[1], eb[2] - sum[2]};
+    _Pragma("unroll") for (int r = 0; r < 3; r++) {
+      const double u = Vi[r * 3] * x[0] + Vi[r * 3 + 1] * x[1] + Vi[r * 3 + 2] * x[2];
+      ssq += u * u;
+      v.pt_new[3 * p + r] = v.pt_pos[3 * p + r] + u;               // :484
+    }
+  }
+  return ssq;
+}
+
 // Bundle::Compute.  Called by all BA_THREADS threads of one workgroup.
 DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
   __shared__ double red[BA_WAVES];
@@ -219,15 +502,7 @@ DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
   while (!sh_converged && !sh_hitmax && !sh_error) {             // :153 (no abort signal: the map-maker runs synchronously)
     // ================= Do_LM_Step =================
     // pass 1 (:209-215): project every measurement still in the list
-    int nvalid = 0;
-    for (int i = threadIdx.x; i < nm; i += BA_THREADS) {
-      double e2 = __builtin_huge_val();
-      if (v.ms_state[i] != MS_ERASED) {
-        ba_project_meas(v, cfg, i);
-        if (v.ms_state[i] == MS_OK) { e2 = v.ms_err2[i]; nvalid++; }
-      }
-      v.scratch[i] = e2;
-    }
+    int nvalid = ba_pass1_project(v, cfg, nm);
     nvalid = ba_block_sum_i(nvalid, ired);
     BA_STAMP(1);
     if (nvalid == 0) { if (threadIdx.x == 0) sh_error = 1; __syncthreads(); break; }
@@ -240,91 +515,35 @@ DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
     }
     const double sigma2 = sh_sigma2;
     BA_STAMP(2);
-    // pass 2 (:241-321): weights, A, B, W, objective
+    // pass 2 (:241-321): weights and objective; A, B, W are re-derived by their consumers
     double cur = 0.0;
-    for (int i = threadIdx.x; i < nm; i += BA_THREADS) {
-      const int stt = v.ms_state[i];
-      if (stt == MS_ERASED) continue;
-      if (stt == MS_BAD) { cur += 1.0; continue; }
-      const double dWeight = tukey_sqrt_weight(v.ms_err2[i], sigma2);
-      const double ew0 = MS(ms_eps, 0, i) * dWeight, ew1 = MS(ms_eps, 1, i) * dWeight;
-      MS(ms_eps, 0, i) = ew0; MS(ms_eps, 1, i) = ew1;
-      if (dWeight == 0) { v.ms_state[i] = MS_BAD; cur += 1.0; continue; }
-      cur += tukey_objective(v.ms_err2[i], sigma2);
-      const int c = v.ms_c[i];
-      const double dd[4] = {MS(ms_derivs, 0, i), MS(ms_derivs, 1, i), MS(ms_derivs, 2, i), MS(ms_derivs, 3, i)};
-      const double sn = v.ms_sin[i];
-      const double d0 = sn * (dWeight * dd[0]), d1 = sn * (dWeight * dd[1]), d2 = sn * (dWeight * dd[2]), d3 = sn * (dWeight * dd[3]);
-      const double cm[3] = {MS(ms_cam, 0, i), MS(ms_cam, 1, i), MS(ms_cam, 2, i)};
-      const double ooz = 1.0 / cm[2];
-      double A[12], B[6];
-      const bool fixed = v.cam_fixed[c] != 0;
-      if (fixed) { _Pragma("unroll") for (int k = 0; k < 12; k++) A[k] = 0.0; }
-      else {
-        const double cc[3] = {cm[0], cm[1], cm[2]};
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-          double f0, f1;
-          se3_generator_motion(k, cc, ooz, f0, f1);
-          A[k] = d0 * f0 + d1 * f1; A[6 + k] = d2 * f0 + d3 * f1;
-        }
+    for (int i0 = threadIdx.x; i0 < nm; i0 += BA_ILP * BA_THREADS) {   // BA_ILP measurements in flight per thread
+      int stt[BA_ILP]; double e2[BA_ILP], ep0[BA_ILP], ep1[BA_ILP], sn[BA_ILP], dd[BA_ILP][4];
+      _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) {
+        const int i = i0 + u * BA_THREADS, ic = i < nm ? i : nm - 1;   // unconditional loads: no branch between them
+        stt[u] = v.ms_state[ic];
+        e2[u] = v.ms_err2[ic]; ep0[u] = MS(ms_eps, 0, ic); ep1[u] = MS(ms_eps, 1, ic); sn[u] = v.ms_sin[ic];
+        _Pragma("unroll") for (int k = 0; k < 4; k++) dd[u][k] = MS(ms_derivs, k, ic);
+        if (i >= nm) stt[u] = MS_ERASED;
       }
-      const Pose& cp = v.cam_pose[c];
-      _Pragma("unroll") for (int k = 0; k < 3; k++) {
-        const double m0 = cp.R[k], m1 = cp.R[3 + k], m2 = cp.R[6 + k];
-        const double f0 = (m0 - cm[0] * m2 * ooz) * ooz, f1 = (m1 - cm[1] * m2 * ooz) * ooz;
-        B[k] = d0 * f0 + d1 * f1; B[3 + k] = d2 * f0 + d3 * f1;
+      _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) {
+        const int i = i0 + u * BA_THREADS;
+        if (stt[u] == MS_ERASED) continue;
+        if (stt[u] == MS_BAD) { cur += 1.0; continue; }
+        const double dWeight = tukey_sqrt_weight(e2[u], sigma2);
+        MS(ms_eps, 0, i) = ep0[u] * dWeight; MS(ms_eps, 1, i) = ep1[u] * dWeight;
+        if (dWeight == 0) { v.ms_state[i] = MS_BAD; cur += 1.0; continue; }
+        cur += tukey_objective(e2[u], sigma2);
+        _Pragma("unroll") for (int k = 0; k < 4; k++) MS(ms_derivs, k, i) = sn[u] * (dWeight * dd[u][k]);   // weighted from here on
       }
-      _Pragma("unroll") for (int k = 0; k < 12; k++) MS(ms_A, k, i) = A[k];
-      _Pragma("unroll") for (int k = 0; k < 6; k++) MS(ms_B, k, i) = B[k];
-      _Pragma("unroll") for (int r = 0; r < 6; r++) _Pragma("unroll") for (int q = 0; q < 3; q++)
-        MS(ms_W, r * 3 + q, i) = fixed ? 0.0 : A[r] * B[q] + A[6 + r] * B[3 + q];
     }
     cur = ba_block_sum(cur, red);
     if (threadIdx.x == 0) sh_cur_err = cur;
     __syncthreads();
     BA_STAMP(3);
-    // V, epsilon_b per point: one lane per point, cameras in id order
-    for (int p = threadIdx.x; p < np; p += BA_THREADS) {
-      double V[6] = {0, 0, 0, 0, 0, 0}, eb[3] = {0, 0, 0};
-      for (int c = 0; c < nc; c++) {
-        const int i = v.lut[(size_t)c * v.max_pts + p];
-        if (i < 0 || v.ms_state[i] != MS_OK) continue;
-        double B[6]; _Pragma("unroll") for (int k = 0; k < 6; k++) B[k] = MS(ms_B, k, i);
-        const double e[2] = {MS(ms_eps, 0, i), MS(ms_eps, 1, i)};
-        int q = 0;
-        _Pragma("unroll") for (int r = 0; r < 3; r++) for (int cc = 0; cc <= r; cc++) V[q++] += B[r] * B[cc] + B[3 + r] * B[3 + cc];   // :49-56 LL triangle
-        _Pragma("unroll") for (int r = 0; r < 3; r++) eb[r] += B[r] * e[0] + B[3 + r] * e[1];
-      }
-      // lower triangle of V: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) -> components 0..5
-      _Pragma("unroll") for (int k = 0; k < 6; k++) PT(pt_V, k, p) = V[k];
-      PT(pt_eb, 0, p) = eb[0]; PT(pt_eb, 1, p) = eb[1]; PT(pt_eb, 2, p) = eb[2];
-    }
+    ba_accum_V(v, nc, np);
     BA_STAMP(4);
-    // U, epsilon_a per adjustable camera: one wavefront per camera (segmented wave reduction)
-    for (int f = wave; f < nfree; f += BA_WAVES) {
-      const int j = v.free_cams[f];
-      double acc[27];
-      _Pragma("unroll") for (int k = 0; k < 27; k++) acc[k] = 0.0;
-      for (int p = lane; p < np; p += 64) {
-        const int i = v.lut[(size_t)j * v.max_pts + p];
-        if (i < 0 || v.ms_state[i] != MS_OK) continue;
-        double A[12]; _Pragma("unroll") for (int k = 0; k < 12; k++) A[k] = MS(ms_A, k, i);
-        const double e[2] = {MS(ms_eps, 0, i), MS(ms_eps, 1, i)};
-        int q = 0;
-        _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) acc[q++] += A[r] * A[c] + A[6 + r] * A[6 + c];       // :40-47
-        _Pragma("unroll") for (int r = 0; r < 6; r++) acc[21 + r] += A[r] * e[0] + A[6 + r] * e[1];
-      }
-      _Pragma("unroll") for (int k = 0; k < 27; k++) acc[k] = ba_wave_sum(acc[k]);
-      if (lane == 0) {
-        double* U = v.cam_U + 36 * j;
-        int q = 0;
-        _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) U[r * 6 + c] = acc[q++];
-        _Pragma("unroll") for (int r = 0; r < 6; r++) v.cam_ea[6 * j + r] = acc[21 + r];
-      }
-    }
-    __syncthreads();
-
+    ba_accum_U(v, nfree, np);
     __syncthreads();
     BA_STAMP(5);
     // ---- inner loop over lambda (:326-501) ----
@@ -348,62 +567,8 @@ DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
       // S: diagonal blocks + E (:362-396) and off-diagonal blocks (:400-426); one wavefront per block
       const int ntask = nfree + nfree * (nfree - 1) / 2;
       for (int task = wave; task < ntask; task += BA_WAVES) {
-        if (task < nfree) {
-          const int j = v.free_cams[task], row = v.cam_row[j];
-          double acc[27];
-          _Pragma("unroll") for (int k = 0; k < 27; k++) acc[k] = 0.0;
-          for (int p = lane; p < np; p += 64) {
-            const int i = v.lut[(size_t)j * v.max_pts + p];
-            if (i < 0 || v.ms_state[i] != MS_OK) continue;
-            double W[18], Vi[9]; _Pragma("unroll") for (int k = 0; k < 18; k++) W[k] = MS(ms_W, k, i);
-            _Pragma("unroll") for (int k = 0; k < 9; k++) Vi[k] = PT(pt_Vinv, k, p);
-            const double eb[3] = {PT(pt_eb, 0, p), PT(pt_eb, 1, p), PT(pt_eb, 2, p)};
-            double Y[18];
-            _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c < 3; c++) Y[r * 3 + c] = W[r * 3] * Vi[c] + W[r * 3 + 1] * Vi[3 + c] + W[r * 3 + 2] * Vi[6 + c];
-            int q = 0;
-            _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) acc[q++] += Y[r * 3] * W[c * 3] + Y[r * 3 + 1] * W[c * 3 + 1] + Y[r * 3 + 2] * W[c * 3 + 2];
-            double ve[3];
-            _Pragma("unroll") for (int r = 0; r < 3; r++) ve[r] = Vi[r * 3] * eb[0] + Vi[r * 3 + 1] * eb[1] + Vi[r * 3 + 2] * eb[2];
-            _Pragma("unroll") for (int r = 0; r < 6; r++) acc[21 + r] += W[r * 3] * ve[0] + W[r * 3 + 1] * ve[1] + W[r * 3 + 2] * ve[2];
-          }
-          _Pragma("unroll") for (int k = 0; k < 27; k++) acc[k] = ba_wave_sum(acc[k]);
-          if (lane == 0) {
-            const double* U = v.cam_U + 36 * j;
-            int q = 0;
-            _Pragma("unroll") for (int r = 0; r < 6; r++)
-              for (int c = 0; c <= r; c++) {
-                double u = U[r * 6 + c];
-                if (r == c) u *= (1.0 + lambda);
-                const double val = u - acc[q++];
-                v.S[(size_t)(row + r) * nS + row + c] = val; v.S[(size_t)(row + c) * nS + row + r] = val;   // mirrored :431-434
-              }
-            _Pragma("unroll") for (int r = 0; r < 6; r++) v.E[row + r] = v.cam_ea[6 * j + r] - acc[21 + r];
-          }
-        } else {
-          int t = task - nfree, fj = 1;
-          while (t >= fj) { t -= fj; fj++; }                         // pair (fj > fk): free-camera ordinals
-          const int fk = t;
-          const int j = v.free_cams[fj], k = v.free_cams[fk];
-          const int jrow = v.cam_row[j], krow = v.cam_row[k];
-          double acc[36];
-          _Pragma("unroll") for (int q = 0; q < 36; q++) acc[q] = 0.0;
-          for (int p = lane; p < np; p += 64) {
-            const int ij = v.lut[(size_t)j * v.max_pts + p], ik = v.lut[(size_t)k * v.max_pts + p];
-            if (ij < 0 || ik < 0 || v.ms_state[ij] != MS_OK || v.ms_state[ik] != MS_OK) continue;
-            double Wj[18], Wk[18], Vi[9];
-            _Pragma("unroll") for (int q = 0; q < 18; q++) { Wj[q] = MS(ms_W, q, ij); Wk[q] = MS(ms_W, q, ik); }
-            _Pragma("unroll") for (int q = 0; q < 9; q++) Vi[q] = PT(pt_Vinv, q, p);
-            double Y[18];
-            _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c < 3; c++) Y[r * 3 + c] = Wj[r * 3] * Vi[c] + Wj[r * 3 + 1] * Vi[3 + c] + Wj[r * 3 + 2] * Vi[6 + c];
-            _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) acc[r * 6 + c] += Y[r * 3] * Wk[c * 3] + Y[r * 3 + 1] * Wk[c * 3 + 1] + Y[r * 3 + 2] * Wk[c * 3 + 2];
-          }
-          _Pragma("unroll") for (int q = 0; q < 36; q++) acc[q] = ba_wave_sum(acc[q]);
-          if (lane == 0)
-            _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) {
-              v.S[(size_t)(jrow + r) * nS + krow + c] = -acc[r * 6 + c];
-              v.S[(size_t)(krow + c) * nS + jrow + r] = -acc[r * 6 + c];
-            }
-        }
+        if (task < nfree) ba_task_diag(v, task, np, nS, lambda);
+        else ba_task_pair(v, task - nfree, np, nS);
       }
       __syncthreads();
       BA_STAMP(7);
@@ -412,26 +577,7 @@ DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
       __syncthreads();
       BA_STAMP(8);
       // map updates (:440-462)
-      double ssq = 0.0;
-      for (int p = threadIdx.x; p < np; p += BA_THREADS) {
-        double sum[3] = {0, 0, 0};
-        for (int f = 0; f < nfree; f++) {
-          const int j = v.free_cams[f];
-          const int i = v.lut[(size_t)j * v.max_pts + p];
-          if (i < 0 || v.ms_state[i] != MS_OK) continue;
-          double W[18]; _Pragma("unroll") for (int k = 0; k < 18; k++) W[k] = MS(ms_W, k, i);
-          const double* cu = v.cam_up + v.cam_row[j];
-          _Pragma("unroll") for (int c = 0; c < 3; c++) { double s = 0; for (int r = 0; r < 6; r++) s += W[r * 3 + c] * cu[r]; sum[c] += s; }
-        }
-        const double eb[3] = {PT(pt_eb, 0, p), PT(pt_eb, 1, p), PT(pt_eb, 2, p)};
-        double Vi[9]; _Pragma("unroll") for (int k = 0; k < 9; k++) Vi[k] = PT(pt_Vinv, k, p);
-        const double x[3] = {eb[0] - sum[0], eb[1] - sum[1], eb[2] - sum[2]};
-        _Pragma("unroll") for (int r = 0; r < 3; r++) {
-          const double u = Vi[r * 3] * x[0] + Vi[r * 3 + 1] * x[1] + Vi[r * 3 + 2] * x[2];
-          ssq += u * u;
-          v.pt_new[3 * p + r] = v.pt_pos[3 * p + r] + u;               // :484
-        }
-      }
+      double ssq = ba_map_update(v, nfree, np);
       for (int t = threadIdx.x; t < nS; t += BA_THREADS) ssq += v.cam_up[t] * v.cam_up[t];
       ssq = ba_block_sum(ssq, red);                                    // :467-470
       for (int j = threadIdx.x; j < nc; j += BA_THREADS) {             // :476-482
@@ -441,17 +587,7 @@ DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
       __syncthreads();
       BA_STAMP(9);
       // FindNewError (:537-561)
-      double ne = 0.0;
-      for (int i = threadIdx.x; i < nm; i += BA_THREADS) {
-        if (v.ms_state[i] == MS_ERASED) continue;
-        double c[3];
-        pose_xform(v.cam_new[v.ms_c[i]], v.pt_new + 3 * v.ms_p[i], c);
-        if (c[2] <= 0) { ne += 1.0; continue; }
-        const CamProj pr = cam_project(cfg.cam, c[0] / c[2], c[1] / c[2]);
-        const double sn = v.ms_sin[i];
-        const double e0 = (MS(ms_found, 0, i) - pr.im[0]) * sn, e1 = (MS(ms_found, 1, i) - pr.im[1]) * sn;
-        ne += tukey_objective(e0 * e0 + e1 * e1, sigma2);
-      }
+      double ne = ba_find_new_error(v, cfg, nm, sigma2);
       ne = ba_block_sum(ne, red);
       BA_STAMP(10);
       if (threadIdx.x == 0) {

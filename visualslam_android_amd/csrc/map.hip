@@ -1,5 +1,6 @@
 // Map upload, per-frame entry points (Tracker::TrackFrame / JNI-equivalent update) and read-back of the C ABI.
 #include "vslam_internal.h"
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -203,8 +204,12 @@ int map_init_states(vslam_system* sys) {
 // ---- per-frame entry points -------------------------------------------------------------------------------------
 extern "C" int vslam_track_frame(vslam_system* sys, const uint8_t* gray, size_t row_stride, size_t stream_stride, int on_device) {
   if (!sys) return VSLAM_E_INVALID;
+  // VSLAM_PROFILE_SERIAL=1 (diagnostic): no overlap between the front-end, tracking and map-maker streams, so the
+  // per-stage HIP-event times are those of each kernel running alone on the device.
+  static const bool serial = getenv("VSLAM_PROFILE_SERIAL") != nullptr;
   int r = fe_make_keyframe_lite(sys, gray, row_stride, stream_stride, on_device);   // jni/Tracker.cc:85
   if (r) return r;
+  if (serial) HIPCHK(hipStreamSynchronize(sys->fe_stream));
   r = ba_frame_start(sys);                                                           // deferred map-maker results that are due now
   if (r) return r;
   r = trk_track_map(sys);                                                            // :103-124
@@ -214,6 +219,7 @@ extern "C" int vslam_track_frame(vslam_system* sys, const uint8_t* gray, size_t 
   if (sys->prof_on && sys->prof_frame < sys->prof_cap) sys->prof_frame++;
   if (!r) HIPCHK(hipEventRecord(sys->ev_track_done[sys->fr_idx], sys->stream));   // the front-end may now reuse this buffer
   sys->frame_no++;
+  if (serial && !r) { HIPCHK(hipStreamSynchronize(sys->stream)); if (sys->ba_stream) HIPCHK(hipStreamSynchronize(sys->ba_stream)); }
   return r;
 }
 
