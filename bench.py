@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector (= fp64 matrix) peak, AMD product brief; the guide lists no fp64 figure: 256 CUs x 128 FMA/clk x 2.4 GHz
 
 
 def dist_env():
@@ -63,6 +64,13 @@ def algorithmic_bytes(stage, S, W, H, P, per_stream):
     return S * table.get(stage, 0.0)
 
 
+def ba_flops(per_stream):
+    """SURVEY.md 8(d) fp64 flops of ONE k_ba_compute launch per stream: F_ba = M*780 + sum_pts C(n_free,2)*216 + (6n)^3/3 per trial."""
+    n = per_stream["ba_free"]
+    per_trial = per_stream["ba_meas"] * 780.0 + per_stream["ba_pts"] * (n * (n - 1) / 2.0) * 216.0 + (6.0 * n) ** 3 / 3.0
+    return per_stream["ba_trials_per_launch"] * per_trial
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,7 +83,7 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--patch", type=int, default=8, help="PatchFinder template side (BASELINE configs: 8; reference default 11)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
-    ap.add_argument("--ba-delay", type=int, default=int(os.environ.get("VSLAM_BENCH_BA_DELAY", 0)),
+    ap.add_argument("--ba-delay", type=int, default=int(os.environ.get("VSLAM_BENCH_BA_DELAY", 12)),
                     help="vslam_params.ba_delay_frames: 0 = synchronous map-maker; D > 0 = Bundle::Compute on its own HIP stream, applied D frames later")
     ap.add_argument("--no-events", action="store_true", help="skip the per-stage HIP events in the timed region")
     args = ap.parse_args()
@@ -183,10 +191,9 @@ def main():
     ba_trials = float(np.mean([b.n_ba_trials - a.n_ba_trials for a, b in zip(st0, st1)]))
     good = int(sum(1 for b in st1 if b.quality == 2))
     ncorn = float(len(systems[0].read_corners(0, 0)))
-    km = systems[0].keyframe_meas(0, st1[0].n_keyframes - 1)
-    ba_meas = float(len(km["pt"])) * 5 + 0.0
-    per_stream = {"corners": ncorn, "patches": att, "zmssd": zm, "found": fnd, "ba_meas": ba_meas, "ba_cams": 5.0,
-                  "ba_pts": float(len(km["pt"])), "ba_trials_per_launch": ba_trials / K}
+    bs = systems[0].bundle_stats(0)           # sizes of the last bundle-adjustment problem of stream 0 (all streams alike)
+    per_stream = {"corners": ncorn, "patches": att, "zmssd": zm, "found": fnd, "ba_meas": float(bs["meas"]), "ba_cams": float(bs["cams"]),
+                  "ba_free": float(bs["free_cams"]), "ba_pts": float(bs["points"]), "ba_trials_per_launch": ba_trials / K}
 
     total_t, gathered = aggregate(elapsed, [elapsed, S * K, zm, att, fnd, kf_adds, ba_trials, good], world)
     frames_total = sum(g[1] for g in gathered)
@@ -207,6 +214,10 @@ def main():
             ach = algorithmic_bytes(dom, Sk, W, H, args.patch, per_stream) / (dms * 1e-3) / 1e9
             roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None, "ms_per_launch": round(dms, 5)}
+            if dom == "ba_compute":             # supplementary: the same launch against the fp64 vector/matrix peak (78.6 TFLOP/s)
+                tf = Sk * ba_flops(per_stream) / (dms * 1e-3) / 1e12
+                roof["fp64"] = {"achieved": round(tf, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP64_PEAK_TFLOPS, 5)}
+            roof["problem"] = {k: per_stream[k] for k in ("ba_cams", "ba_free", "ba_pts", "ba_meas", "ba_trials_per_launch")}
         # ---- CPU baseline: the oracle's TrackFrame + BA on one core over a bounded sample of the same frames -------------
         from oracle import binding as orc
         o = orc.OracleSystem(orc.params_from_vslam(vpk))

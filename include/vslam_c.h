@@ -178,6 +178,9 @@ int vslam_get_keyframe_measurements(vslam_system* sys, int stream, int keyframe,
                                     double* root_pos, int* source, int cap);
 int vslam_get_template(vslam_system* sys, int stream, int point, uint8_t* tmpl /* P*P */, int* sum, int* sumsq,
                        int* bad);
+/* Size of the last bundle-adjustment problem MapMaker::BundleAdjust (jni/MapMaker.cc:854-960) assembled for the stream:
+ * out[0..5] = cameras, adjustable cameras, points, measurements added, LM trials (mnCounter), accepted steps. */
+int vslam_get_bundle_stats(vslam_system* sys, int stream, int out[6]);
 
 /* ---- measurement: HIP-event time per stage of vslam_track_frame, on the system's own stream ---- */
 #define VSLAM_N_STAGES 14

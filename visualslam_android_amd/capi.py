@@ -81,6 +81,7 @@ SYMBOLS = {
     "vslam_get_point_tracks": (_i, [_sys, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "vslam_get_points": (_i, [_sys, _i, _vp, _vp, _vp, _vp, _i]),
     "vslam_get_keyframe_pose": (_i, [_sys, _i, _i, _vp]),
+    "vslam_get_bundle_stats": (_i, [_sys, _i, _vp]),
     "vslam_get_keyframe_measurements": (_i, [_sys, _i, _i, _vp, _vp, _vp, _vp, _i]),
     "vslam_get_template": (_i, [_sys, _i, _i, _vp, _ip, _ip, _ip]),
     "vslam_stage_name": (C.c_char_p, [_i]),
@@ -304,6 +305,12 @@ class System:
         pos = np.zeros((n, 3)); bad, nin, nout = (np.zeros(n, np.int32) for _ in range(3))
         _check(self.lib.vslam_get_points(self.h, stream, pos.ctypes.data, bad.ctypes.data, nin.ctypes.data, nout.ctypes.data, n))
         return {"pos": pos, "bad": bad, "n_in": nin, "n_out": nout}
+
+    def bundle_stats(self, stream):
+        """Sizes of the last assembled bundle-adjustment problem of the stream."""
+        o = np.zeros(6, np.int32)
+        _check(self.lib.vslam_get_bundle_stats(self.h, stream, o.ctypes.data))
+        return dict(zip(("cams", "free_cams", "points", "meas", "trials", "accepted"), (int(x) for x in o)))
 
     def keyframe_pose(self, stream, kf):
         p = np.zeros(12)

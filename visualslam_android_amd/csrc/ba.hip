@@ -574,6 +574,17 @@ int ba_run(vslam_system* sys, int mode) {
 
 int ba_add_keyframe_and_adjust(vslam_system* sys) { return ba_run(sys, 0); }
 
+extern "C" int vslam_get_bundle_stats(vslam_system* sys, int s, int out[6]) {
+  if (!sys || !out || s < 0 || s >= sys->S || !sys->ba_ws) { vslam_set_error("get_bundle_stats: bad argument"); return VSLAM_E_INVALID; }
+  BaSystemWs* ws = (BaSystemWs*)sys->ba_ws;
+  HIPCHK(hipStreamSynchronize(sys->stream));
+  if (sys->ba_stream) HIPCHK(hipStreamSynchronize(sys->ba_stream));
+  BaResult r;
+  HIPCHK(hipMemcpy(&r, ws->pool.res + s, sizeof(r), hipMemcpyDeviceToHost));
+  out[0] = r.n_cams; out[1] = r.n_free; out[2] = r.n_pts; out[3] = r.n_meas; out[4] = r.counter; out[5] = r.accepted;
+  return VSLAM_OK;
+}
+
 #ifdef VSLAM_BA_PROF
 extern "C" int vslam_debug_ba_prof(unsigned long long* out32, int reset) {
   HIPCHK(hipDeviceSynchronize());
