@@ -64,6 +64,25 @@ def algorithmic_bytes(stage, S, W, H, P, per_stream):
     return S * table.get(stage, 0.0)
 
 
+def pmc_traffic(kernel, cfg):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*traffic.json), or None.
+
+    bench.py cannot run rocprofv3 on itself; the counters were collected with this same command and configuration
+    (FETCH_SIZE and WRITE_SIZE in separate --pmc passes, kilobytes; FETCH_SIZE doubled as the MI355X guide prescribes for gfx950).
+    """
+    import glob
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*traffic.json")), reverse=True):
+        try:
+            with open(f) as fh:
+                t = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if t.get("kernel") == kernel and all(cfg.get(k) == v for k, v in t.get("config", {}).items()):
+            return {"bytes_per_launch": round((2.0 * t["fetch_size_kb_per_launch"] + t["write_size_kb_per_launch"]) * 1024.0),
+                    "source": os.path.relpath(f, os.path.dirname(os.path.abspath(__file__)))}
+    return None
+
+
 def ba_flops(per_stream):
     """SURVEY.md 8(d) fp64 flops of ONE k_ba_compute launch per stream: F_ba = M*780 + sum_pts C(n_free,2)*216 + (6n)^3/3 per trial."""
     n = per_stream["ba_free"]
@@ -217,6 +236,10 @@ def main():
             if dom == "ba_compute":             # supplementary: the same launch against the fp64 vector/matrix peak (78.6 TFLOP/s)
                 tf = Sk * ba_flops(per_stream) / (dms * 1e-3) / 1e12
                 roof["fp64"] = {"achieved": round(tf, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP64_PEAK_TFLOPS, 5)}
+            tr = pmc_traffic(dom, {"streams_per_gpu": S, "patch_size": args.patch, "ba_delay_frames": args.ba_delay, "width": W, "height": H})
+            if tr:
+                roof["traffic"] = tr["bytes_per_launch"]; roof["traffic_source"] = tr["source"]
+                roof["algorithmic_bytes"] = round(algorithmic_bytes(dom, Sk, W, H, args.patch, per_stream))
             roof["problem"] = {k: per_stream[k] for k in ("ba_cams", "ba_free", "ba_pts", "ba_meas", "ba_trials_per_launch")}
         # ---- CPU baseline: the oracle's TrackFrame + BA on one core over a bounded sample of the same frames -------------
         from oracle import binding as orc
