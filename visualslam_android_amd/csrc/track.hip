@@ -499,17 +499,15 @@ __global__ __launch_bounds__(64) void k_search8(MapDev m, TrackParams tp, Search
     const double across[2] = {m2[0], m2[2]}, down[2] = {m2[1], m2[3]};
     double px = (double)p.irx - (m2[0] * HALF + m2[1] * HALF), py = (double)p.iry - (m2[2] * HALF + m2[3] * HALF);
     const double cr[2] = {down[0] - PS * across[0], down[1] - PS * across[1]};
-    double rx[PS], ry[PS];
-#pragma unroll
-    for (int j = 0; j < PS; j++) { rx[j] = 0; ry[j] = 0; }
+    // every lane walks the accumulated sample position through the rows above its own (PS steps + the carriage return
+    // each, exactly the additions transform_image makes), then samples its row while stepping along it
 #pragma unroll 1
-    for (int i = 0; i < PS; i++) {
+    for (int i = 0; i < PS - 1; i++) {
+      if (i < sub) {
 #pragma unroll
-      for (int j = 0; j < PS; j++) {
-        if (i == sub) { rx[j] = px; ry[j] = py; }
-        px += across[0]; py += across[1];
+        for (int j = 0; j < PS; j++) { px += across[0]; py += across[1]; }
+        px += cr[0]; py += cr[1];
       }
-      px += cr[0]; py += cr[1];
     }
     if (refresh) {
       int nOutside = 0, sum = 0, sumsq = 0;
@@ -517,7 +515,8 @@ __global__ __launch_bounds__(64) void k_search8(MapDev m, TrackParams tp, Search
       unsigned w0 = 0, w1 = 0;
 #pragma unroll
       for (int j = 0; j < PS; j++) {
-        double x = rx[j], y = ry[j];
+        double x = px, y = py;
+        px += across[0]; py += across[1];
         int v = 0;
         if (0 <= x && 0 <= y && x < x_bound && y < y_bound) {
           const int lx = (int)x, ly = (int)y;                        // sample(), ImageHandler.cpp:12-19
@@ -623,76 +622,103 @@ __global__ __launch_bounds__(64) void k_search8(MapDev m, TrackParams tp, Search
   const uint32_t bc = found ? corners[bestIdx] : 0u;
   const double coarse[2] = {level_zero_pos((double)(bc & 0xFFFF), level), level_zero_pos((double)(bc >> 16), level)};
   if (found) flags |= TDF_FOUND;
-  const bool dosub = found && nSubPixIts > 0;
-  if (found && !dosub) {                                             // :668-671
-    flags &= ~TDF_SUBPIX;
+  const bool dosub = found && nSubPixIts > 0;                        // refined by k_subpix8, which also counts it as found
+  if (found) {                                                       // :668-671
+    flags = dosub ? (flags | TDF_SUBPIX) : (flags & ~TDF_SUBPIX);
     if (lead) { td.flags = flags; td.sqrt_inv_noise = 1.0 / scale; td.vfound[0] = coarse[0]; td.vfound[1] = coarse[1]; }
   }
-  if (__any(dosub)) {
-    // ---- MakeSubPixTemplate (:242-271) + IterateSubPixToConvergence (:273-350): lane y owns interior row y ----
-    const bool rowok = sub >= 1 && sub <= 6;
-    const uint2 rup = make_uint2(__shfl(trow.x, lane - 1), __shfl(trow.y, lane - 1));
-    const uint2 rdn = make_uint2(__shfl(trow.x, lane + 1), __shfl(trow.y, lane + 1));
-    double gx[6], gy[6];
-    double h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0;
+  for (int l = 0; l < NLEV; l++) {                                   // manMeasFound[level]++ (:652)
+    const int c = __popcll(__ballot(found && !dosub && lead && level == l));
+    if (lane == 0 && c) atomicAdd(&st->found[l], c);
+  }
+}
+
+// MakeSubPixTemplate (jni/PatchFinder.cc:242-271) + IterateSubPixToConvergence (:273-350) for the patches k_search8 found
+// with a sub-pixel budget (level-3 points in the fine stage, every point in the coarse stage).  A kernel of its own so
+// that its registers (gradients, 3x3 inverse) do not halve the occupancy of the search proper.  Eight patches per
+// wavefront, lane y owns interior row y of the 8x8 template.
+__global__ __launch_bounds__(64) void k_subpix8(MapDev m, TrackParams tp, SearchArgs a, int stage) {
+  constexpr int PS = 8, HALF = 4;
+  const int s = blockIdx.y;
+  TrackerState* st = &m.st[s];
+  if (!(st->map_good && st->lost_frames < 3)) return;
+  const int nsub = stage == 0 ? st->n_search : st->n_l3;             // entries that carry a sub-pixel budget
+  if ((int)blockIdx.x * 8 >= nsub) return;
+  const int lane = threadIdx.x, grp = lane >> 3, sub = lane & 7;
+  const int e = blockIdx.x * 8 + grp;
+  const bool lead = sub == 0;
+  const int2 ent = e < nsub ? m.search_list[(size_t)s * tp.max_points + e] : make_int2(0, 0);
+  const int idx = ent.x, nSubPixIts = ent.y;
+  TrackData& td = m.td[(size_t)s * tp.max_points + idx];
+  int flags = td.flags;
+  const bool dosub = e < nsub && nSubPixIts > 0 && (flags & TDF_FOUND) && (flags & TDF_SUBPIX);
+  if (!__any(dosub)) return;
+  const int level = dosub ? td.level : 0, scale = 1 << level;
+  const int rows = a.h[level], cols = a.w[level];
+  const uint8_t* img = a.img[level] + (size_t)s * a.img_sstride[level];
+  const int ip = a.img_pitch[level];
+  const uint2 trow = *(const uint2*)(m.tmpl + ((size_t)s * tp.max_points + idx) * TMPL_PITCH + sub * PS);
+  const bool rowok = sub >= 1 && sub <= 6;
+  const uint2 rup = make_uint2(__shfl(trow.x, lane - 1), __shfl(trow.y, lane - 1));
+  const uint2 rdn = make_uint2(__shfl(trow.x, lane + 1), __shfl(trow.y, lane + 1));
+  double gx[6], gy[6];
+  double h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0;
 #pragma unroll
-    for (int x = 1; x <= 6; x++) {
-      gx[x - 1] = 0; gy[x - 1] = 0;
-      if (rowok) {
-        gx[x - 1] = 0.5 * (row_byte(trow, x + 1) - row_byte(trow, x - 1));
-        gy[x - 1] = 0.5 * (row_byte(rdn, x) - row_byte(rup, x));
-        h00 += gx[x - 1] * gx[x - 1]; h01 += gx[x - 1] * gy[x - 1]; h02 += gx[x - 1];
-        h11 += gy[x - 1] * gy[x - 1]; h12 += gy[x - 1]; h22 += 1.0;
-      }
-    }
-    h00 = grp_sum_d(h00); h01 = grp_sum_d(h01); h02 = grp_sum_d(h02);     // quarter-integers: exact in any order
-    h11 = grp_sum_d(h11); h12 = grp_sum_d(h12); h22 = grp_sum_d(h22);
-    const double H[9] = {h00, h01, h02, h01, h11, h12, h02, h12, h22};
-    double Hinv[9];
-    inv3(H, Hinv);
-    double sub0 = coarse[0], sub1 = coarse[1], meanDiff = 0.0;
-    bool running = dosub, converged = false;
-    for (int it = 0; __any(running); it++) {
-      if (it >= nSubPixIts) running = false;
-      double cx = 0, cy = 0;
-      if (running) {
-        cx = level_n_pos(sub0, level); cy = level_n_pos(sub1, level);
-        const int xb = (int)(cx > 0.0 ? cx + 0.5 : cx - 0.5), yb = (int)(cy > 0.0 ? cy + 0.5 : cy - 0.5);
-        const int b = HALF + 1;
-        if (!(xb >= b && yb >= b && xb < cols - b && yb < rows - b)) running = false;   // went off edge -> fail
-      }
-      double a0 = 0, a1 = 0, a2 = 0;
-      if (running && rowok) {
-        const double bx = cx - HALF, by = cy - HALF;
-        const double dX = bx - floor(bx), dY = by - floor(by);
-        const float fTL = (float)((1.0 - dX) * (1.0 - dY)), fTR = (float)((dX) * (1.0 - dY));
-        const float fBL = (float)((1.0 - dX) * (dY)), fBR = (float)((dX) * (dY));
-        const uint8_t* r0 = img + (size_t)((int)by + sub) * ip + (int)bx + 1;
-        const uint2 p0 = load_row8(r0), p1 = load_row8(r0 + ip);
-#pragma unroll
-        for (int x = 1; x <= 6; x++) {
-          const float fPixel = fTL * row_byte(p0, x - 1) + fTR * row_byte(p0, x) + fBL * row_byte(p1, x - 1) + fBR * row_byte(p1, x);
-          const double dDiff = (fPixel - (float)row_byte(trow, x)) + meanDiff;
-          a0 += dDiff * gx[x - 1]; a1 += dDiff * gy[x - 1]; a2 += dDiff;
-        }
-      }
-      a0 = grp_sum_d(a0); a1 = grp_sum_d(a1); a2 = grp_sum_d(a2);
-      if (running) {
-        const double u0 = Hinv[0] * a0 + Hinv[1] * a1 + Hinv[2] * a2;
-        const double u1 = Hinv[3] * a0 + Hinv[4] * a1 + Hinv[5] * a2;
-        const double u2 = Hinv[6] * a0 + Hinv[7] * a1 + Hinv[8] * a2;
-        sub0 -= u0 * scale; sub1 -= u1 * scale; meanDiff -= u2;
-        if (u0 * u0 + u1 * u1 < 0.03 * 0.03) { converged = true; running = false; }
-      }
-    }
-    if (dosub) {
-      flags |= TDF_SUBPIX;
-      if (!converged) { found = false; if (lead) td.flags = flags & ~TDF_FOUND; }   // :658-666 un-finds the point
-      else if (lead) { td.flags = flags; td.sqrt_inv_noise = 1.0 / scale; td.vfound[0] = sub0; td.vfound[1] = sub1; }
+  for (int x = 1; x <= 6; x++) {
+    gx[x - 1] = 0; gy[x - 1] = 0;
+    if (rowok) {
+      gx[x - 1] = 0.5 * (row_byte(trow, x + 1) - row_byte(trow, x - 1));
+      gy[x - 1] = 0.5 * (row_byte(rdn, x) - row_byte(rup, x));
+      h00 += gx[x - 1] * gx[x - 1]; h01 += gx[x - 1] * gy[x - 1]; h02 += gx[x - 1];
+      h11 += gy[x - 1] * gy[x - 1]; h12 += gy[x - 1]; h22 += 1.0;
     }
   }
+  h00 = grp_sum_d(h00); h01 = grp_sum_d(h01); h02 = grp_sum_d(h02);     // quarter-integers: exact in any order
+  h11 = grp_sum_d(h11); h12 = grp_sum_d(h12); h22 = grp_sum_d(h22);
+  const double H[9] = {h00, h01, h02, h01, h11, h12, h02, h12, h22};
+  double Hinv[9];
+  inv3(H, Hinv);
+  double sub0 = td.vfound[0], sub1 = td.vfound[1], meanDiff = 0.0;      // the coarse position k_search8 left
+  bool running = dosub, converged = false;
+  for (int it = 0; __any(running); it++) {
+    if (it >= nSubPixIts) running = false;
+    double cx = 0, cy = 0;
+    if (running) {
+      cx = level_n_pos(sub0, level); cy = level_n_pos(sub1, level);
+      const int xb = (int)(cx > 0.0 ? cx + 0.5 : cx - 0.5), yb = (int)(cy > 0.0 ? cy + 0.5 : cy - 0.5);
+      const int b = HALF + 1;
+      if (!(xb >= b && yb >= b && xb < cols - b && yb < rows - b)) running = false;   // went off edge -> fail
+    }
+    double a0 = 0, a1 = 0, a2 = 0;
+    if (running && rowok) {
+      const double bx = cx - HALF, by = cy - HALF;
+      const double dX = bx - floor(bx), dY = by - floor(by);
+      const float fTL = (float)((1.0 - dX) * (1.0 - dY)), fTR = (float)((dX) * (1.0 - dY));
+      const float fBL = (float)((1.0 - dX) * (dY)), fBR = (float)((dX) * (dY));
+      const uint8_t* r0 = img + (size_t)((int)by + sub) * ip + (int)bx + 1;
+      const uint2 p0 = load_row8(r0), p1 = load_row8(r0 + ip);
+#pragma unroll
+      for (int x = 1; x <= 6; x++) {
+        const float fPixel = fTL * row_byte(p0, x - 1) + fTR * row_byte(p0, x) + fBL * row_byte(p1, x - 1) + fBR * row_byte(p1, x);
+        const double dDiff = (fPixel - (float)row_byte(trow, x)) + meanDiff;
+        a0 += dDiff * gx[x - 1]; a1 += dDiff * gy[x - 1]; a2 += dDiff;
+      }
+    }
+    a0 = grp_sum_d(a0); a1 = grp_sum_d(a1); a2 = grp_sum_d(a2);
+    if (running) {
+      const double u0 = Hinv[0] * a0 + Hinv[1] * a1 + Hinv[2] * a2;
+      const double u1 = Hinv[3] * a0 + Hinv[4] * a1 + Hinv[5] * a2;
+      const double u2 = Hinv[6] * a0 + Hinv[7] * a1 + Hinv[8] * a2;
+      sub0 -= u0 * scale; sub1 -= u1 * scale; meanDiff -= u2;
+      if (u0 * u0 + u1 * u1 < 0.03 * 0.03) { converged = true; running = false; }
+    }
+  }
+  if (dosub && lead) {
+    if (!converged) td.flags = flags & ~TDF_FOUND;                   // :658-666 un-finds the point
+    else { td.vfound[0] = sub0; td.vfound[1] = sub1; }
+  }
   for (int l = 0; l < NLEV; l++) {                                   // manMeasFound[level]++ (:652)
-    const int c = __popcll(__ballot(found && lead && level == l));
+    const int c = __popcll(__ballot(dosub && converged && lead && level == l));
     if (lane == 0 && c) atomicAdd(&st->found[l], c);
   }
 }
@@ -1045,7 +1071,10 @@ int trk_track_map(vslam_system* sys) {
   prof_mark(sys, 5);
   if (!tp.coarse_disabled) {
     const int nc = 2 * tp.coarse_max;
-    if (tp.P == 8) hipLaunchKernelGGL(k_search8, dim3((nc + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 0);
+    if (tp.P == 8) {
+      hipLaunchKernelGGL(k_search8, dim3((nc + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 0);
+      if (tp.coarse_subpix_its > 0) hipLaunchKernelGGL(k_subpix8, dim3((nc + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 0);
+    }
     else hipLaunchKernelGGL(k_search<11>, dim3(nc, S), dim3(64), 0, sys->stream, m, tp, a, 0);
     prof_mark(sys, 6);
     hipLaunchKernelGGL(k_pose, dim3(S), dim3(POSE_THREADS), 0, sys->stream, m, tp, 0);
@@ -1053,7 +1082,10 @@ int trk_track_map(vslam_system* sys) {
   prof_mark(sys, 7);
   hipLaunchKernelGGL(k_plan, dim3(S), dim3(TRK_THREADS), 0, sys->stream, m, tp, 1);
   prof_mark(sys, 8);
-  if (tp.P == 8) hipLaunchKernelGGL(k_search8, dim3((maxSearch + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 1);
+  if (tp.P == 8) {
+    hipLaunchKernelGGL(k_search8, dim3((maxSearch + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 1);
+    if (tp.fine_subpix_its > 0) hipLaunchKernelGGL(k_subpix8, dim3((maxSearch + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 1);
+  }
   else hipLaunchKernelGGL(k_search<11>, dim3(maxSearch, S), dim3(64), 0, sys->stream, m, tp, a, 1);
   prof_mark(sys, 9);
   hipLaunchKernelGGL(k_pose, dim3(S), dim3(POSE_THREADS), 0, sys->stream, m, tp, 1);
