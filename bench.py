@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("VSLAM_BENCH_STREAMS", 256)), help="sequences per GPU")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("VSLAM_BENCH_STREAMS", 512)), help="sequences per GPU")
     ap.add_argument("--systems", type=int, default=int(os.environ.get("VSLAM_BENCH_SYSTEMS", 1)),
                     help="split the streams over this many vslam_system handles (one HIP stream each) so their kernels overlap")
     ap.add_argument("--width", type=int, default=640)

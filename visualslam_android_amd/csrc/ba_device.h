@@ -475,8 +475,8 @@ __device__ __attribute__((noinline)) double ba_map_update(const BaView& v, int n
 DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
   __shared__ double red[BA_WAVES];
   __shared__ int ired[BA_WAVES];
-  __shared__ int hist[256];
-  __shared__ unsigned long long sel[3];
+  __shared__ int hist[768];
+  __shared__ unsigned long long sel[1];
   __shared__ double sh_lambda, sh_factor, sh_sigma2, sh_cur_err, sh_new_err;
   __shared__ double lds_A[BA_LDS_N * (BA_LDS_N + 1)];
   __shared__ int sh_converged, sh_hitmax, sh_counter, sh_accepted, sh_error, sh_nout;

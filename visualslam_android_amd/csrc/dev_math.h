@@ -267,53 +267,76 @@ HDFN void inv2(const double m[4], double o[4]) {
 }
 
 #ifdef __HIPCC__
+// Sum N (a power of two, <= 64) per-lane values over the 64 lanes of a wavefront by recursive halving: at distance d
+// the lanes with bit d clear keep the lower half of the values and hand the upper half to their partner (and vice versa),
+// so N/2 + N/4 + ... shuffles move the data instead of 6 N.  The pairing tree -- hence every rounding -- is that of
+// the plain xor butterfly.  Returns the total of value wave_multi_index<N>(lane); acc is clobbered.
+template <int N>
+DEVFN double wave_multi_sum(double* acc) {
+  const int lane = threadIdx.x & 63;
+  int d = 32;
+#pragma unroll
+  for (int half = N / 2; half >= 1; half >>= 1, d >>= 1) {
+    // bit-mask selects: a ?: on the array elements would be folded into a dynamically indexed (scratch) access
+    const unsigned long long m = (lane & d) ? ~0ull : 0ull;
+#pragma unroll
+    for (int j = 0; j < half; j++) {
+      const unsigned long long lo = (unsigned long long)__double_as_longlong(acc[j]), hi = (unsigned long long)__double_as_longlong(acc[j + half]);
+      const unsigned long long x = (hi ^ lo) & m;
+      const double send = __longlong_as_double((long long)(hi ^ x));   // upper lanes hand over the lower half
+      const double keep = __longlong_as_double((long long)(lo ^ x));   // ... and keep the upper half
+      acc[j] = keep + __shfl_xor(send, d);
+    }
+  }
+#pragma unroll
+  for (; d >= 1; d >>= 1) acc[0] += __shfl_xor(acc[0], d);
+  return acc[0];
+}
+template <int N> DEVFN int wave_multi_index(int lane) { return N == 64 ? lane : (N == 32 ? (lane >> 1) & 31 : (N == 16 ? (lane >> 2) & 15 : (lane >> 3) & 7)); }
+
 // k-th smallest (0-based) of n non-negative doubles in global memory or LDS (bit patterns order like the values):
-// MSB-first radix select, 8 bits per pass, histogram in LDS; stops as soon as the selected bin holds a single
-// value (the usual case after 3-4 passes).  hist: LDS [256] ints, sel: LDS [3] u64.
+// MSB-first radix select, 8 bits per pass, stopping as soon as the selected bin holds a single value (the usual case
+// after 3 passes).  One barrier per pass: the histogram rotates through three LDS buffers (the one for pass p+2 is
+// cleared while pass p is scanned) and every wavefront scans the 256 bins redundantly, so nothing is broadcast.
+// hist: LDS [768] ints, sel: LDS [1] u64.  All threads of the workgroup call it and get the same result.
 DEVFN double block_radix_select(const double* v, int n, int k, int* hist, unsigned long long* sel) {
+  for (int i = threadIdx.x; i < 768; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
   unsigned long long prefix = 0, mask = 0;
   int kk = k;
+  const int l = threadIdx.x & 63;
   for (int pass = 0; pass < 8; pass++) {
     const int shift = 56 - 8 * pass;
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
-    __syncthreads();
+    int* H = hist + 256 * (pass % 3);
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
       const unsigned long long b = (unsigned long long)__double_as_longlong(v[i]);
-      if ((b & mask) == prefix) atomicAdd(&hist[(b >> shift) & 255], 1);
+      if ((b & mask) == prefix) atomicAdd(&H[(b >> shift) & 255], 1);
     }
     __syncthreads();
-    if (threadIdx.x < 64) {                                     // wave 0: 4 bins per lane, shuffle prefix sum
-      const int l = threadIdx.x;
-      const int h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
-      const int tot = h0 + h1 + h2 + h3;
-      int inc = tot;
-      for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (l >= d) inc += t; }
-      const unsigned long long bm = __ballot(inc > kk);            // first lane whose inclusive prefix passes kk
-      const int L = __ffsll((long long)bm) - 1;
-      if (l == L) {
-        int acc = inc - tot, bin = 4 * l, cnt = h0;
-        if (acc + h0 > kk) { }
-        else if (acc + h0 + h1 > kk) { acc += h0; bin += 1; cnt = h1; }
-        else if (acc + h0 + h1 + h2 > kk) { acc += h0 + h1; bin += 2; cnt = h2; }
-        else { acc += h0 + h1 + h2; bin += 3; cnt = h3; }
-        sel[0] = prefix | ((unsigned long long)bin << shift);
-        sel[1] = (unsigned long long)(kk - acc);
-        sel[2] = (unsigned long long)cnt;
-      }
-    }
-    __syncthreads();
-    prefix = sel[0]; kk = (int)sel[1];
-    const bool unique = sel[2] == 1ull;
+    const int h0 = H[4 * l], h1 = H[4 * l + 1], h2 = H[4 * l + 2], h3 = H[4 * l + 3];   // 4 bins per lane, shuffle prefix sum
+    const int tot = h0 + h1 + h2 + h3;
+    int inc = tot;
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (l >= d) inc += t; }
+    const unsigned long long bm = __ballot(inc > kk);              // first lane whose inclusive prefix passes kk
+    const int L = __ffsll((long long)bm) - 1;
+    int acc = inc - tot, bin = 4 * l, cnt = h0;
+    if (acc + h0 > kk) { }
+    else if (acc + h0 + h1 > kk) { acc += h0; bin += 1; cnt = h1; }
+    else if (acc + h0 + h1 + h2 > kk) { acc += h0 + h1; bin += 2; cnt = h2; }
+    else { acc += h0 + h1 + h2; bin += 3; cnt = h3; }
+    bin = __shfl(bin, L); acc = __shfl(acc, L); cnt = __shfl(cnt, L);
+    prefix |= (unsigned long long)bin << shift;
+    kk -= acc;
     mask |= 255ull << shift;
-    __syncthreads();
-    if (unique && pass < 7) {                                    // one value left under the prefix: fetch it whole
+    int* Z = hist + 256 * ((pass + 2) % 3);
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) Z[i] = 0;
+    if (cnt == 1 && pass < 7) {                                    // one value left under the prefix: fetch it whole
       for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const unsigned long long b = (unsigned long long)__double_as_longlong(v[i]);
         if ((b & mask) == prefix) sel[0] = b;
       }
       __syncthreads();
       prefix = sel[0];
-      __syncthreads();
       break;
     }
   }

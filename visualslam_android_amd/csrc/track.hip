@@ -727,7 +727,14 @@ __global__ __launch_bounds__(64) void k_subpix8(MapDev m, TrackParams tp, Search
 // k_pose: one workgroup per stream.  The tracker data of the iteration set is gathered once into a component-major
 // working set indexed by iteration-set entry (coalesced, L2 resident) and scattered back after the ten iterations;
 // entry e is always handled by thread e % POSE_THREADS, so the working set needs no synchronisation.
-#define POSE_THREADS 512
+#define POSE_THREADS 256
+// Diagnostic build only (-DVSLAM_BA_PROF, tools/build_baprof.sh): clock64() stamps of block 0 / thread 0 per phase of k_pose.
+#ifdef VSLAM_BA_PROF
+__device__ unsigned long long g_pose_prof[16];
+#define POSE_STAMP(id) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = clock64(); g_pose_prof[id] += t_ - g_pose_prof[15]; g_pose_prof[15] = t_; } } while (0)
+#else
+#define POSE_STAMP(id) do { } while (0)
+#endif
 #define POSE_WAVES (POSE_THREADS / 64)
 
 struct PoseItem {            // TrackerData fields used by the pose iterations (jni/TrackerData.h:36-66)
@@ -760,7 +767,7 @@ DEVFN void item_store(const PoseItem& it, const PoseWs& w, int e, bool all) {   
 // CalcPoseUpdate, jni/Tracker.cc:683-774 (Tukey).  All threads of the workgroup call it; result in up[6] (LDS).
 DEVFN void calc_pose_update(const PoseWs& ws, MapPointDev* pts, int n, int nvalid_thread, const TrackParams& tp,
                             double dOverrideSigma, bool bMarkOutliers, double* sortbuf, double* red /* [waves][28] */,
-                            double* up /* [6] */, int* icnt, int* hist /* [256] */, unsigned long long* sel /* [3] */) {
+                            double* up /* [6] */, int* icnt, int* hist /* [768] */, unsigned long long* sel /* [1] */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int nvalid = nvalid_thread;                                        // residuals are already in sortbuf (k_pose)
   nvalid = wave_sum_i(nvalid);
@@ -773,12 +780,14 @@ DEVFN void calc_pose_update(const PoseWs& ws, MapPointDev* pts, int n, int nvali
     __syncthreads();
     return;
   }
+  POSE_STAMP(2);
   double sigma2;
   if (dOverrideSigma > 0) sigma2 = dOverrideSigma;                  // :720-721
   else {                                                            // Tukey::FindSigmaSquared, jni/MEstimator.h:67-77
     const double med = block_radix_select(sortbuf, n, nvalid / 2, hist, sel);   // same order statistic as sort + [n/2]
     sigma2 = tukey_sigma_squared(med, (unsigned long)nvalid);
   }
+  POSE_STAMP(3);
   const bool qint = (tp.quirks & VSLAM_Q_POSE_INT_RESIDUAL) != 0;
   double acc[27];
 #pragma unroll
@@ -810,9 +819,17 @@ DEVFN void calc_pose_update(const PoseWs& ws, MapPointDev* pts, int n, int nvali
       }
     }
   }
+  POSE_STAMP(4);
+  {
+    double a32[32];
 #pragma unroll
-  for (int i = 0; i < 27; i++) { const double v = wave_sum_d(acc[i]); if (lane == 0) red[wave * 28 + i] = v; }
+    for (int i = 0; i < 32; i++) a32[i] = i < 27 ? acc[i] : 0.0;
+    const double tot = wave_multi_sum<32>(a32);
+    const int vi = wave_multi_index<32>(lane);
+    if (!(lane & 1) && vi < 27) red[wave * 28 + vi] = tot;
+  }
   __syncthreads();
+  POSE_STAMP(5);
   if (threadIdx.x == 0) {
     double C[36], v[6];
     int q = 0;
@@ -832,6 +849,7 @@ DEVFN void calc_pose_update(const PoseWs& ws, MapPointDev* pts, int n, int nvali
     for (int r = 0; r < 6; r++) up[r] = v[r];
   }
   __syncthreads();
+  POSE_STAMP(6);
 }
 
 // KeyFrameLinearDist, jni/MapMaker.cc:705-712
@@ -854,8 +872,8 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose(MapDev m, TrackParams tp,
   __shared__ double red[POSE_WAVES * 28 + 2];
   __shared__ double up[6], last_up[6];
   __shared__ int icnt[POSE_WAVES];
-  __shared__ int hist[256];
-  __shared__ unsigned long long sel[3];
+  __shared__ int hist[768];
+  __shared__ unsigned long long sel[1];
   __shared__ Pose pose;
   if (threadIdx.x == 0) pose = st->pose_cur;
   if (threadIdx.x < 6) last_up[threadIdx.x] = 0.0;
@@ -865,6 +883,9 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose(MapDev m, TrackParams tp,
     const int nFound = st->found[0] + st->found[1] + st->found[2] + st->found[3];
     if (nFound < tp.coarse_min) return;                              // :465
   }
+#ifdef VSLAM_BA_PROF
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_pose_prof[15] = clock64();
+#endif
   const PoseWs ws = {m.pose_ws + (size_t)s * POSE_WS_COMPS * P, m.pose_wsi + (size_t)s * 2 * P, P};
   for (int e = threadIdx.x; e < n; e += POSE_THREADS) {             // gather
     const int idx = ilist[e];
@@ -876,6 +897,7 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose(MapDev m, TrackParams tp,
     ws.d[11 * P + e] = t.sqrt_inv_noise;
   }
   __syncthreads();
+  POSE_STAMP(0);
   for (int iter = 0; iter < 10; iter++) {                            // coarse :466-488, fine :543-577
     const bool nonlinear = stage == 0 || iter == 0 || iter == 4 || iter == 9;
     int nvalid = 0;
@@ -902,12 +924,15 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose(MapDev m, TrackParams tp,
       }
       sortbuf[e] = e2;
     }
+    POSE_STAMP(1);
     const double override_sigma = iter > 5 ? (stage == 0 ? 1.0 : 16.0) : 0.0;
     calc_pose_update(ws, pts, n, nvalid, tp, override_sigma, stage == 1 && iter == 9, sortbuf, red, up, icnt, hist, sel);
     if (threadIdx.x == 0) pose = pose_mul(se3_exp(up), pose);        // :487 / :573
     if (threadIdx.x < 6) last_up[threadIdx.x] = up[threadIdx.x];
     __syncthreads();
+    POSE_STAMP(7);
   }
+  POSE_STAMP(8);
   for (int e = threadIdx.x; e < n; e += POSE_THREADS) {             // scatter what the iterations changed
     TrackData& t = td[ws.i[P + e]];
     t.flags = ws.i[e];
@@ -986,7 +1011,17 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose(MapDev m, TrackParams tp,
       st->last_kf_dropped = st->frame;
     }
   }
+  POSE_STAMP(9);
 }
+
+#ifdef VSLAM_BA_PROF
+extern "C" int vslam_debug_pose_prof(unsigned long long* out16, int reset) {
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_pose_prof), sizeof(unsigned long long) * 16));
+  if (reset) { unsigned long long z[16] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_pose_prof), z, sizeof(z))); }
+  return VSLAM_OK;
+}
+#endif
 
 // ---- host side ----------------------------------------------------------------------------------------------------
 template <class T>
