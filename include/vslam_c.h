@@ -108,6 +108,18 @@ int vslam_read_row_lut(vslam_system* sys, int stream, int level, int* lut /* hei
 int vslam_read_max_corners(vslam_system* sys, int stream, int level, uint32_t* corners, int* scores,
                            int cap, int* n);
 
+/* KeyFrame::MakeKeyFrame_Rest (jni/KeyFrame.cc:53-95) for the current frame of every stream: fast_nonmax on the four levels,
+ * then the candidate list -- maximal corners inside the 10-px border whose Shi-Tomasi score (half-window 3,
+ * jni/vision/ImageHandler.cpp:124-155) exceeds min_shi_tomasi_score (reference: 70, :57).  The SmallBlurryImage part of the
+ * function belongs to the relocaliser and is not built. */
+int vslam_make_keyframe_rest(vslam_system* sys, double min_shi_tomasi_score);
+/* MapMaker::ThinCandidates (jni/MapMaker.cc:393-422) on all four levels of the current candidate lists, against the
+ * measurements of `keyframe` of each stream (keyframe < 0: the tracker's measurements of the current frame, i.e. what
+ * MapMaker::AddKeyFrame copies into the new keyframe). */
+int vslam_thin_candidates(vslam_system* sys, int keyframe);
+/* Candidate::irLevelPos (packed x | y<<16) and dSTScore of one level, raster order; *n = count (may exceed cap). */
+int vslam_read_candidates(vslam_system* sys, int stream, int level, uint32_t* pos, double* score, int cap, int* n);
+
 /* ---- MiniPatch (jni/MiniPatch.cc), the primitives of the reference's trail tracking ------------- */
 /* MiniPatch::SampleFromImage (:71-83): 9x9 patches around n integer positions of the current frame's level 0
  * of `stream`; ok[i] = 0 where the patch would leave the image (the reference asserts). Synchronous. */

@@ -27,6 +27,7 @@ def lib():
             build()
         _lib = C.CDLL(LIB)
         _lib.orc_shi_tomasi.restype = C.c_double
+        _lib.orc_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     return _lib
 
 
@@ -73,6 +74,23 @@ def nonmax(corners, scores, quirk=False):
     out = np.empty(max(len(corners), 1), np.uint32)
     n = lib().orc_nonmax(_p(corners), _p(scores), len(corners), int(bool(quirk)), _p(out))
     return out[:n].copy()
+
+
+def candidates(img, maxcorners, min_score=70.0, border=10):
+    """MakeKeyFrame_Rest candidate loop on one level image -> (packed positions, Shi-Tomasi scores)."""
+    img = np.ascontiguousarray(img)
+    mc = np.ascontiguousarray(maxcorners, np.uint32)
+    pos = np.empty(max(len(mc), 1), np.uint32); sc = np.empty(max(len(mc), 1), np.float64)
+    n = lib().orc_candidates(_p(img), img.shape[1], img.shape[0], img.shape[1], _p(mc), len(mc), float(min_score), int(border), _p(pos), _p(sc), len(pos))
+    return pos[:n].copy(), sc[:n].copy()
+
+
+def thin_candidates(pos, score, level, meas_root, meas_level):
+    pos = np.ascontiguousarray(pos, np.uint32); score = np.ascontiguousarray(score, np.float64)
+    mr = np.ascontiguousarray(meas_root, np.float64).reshape(-1, 2); ml = np.ascontiguousarray(meas_level, np.int32)
+    op = np.empty(max(len(pos), 1), np.uint32); os_ = np.empty(max(len(pos), 1), np.float64)
+    n = lib().orc_thin_candidates(_p(pos), _p(score), len(pos), int(level), _p(mr), _p(ml), len(ml), _p(op), _p(os_))
+    return op[:n].copy(), os_[:n].copy()
 
 
 def shi_tomasi(img, nsize, px, py):

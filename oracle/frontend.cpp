@@ -160,6 +160,48 @@ extern "C" double orc_shi_tomasi(const uint8_t* img, int stride, int nsize, int 
   return 0.5 * (dXX + dYY - sqrt((dXX + dYY) * (dXX + dYY) - 4 * (dXX * dYY - dXY * dXY)));
 }
 
+extern "C" int orc_candidates(const uint8_t* img, int w, int h, int stride, const uint32_t* maxcorners, int n,
+                              double min_score, int border, uint32_t* out_pos, double* out_score, int cap) {
+  // KeyFrame::MakeKeyFrame_Rest candidate loop, jni/KeyFrame.cc:66-95 (colour sampling and the SBI are not part of the path)
+  int m = 0;
+  for (int i = 0; i < n; i++) {
+    const int x = maxcorners[i] & 0xFFFF, y = maxcorners[i] >> 16;
+    if (!(x >= border && y >= border && x < w - border && y < h - border)) continue;   // :72-73
+    const double st = orc_shi_tomasi(img, stride, 3, x, y);                               // :79
+    if (st > min_score) {                                                                 // :81
+      if (m < cap) { out_pos[m] = maxcorners[i]; out_score[m] = st; }
+      m++;
+    }
+  }
+  return m;
+}
+
+extern "C" int orc_thin_candidates(const uint32_t* pos, const double* score, int n, int level, const double* meas_root,
+                                   const int* meas_level, int n_meas, uint32_t* out_pos, double* out_score) {
+  // MapMaker::ThinCandidates, jni/MapMaker.cc:393-422; rounded() :381-386; LevelScale jni/LevelHelpers.h
+  std::vector<double> busy;
+  const int scale = 1 << level;
+  for (int j = 0; j < n_meas; j++) {
+    if (!(meas_level[j] == level || meas_level[j] == level + 1)) continue;
+    for (int k = 0; k < 2; k++) {
+      const double v = meas_root[2 * j + k] / scale;
+      busy.push_back((double)static_cast<int>(v > 0.0 ? v + 0.5 : v - 0.5));
+    }
+  }
+  const unsigned int nMinMagSquared = 10 * 10;
+  int m = 0;
+  for (int i = 0; i < n; i++) {
+    const double cx = pos[i] & 0xFFFF, cy = pos[i] >> 16;
+    bool good = true;
+    for (size_t j = 0; j < busy.size(); j += 2) {
+      const double dx = busy[j] - cx, dy = busy[j + 1] - cy;
+      if (dx * dx + dy * dy < nMinMagSquared) { good = false; break; }
+    }
+    if (good) { out_pos[m] = pos[i]; out_score[m] = score[i]; m++; }
+  }
+  return m;
+}
+
 extern "C" int orc_make_keyframe_lite(const uint8_t* gray, int w, int h, int stride,
                                       const int thr[ORC_LEVELS], uint8_t* const lvl_img[ORC_LEVELS],
                                       uint32_t* const corners[ORC_LEVELS], int cap,

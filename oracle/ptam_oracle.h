@@ -61,6 +61,15 @@ int orc_nonmax(const uint32_t* corners, const int* scores, int n, int quirk, uin
 /* FindShiTomasiScoreAtPoint, jni/vision/ImageHandler.cpp:124-155 */
 double orc_shi_tomasi(const uint8_t* img, int stride, int nsize, int px, int py);
 
+/* KeyFrame::MakeKeyFrame_Rest candidate loop, jni/KeyFrame.cc:66-95: maximal corners inside the border whose Shi-Tomasi
+ * score (half-window 3) exceeds min_score, in raster order.  Returns the count (may exceed cap). */
+int orc_candidates(const uint8_t* img, int w, int h, int stride, const uint32_t* maxcorners, int n, double min_score,
+                   int border, uint32_t* out_pos, double* out_score, int cap);
+/* MapMaker::ThinCandidates, jni/MapMaker.cc:393-422: drop candidates closer than 10 px (level pixels) to a measurement of
+ * the keyframe at the same level or one level up.  out arrays hold n entries.  Returns the number kept. */
+int orc_thin_candidates(const uint32_t* pos, const double* score, int n, int level, const double* meas_root,
+                        const int* meas_level, int n_meas, uint32_t* out_pos, double* out_score);
+
 /* KeyFrame::MakeKeyFrame_Lite, jni/KeyFrame.cc:5-51: 4-level pyramid + FAST-10 + row LUT.
  * lvl_img[l] must hold (w>>l)*(h>>l) bytes (tight pitch); corners[l] cap entries;
  * lut[l] (h>>l) ints.  Returns 0. */

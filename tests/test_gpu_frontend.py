@@ -83,3 +83,23 @@ def test_fast_nonmax_bit_exact(oracle, quirk):
             assert np.array_equal(gsc[:len(corners)], sc), (s, l)
             assert np.array_equal(got, keep), (s, l)
     g.close()
+
+
+def test_keyframe_rest_candidates_bit_exact(oracle):
+    """vslam_make_keyframe_rest: fast_nonmax + Shi-Tomasi candidates (jni/KeyFrame.cc:53-95), lists and scores bit-exact."""
+    frames = np.stack([synth_image(500 + s, 640, 480) for s in range(2)])
+    g = run_gpu(frames)
+    g.make_keyframe_rest(70.0)
+    total = 0
+    for s in range(2):
+        want = oracle.make_keyframe_lite(frames[s])
+        for l in range(4):
+            img, corners, _ = want[l]
+            keep = oracle.nonmax(corners, oracle.fast_score(img, corners, 10))
+            pos, sc = oracle.candidates(img, keep, 70.0, 10)
+            gpos, gsc = g.read_candidates(s, l)
+            assert np.array_equal(gpos, pos), (s, l)
+            assert np.array_equal(gsc, sc), (s, l)          # integer gradient sums, IEEE division and sqrt: bit-exact
+            total += len(pos)
+    assert total > 50
+    g.close()

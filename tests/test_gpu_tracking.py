@@ -211,3 +211,43 @@ def test_explicit_bundle_adjust_recent_and_all():
         po, pg = o.points(), g.points(0)
         assert np.array_equal(po["bad"], pg["bad"]) and np.abs(po["pos"] - pg["pos"]).max() < 1e-8
     g.close()
+
+
+def test_thin_candidates_matches_oracle():
+    """MakeKeyFrame_Rest + MapMaker::ThinCandidates (jni/KeyFrame.cc:53-95, jni/MapMaker.cc:393-422) of a tracked frame:
+    against the tracker's own measurements (what AddKeyFrame would copy) and against a stored keyframe's."""
+    from oracle import binding as orc
+    w, h = 640, 480
+    f, m, frames = make_scene(w, h, seed=77, n_frames=2)
+    vp = capi.default_params(w, h, 2, patch_size=8)
+    g = capi.System(vp)
+    for s in range(2):
+        g.load_map(s, m); g.set_pose(s, f.pose(-1))
+    o = make_oracle(capi.default_params(w, h, 1, patch_size=8), m, f.pose(-1))
+    for t in range(2):
+        g.track_frame(np.stack([frames[t]] * 2)); o.track_frame(frames[t])
+    lv = orc.make_keyframe_lite(frames[1])
+    cands = []
+    for l in range(4):
+        img, corners, _ = lv[l]
+        keep = orc.nonmax(corners, orc.fast_score(img, corners, 10))
+        cands.append(orc.candidates(img, keep, 70.0, 10))
+    to = o.point_tracks()
+    found = (to["found"] == 1) & (g.point_tracks(0)["level"] >= 0)       # bFound is stale for points outside this frame's PVS
+    for which in (-1, 0):
+        if which < 0:
+            root, lev = to["vfound"][found], to["level"][found]
+        else:
+            km = o.keyframe_meas(0)
+            root, lev = km["root"], km["level"]
+        g.make_keyframe_rest(70.0)
+        g.thin_candidates(which)
+        removed = 0
+        for l in range(4):
+            want, wsc = orc.thin_candidates(cands[l][0], cands[l][1], l, root, lev)
+            for s in range(2):
+                got, gsc = g.read_candidates(s, l)
+                assert np.array_equal(got, want) and np.array_equal(gsc, wsc), (which, l, s)
+            removed += len(cands[l][0]) - len(want)
+        assert removed > 0                                  # the map's own points sit on corners: thinning must bite
+    g.close()

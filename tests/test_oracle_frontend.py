@@ -117,3 +117,28 @@ def test_shi_tomasi_known_answer(oracle):
     assert abs(oracle.shi_tomasi(img, 3, 16, 16)) < 1e-9
     img[16:, :] = 200                                    # corner: both eigenvalues > 0
     assert oracle.shi_tomasi(img, 3, 16, 16) > 70
+
+
+def test_candidates_and_thinning_semantics(oracle):
+    """KeyFrame::MakeKeyFrame_Rest candidate loop (jni/KeyFrame.cc:66-95) + MapMaker::ThinCandidates (jni/MapMaker.cc:393-422)."""
+    img = np.zeros((64, 64), np.uint8)
+    img[20:, 20:] = 200                                  # one strong corner at (20, 20)
+    pack = lambda x, y: np.uint32(x | (y << 16))
+    mc = np.array([pack(5, 5), pack(20, 20), pack(40, 20), pack(58, 40)], np.uint32)   # border, corner, edge, border
+    pos, sc = oracle.candidates(img, mc, 70.0, 10)
+    assert list(pos) == [pack(20, 20)] and sc[0] == oracle.shi_tomasi(img, 3, 20, 20) and sc[0] > 70
+    # strict threshold: a candidate at exactly the minimum score is dropped (:81 uses >)
+    assert len(oracle.candidates(img, mc, sc[0], 10)[0]) == 0
+    # thinning on level 1: a measurement at level 1 or 2 within 10 level-pixels kills the candidate, others do not
+    cand = np.array([pack(20, 20), pack(50, 50)], np.uint32); csc = np.array([80.0, 90.0])
+    root = np.array([[2 * 20 + 12.0, 2 * 20.0], [200.0, 200.0], [2 * 20.0, 2 * 20.0]])   # L0 coordinates
+    for lev, want in (([1, 1, 0], [pack(20, 20), pack(50, 50)][1:] ), ([0, 3, 0], [pack(20, 20), pack(50, 50)])):
+        got, gs = oracle.thin_candidates(cand, csc, 1, root, np.array(lev, np.int32))
+        assert list(got) == list(want)
+    # distance exactly 10 survives (< 100 is the kill test), 9.x does not; positions are rounded() half away from zero
+    got, _ = oracle.thin_candidates(cand[:1], csc[:1], 0, np.array([[30.0, 20.0]]), np.array([0], np.int32))
+    assert len(got) == 1
+    got, _ = oracle.thin_candidates(cand[:1], csc[:1], 0, np.array([[29.49, 20.0]]), np.array([1], np.int32))
+    assert len(got) == 0
+    got, _ = oracle.thin_candidates(cand[:1], csc[:1], 0, np.array([[29.5, 20.0]]), np.array([1], np.int32))
+    assert len(got) == 1

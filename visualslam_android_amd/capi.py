@@ -62,6 +62,9 @@ SYMBOLS = {
     "vslam_read_corners": (_i, [_sys, _i, _i, _vp, _i, _ip]),
     "vslam_read_row_lut": (_i, [_sys, _i, _i, _vp]),
     "vslam_read_max_corners": (_i, [_sys, _i, _i, _vp, _vp, _i, _ip]),
+    "vslam_make_keyframe_rest": (_i, [_sys, C.c_double]),
+    "vslam_thin_candidates": (_i, [_sys, _i]),
+    "vslam_read_candidates": (_i, [_sys, _i, _i, _vp, _vp, _i, _ip]),
     "vslam_minipatch_sample": (_i, [_sys, _i, _i, _vp, _vp, _vp]),
     "vslam_minipatch_find": (_i, [_sys, _i, _i, _vp, _vp, _i, _i, _vp]),
     "vslam_add_keyframe": (_i, [_sys, _i]),
@@ -305,6 +308,19 @@ class System:
         pos = np.zeros((n, 3)); bad, nin, nout = (np.zeros(n, np.int32) for _ in range(3))
         _check(self.lib.vslam_get_points(self.h, stream, pos.ctypes.data, bad.ctypes.data, nin.ctypes.data, nout.ctypes.data, n))
         return {"pos": pos, "bad": bad, "n_in": nin, "n_out": nout}
+
+    def make_keyframe_rest(self, min_score=70.0):
+        _check(self.lib.vslam_make_keyframe_rest(self.h, float(min_score)))
+
+    def thin_candidates(self, keyframe=-1):
+        _check(self.lib.vslam_thin_candidates(self.h, int(keyframe)))
+
+    def read_candidates(self, stream, level):
+        n = C.c_int(0)
+        _check(self.lib.vslam_read_candidates(self.h, stream, level, None, None, 0, C.byref(n)))
+        pos = np.zeros(max(n.value, 1), np.uint32); sc = np.zeros(max(n.value, 1), np.float64)
+        _check(self.lib.vslam_read_candidates(self.h, stream, level, pos.ctypes.data, sc.ctypes.data, len(pos), C.byref(n)))
+        return pos[:n.value], sc[:n.value]
 
     def bundle_stats(self, stream):
         """Sizes of the last assembled bundle-adjustment problem of the stream."""

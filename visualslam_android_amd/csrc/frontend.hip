@@ -333,6 +333,132 @@ __global__ __launch_bounds__(FE_THREADS) void k_nonmax(NmArgs a) {
   if (threadIdx.x == 0) a.nmax[s * NLEV + l] = carry;
 }
 
+// KeyFrame::MakeKeyFrame_Rest candidate loop (jni/KeyFrame.cc:66-95): maximal corners inside the 10-px border whose
+// Shi-Tomasi score (FindShiTomasiScoreAtPoint, jni/vision/ImageHandler.cpp:124-155, half-window 3) exceeds the minimum,
+// in raster order.  One workgroup per (level, stream); one lane per maximal corner; block scan keeps the order.
+// The three gradient sums are integers (exact in fp64 in any order), the rest follows the reference expression.
+struct CandArgs {
+  const uint8_t* img[NLEV]; size_t img_sstride[NLEV]; int img_pitch[NLEV];
+  int w[NLEV], h[NLEV], cap[NLEV];
+  const uint32_t* maxcorners[NLEV]; const int* nmax;
+  uint32_t* cand[NLEV]; double* cand_score[NLEV]; int* ncand;
+  double min_score; int border;
+};
+
+__device__ __forceinline__ double shi_tomasi7(const uint8_t* img, int pitch, int px, int py) {
+  int sxx = 0, syy = 0, sxy = 0;
+  for (int cy = py - 3; cy <= py + 3; cy++) {
+    const uint8_t* r = img + (size_t)cy * pitch;
+#pragma unroll
+    for (int cx = -3; cx <= 3; cx++) {
+      const int dx = (int)r[px + cx + 1] - (int)r[px + cx - 1];
+      const int dy = (int)r[px + cx + pitch] - (int)r[px + cx - pitch];
+      sxx += dx * dx; syy += dy * dy; sxy += dx * dy;
+    }
+  }
+  const int nPixels = 49;
+  const double dXX = (double)sxx / (2.0 * nPixels), dYY = (double)syy / (2.0 * nPixels), dXY = (double)sxy / (2.0 * nPixels);
+  return 0.5 * (dXX + dYY - sqrt((dXX + dYY) * (dXX + dYY) - 4 * (dXX * dYY - dXY * dXY)));
+}
+
+// ordered append of the lanes with keep != 0 (block-wide, raster order preserved); returns the new carry
+__device__ __forceinline__ int block_ordered_slot(int keep, int* wsum, int* carry, int& slot) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = keep;
+  for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(inc, d); if (lane >= d) inc += v; }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int base = *carry;
+  for (int w = 0; w < wave; w++) base += wsum[w];
+  slot = base + inc - 1;
+  __syncthreads();
+  if (threadIdx.x == FE_THREADS - 1) *carry = base + inc;
+  __syncthreads();
+  return 0;
+}
+
+__global__ __launch_bounds__(FE_THREADS) void k_candidates(CandArgs a) {
+  __shared__ int wsum[FE_THREADS / 64];
+  __shared__ int carry;
+  const int l = blockIdx.x, s = blockIdx.y;
+  const int n = a.nmax[s * NLEV + l], cap = a.cap[l];
+  const uint32_t* mc = a.maxcorners[l] + (size_t)s * cap;
+  const uint8_t* img = a.img[l] + (size_t)s * a.img_sstride[l];
+  uint32_t* out = a.cand[l] + (size_t)s * cap;
+  double* outs = a.cand_score[l] + (size_t)s * cap;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += FE_THREADS) {
+    const int i = i0 + threadIdx.x;
+    int keep = 0; uint32_t me = 0; double st = 0.0;
+    if (i < n) {
+      me = mc[i];
+      const int x = me & 0xFFFF, y = me >> 16;
+      if (x >= a.border && y >= a.border && x < a.w[l] - a.border && y < a.h[l] - a.border) {   // :72-73
+        st = shi_tomasi7(img, a.img_pitch[l], x, y);
+        keep = st > a.min_score;                                                                // :81
+      }
+    }
+    int slot;
+    block_ordered_slot(keep, wsum, &carry, slot);
+    if (keep) { out[slot] = me; outs[slot] = st; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) a.ncand[s * NLEV + l] = carry;
+}
+
+// MapMaker::ThinCandidates (jni/MapMaker.cc:393-422) on every level: a candidate survives when no measurement of the
+// keyframe at the same level or one level up lies within 10 level-pixels (rounded(), :381-386).  One workgroup per
+// (level, stream); the busy positions are staged in LDS; the surviving list is compacted in place, order kept.
+#define THIN_BUSY_CAP 4096
+struct ThinArgs {
+  uint32_t* cand[NLEV]; double* cand_score[NLEV]; int* ncand; int cap[NLEV];
+  const MeasDev* meas; size_t meas_sstride; const int* n_points; size_t st_stride;   // measurement row of the keyframe per stream
+};
+
+__global__ __launch_bounds__(FE_THREADS) void k_thin_candidates(ThinArgs a, const TrackerState* st) {
+  __shared__ int busy[THIN_BUSY_CAP * 2];
+  __shared__ int nbusy;
+  __shared__ int wsum[FE_THREADS / 64];
+  __shared__ int carry;
+  const int l = blockIdx.x, s = blockIdx.y;
+  const MeasDev* ms = a.meas + (size_t)s * a.meas_sstride;
+  const int np = st[s].n_points;
+  if (threadIdx.x == 0) { nbusy = 0; carry = 0; }
+  __syncthreads();
+  const int scale = 1 << l;
+  for (int i = threadIdx.x; i < np; i += FE_THREADS) {
+    const MeasDev m = ms[i];
+    if (!m.valid || !(m.level == l || m.level == l + 1)) continue;
+    const double vx = m.root[0] / scale, vy = m.root[1] / scale;
+    const int k = atomicAdd(&nbusy, 1);
+    if (k < THIN_BUSY_CAP) { busy[2 * k] = (int)(vx > 0.0 ? vx + 0.5 : vx - 0.5); busy[2 * k + 1] = (int)(vy > 0.0 ? vy + 0.5 : vy - 0.5); }
+  }
+  __syncthreads();
+  const int nb = nbusy < THIN_BUSY_CAP ? nbusy : THIN_BUSY_CAP;
+  const int n = a.ncand[s * NLEV + l];
+  uint32_t* cp = a.cand[l] + (size_t)s * a.cap[l];
+  double* cs = a.cand_score[l] + (size_t)s * a.cap[l];
+  for (int i0 = 0; i0 < n; i0 += FE_THREADS) {
+    const int i = i0 + threadIdx.x;
+    int keep = 0; uint32_t me = 0; double sc = 0.0;
+    if (i < n) {
+      me = cp[i]; sc = cs[i];
+      const int cx = me & 0xFFFF, cy = me >> 16;
+      keep = 1;
+      for (int j = 0; j < nb; j++) {
+        const int dx = busy[2 * j] - cx, dy = busy[2 * j + 1] - cy;
+        if (dx * dx + dy * dy < 100) { keep = 0; break; }
+      }
+    }
+    int slot;
+    block_ordered_slot(keep, wsum, &carry, slot);          // barriers inside: every read of this chunk precedes its writes
+    if (keep) { cp[slot] = me; cs[slot] = sc; }            // slot <= i: in-place compaction never overtakes the reads
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) a.ncand[s * NLEV + l] = carry;
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------
 static void fill_fe_args(vslam_system* sys, FeArgs& a) {
   for (int l = 0; l < NLEV; l++) {
@@ -411,6 +537,39 @@ int fe_fast_nonmax(vslam_system* sys) {
   a.quirk = (sys->p.quirks & VSLAM_Q_NONMAX_RIGHT_NEIGHBOUR) ? 1 : 0;
   hipLaunchKernelGGL(k_score, dim3((maxcap + FE_THREADS - 1) / FE_THREADS, NLEV, sys->S), dim3(FE_THREADS), 0, sys->stream, a);
   hipLaunchKernelGGL(k_nonmax, dim3(NLEV, sys->S), dim3(FE_THREADS), 0, sys->stream, a);
+  HIPCHK(hipGetLastError());
+  return VSLAM_OK;
+}
+
+// KeyFrame::MakeKeyFrame_Rest (jni/KeyFrame.cc:53-95) for the current frame of every stream: fast_nonmax + candidates.
+int fe_make_keyframe_rest(vslam_system* sys, double min_score) {
+  int r = fe_fast_nonmax(sys);
+  if (r) return r;
+  CandArgs a;
+  for (int l = 0; l < NLEV; l++) {
+    a.img[l] = sys->fr.img[l]; a.img_sstride[l] = sys->fr.img_sstride[l]; a.img_pitch[l] = sys->fr.img_pitch[l];
+    a.w[l] = sys->geom[l].w; a.h[l] = sys->geom[l].h; a.cap[l] = sys->geom[l].cap;
+    a.maxcorners[l] = sys->fr.maxcorners[l];
+    a.cand[l] = sys->cand[l]; a.cand_score[l] = sys->cand_score[l];
+  }
+  a.nmax = sys->fr.nmax; a.ncand = sys->ncand;
+  a.min_score = min_score; a.border = 10;                            // gvdCandidateMinSTScore / border, jni/KeyFrame.cc:57,65
+  hipLaunchKernelGGL(k_candidates, dim3(NLEV, sys->S), dim3(FE_THREADS), 0, sys->stream, a);
+  HIPCHK(hipGetLastError());
+  sys->have_candidates = true;
+  return VSLAM_OK;
+}
+
+int fe_thin_candidates(vslam_system* sys, int keyframe) {
+  if (!sys->have_candidates) { vslam_set_error("thin_candidates: call vslam_make_keyframe_rest first"); return VSLAM_E_STATE; }
+  if (keyframe >= sys->p.max_keyframes) { vslam_set_error("thin_candidates: bad keyframe"); return VSLAM_E_INVALID; }
+  ThinArgs a;
+  for (int l = 0; l < NLEV; l++) { a.cand[l] = sys->cand[l]; a.cand_score[l] = sys->cand_score[l]; a.cap[l] = sys->geom[l].cap; }
+  a.ncand = sys->ncand;
+  const size_t P = sys->p.max_points, K = sys->p.max_keyframes;
+  if (keyframe < 0) { a.meas = sys->map.cur_meas; a.meas_sstride = P; }           // the tracker's measurements of this frame
+  else { a.meas = sys->map.kf_meas + (size_t)keyframe * P; a.meas_sstride = K * P; }
+  hipLaunchKernelGGL(k_thin_candidates, dim3(NLEV, sys->S), dim3(FE_THREADS), 0, sys->stream, a, sys->map.st);
   HIPCHK(hipGetLastError());
   return VSLAM_OK;
 }

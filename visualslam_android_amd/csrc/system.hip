@@ -115,6 +115,9 @@ extern "C" int vslam_create(const vslam_params* p, vslam_system** out) {
     ALLOC(fr.nmax, (size_t)S * NLEV);
     ALLOC(fr.overflow, 1);
   }
+  for (int l = 0; l < NLEV; l++) { ALLOC(sys->cand[l], (size_t)S * sys->geom[l].cap); ALLOC(sys->cand_score[l], (size_t)S * sys->geom[l].cap); }
+  ALLOC(sys->ncand, (size_t)S * NLEV);
+  sys->have_candidates = false;
   if (p->ba_delay_frames > 0) {
     if (hipStreamCreateWithFlags(&sys->ba_stream, hipStreamNonBlocking) != hipSuccess) { vslam_set_error("create: hipStreamCreate failed"); vslam_destroy(sys); return VSLAM_E_HIP; }
     for (int i = 0; i < p->ba_delay_frames + 2; i++) {
@@ -217,6 +220,31 @@ extern "C" int vslam_read_row_lut(vslam_system* sys, int stream, int level, int*
   int r = check_sl(sys, stream, level); if (r) return r;
   const int h = sys->geom[level].h;
   HIPCHK(hipMemcpyAsync(lut, sys->fr.rowlut[level] + (size_t)stream * (h + 1), (size_t)h * 4, hipMemcpyDeviceToHost, sys->stream));
+  HIPCHK(hipStreamSynchronize(sys->stream));
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_make_keyframe_rest(vslam_system* sys, double min_shi_tomasi_score) {
+  if (!sys) return VSLAM_E_INVALID;
+  return fe_make_keyframe_rest(sys, min_shi_tomasi_score);
+}
+
+extern "C" int vslam_thin_candidates(vslam_system* sys, int keyframe) {
+  if (!sys) return VSLAM_E_INVALID;
+  return fe_thin_candidates(sys, keyframe);
+}
+
+extern "C" int vslam_read_candidates(vslam_system* sys, int stream, int level, uint32_t* pos, double* score, int cap, int* n) {
+  int r = check_sl(sys, stream, level); if (r) return r;
+  if (!sys->have_candidates) { vslam_set_error("read_candidates: call vslam_make_keyframe_rest first"); return VSLAM_E_STATE; }
+  int cnt = 0;
+  HIPCHK(hipMemcpyAsync(&cnt, sys->ncand + stream * NLEV + level, sizeof(int), hipMemcpyDeviceToHost, sys->stream));
+  HIPCHK(hipStreamSynchronize(sys->stream));
+  if (n) *n = cnt;
+  const size_t off = (size_t)stream * sys->geom[level].cap;
+  const size_t m = (size_t)(cnt < cap ? cnt : cap);
+  if (pos && m) HIPCHK(hipMemcpyAsync(pos, sys->cand[level] + off, m * 4, hipMemcpyDeviceToHost, sys->stream));
+  if (score && m) HIPCHK(hipMemcpyAsync(score, sys->cand_score[level] + off, m * 8, hipMemcpyDeviceToHost, sys->stream));
   HIPCHK(hipStreamSynchronize(sys->stream));
   return VSLAM_OK;
 }

@@ -146,6 +146,8 @@ struct vslam_system {
   long frame_no = 0;
   std::vector<void*> allocs;   // everything to hipFree
   bool have_frame;
+  // KeyFrame::Level::vCandidates of the current frame (jni/KeyFrame.h:62-70), filled by vslam_make_keyframe_rest
+  uint32_t* cand[NLEV]; double* cand_score[NLEV]; int* ncand; bool have_candidates;
   TrackParams tp;
   MapDev map;
   void* ba_ws;                 // bundle-adjustment workspace (ba.hip)
@@ -170,6 +172,8 @@ static inline void prof_mark(vslam_system* sys, int k) {
 int fe_make_keyframe_lite(vslam_system* sys, const uint8_t* gray, size_t row_stride, size_t stream_stride,
                           int on_device);
 int fe_fast_nonmax(vslam_system* sys);
+int fe_make_keyframe_rest(vslam_system* sys, double min_score);
+int fe_thin_candidates(vslam_system* sys, int keyframe);
 // track.hip
 void trk_fill_params(const vslam_params& p, TrackParams& t);
 int trk_alloc(vslam_system* sys);
