@@ -75,7 +75,19 @@ struct KeyFrame {
     vslam_detail::check(vslam_make_keyframe_lite(sys, im.data, im.step, 0, 0));
     vslam_detail::check(vslam_synchronize(sys));
   }
-  void MakeKeyFrame_Rest() { vslam_detail::check(vslam_fast_nonmax(sys)); }   // jni/KeyFrame.cc:53-63 (non-max part)
+  // jni/KeyFrame.cc:53-95: fast_nonmax + Shi-Tomasi candidates (gvdCandidateMinSTScore = 70); the SmallBlurryImage
+  // of the relocaliser is not built.
+  void MakeKeyFrame_Rest() { vslam_detail::check(vslam_make_keyframe_rest(sys, 70.0)); }
+  struct Candidate { int x, y; double dSTScore; };                  // jni/KeyFrame.h:36-43 (irLevelPos, dSTScore)
+  std::vector<Candidate> Candidates(int level) const {              // Level::vCandidates
+    int n = 0;
+    vslam_detail::check(vslam_read_candidates(sys, 0, level, nullptr, nullptr, 0, &n));
+    std::vector<uint32_t> p(n > 0 ? n : 1); std::vector<double> sc(n > 0 ? n : 1);
+    vslam_detail::check(vslam_read_candidates(sys, 0, level, p.data(), sc.data(), (int)p.size(), &n));
+    std::vector<Candidate> out(n);
+    for (int i = 0; i < n; i++) out[i] = {(int)(p[i] & 0xFFFF), (int)(p[i] >> 16), sc[i]};
+    return out;
+  }
   std::vector<std::pair<int, int>> Corners(int level) const {     // Level::vCorners
     std::vector<uint32_t> c(1 << 20); int n = 0;
     vslam_detail::check(vslam_read_corners(sys, 0, level, c.data(), (int)c.size(), &n));
@@ -96,6 +108,8 @@ class MapMaker {
   int QueueSize() { return 0; }
   void BundleAdjustRecent() { vslam_detail::check(vslam_bundle_adjust_recent(mMap.sys)); }             // :801-851
   void BundleAdjustAll() { vslam_detail::check(vslam_bundle_adjust_all(mMap.sys)); }                   // :776-798
+  // :393-422, all four levels of the current candidate lists against keyframe nKeyFrame's measurements (< 0: the tracker's)
+  void ThinCandidates(int nKeyFrame = -1) { vslam_detail::check(vslam_thin_candidates(mMap.sys, nKeyFrame)); }
  protected:
   Map& mMap;
   ATANCamera mCamera;

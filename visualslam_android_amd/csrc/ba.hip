@@ -13,7 +13,7 @@ struct BaPool {            // device arrays for N problems
   Pose* cam_pose; Pose* cam_new; int* cam_fixed; int* cam_row; double* cam_U; double* cam_ea;
   double* pt_pos; double* pt_new; double* pt_V; double* pt_eb; double* pt_Vinv; int* pt_nmeas; int* pt_nout;
   int* ms_p; int* ms_c; int* ms_state; double* ms_found; double* ms_sin; double* ms_cam; double* ms_eps; double* ms_err2;
-  double* ms_derivs;
+  double* ms_derivs; double* ms_tcam; double* ms_tfac; double* ms_teps;
   int* lut; double* S; double* E; double* cam_up; double* map_up; double* scratch; int* outl; int* free_cams;
   int* id_view; int* id_point;   // BundleAdjust translation tables (:861-864)
 };
@@ -29,7 +29,7 @@ __host__ __device__ inline BaView ba_view(const BaPool& b, int n) {
   v.pt_Vinv = b.pt_Vinv + n * P * 9; v.pt_nmeas = b.pt_nmeas + n * P; v.pt_nout = b.pt_nout + n * P;
   v.ms_p = b.ms_p + n * M; v.ms_c = b.ms_c + n * M; v.ms_state = b.ms_state + n * M; v.ms_found = b.ms_found + n * M * 2;
   v.ms_sin = b.ms_sin + n * M; v.ms_cam = b.ms_cam + n * M * 3; v.ms_eps = b.ms_eps + n * M * 2; v.ms_err2 = b.ms_err2 + n * M;
-  v.ms_derivs = b.ms_derivs + n * M * 4;
+  v.ms_derivs = b.ms_derivs + n * M * 4; v.ms_tcam = b.ms_tcam + n * M * 3; v.ms_tfac = b.ms_tfac + n * M; v.ms_teps = b.ms_teps + n * M * 2;
   v.lut = b.lut + n * C * P; v.S = b.S + n * F * F; v.E = b.E + n * F; v.cam_up = b.cam_up + n * F; v.map_up = b.map_up + n * P * 3;
   v.scratch = b.scratch + n * M; v.outl = b.outl + n * M * 2; v.free_cams = b.free_cams + n * C;
   return v;
@@ -61,7 +61,7 @@ static int pool_create(BaPool& b, std::vector<void*>& allocs, hipStream_t st, in
   PALLOC(pt_pos, n * P * 3); PALLOC(pt_new, n * P * 3); PALLOC(pt_V, n * P * 9); PALLOC(pt_eb, n * P * 3); PALLOC(pt_Vinv, n * P * 9);
   PALLOC(pt_nmeas, n * P); PALLOC(pt_nout, n * P);
   PALLOC(ms_p, n * M); PALLOC(ms_c, n * M); PALLOC(ms_state, n * M); PALLOC(ms_found, n * M * 2); PALLOC(ms_sin, n * M); PALLOC(ms_cam, n * M * 3);
-  PALLOC(ms_eps, n * M * 2); PALLOC(ms_err2, n * M); PALLOC(ms_derivs, n * M * 4);
+  PALLOC(ms_eps, n * M * 2); PALLOC(ms_err2, n * M); PALLOC(ms_derivs, n * M * 4); PALLOC(ms_tcam, n * M * 3); PALLOC(ms_tfac, n * M); PALLOC(ms_teps, n * M * 2);
   PALLOC(lut, n * C * P); PALLOC(S, n * F * F); PALLOC(E, n * F); PALLOC(cam_up, n * F); PALLOC(map_up, n * P * 3);
   PALLOC(scratch, n * M); PALLOC(outl, n * M * 2); PALLOC(free_cams, n * C); PALLOC(id_view, n * C); PALLOC(id_point, n * P);
   return VSLAM_OK;

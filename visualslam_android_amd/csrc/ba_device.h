@@ -44,6 +44,7 @@ struct BaView {          // pointers already offset to one problem
   double* pt_pos; double* pt_new; double* pt_V; double* pt_eb; double* pt_Vinv; int* pt_nmeas; int* pt_nout;
   int* ms_p; int* ms_c; int* ms_state; double* ms_found; double* ms_sin; double* ms_cam; double* ms_eps; double* ms_err2;
   double* ms_derivs;
+  double* ms_tcam; double* ms_tfac; double* ms_teps;   // FindNewError's projection of the trial state, reused by pass 1 after an accepted step
   int* lut;              // [max_cams][max_pts]
   double* S; double* E; double* cam_up; double* map_up;
   double* scratch;       // [max_meas]
@@ -265,6 +266,47 @@ __device__ __attribute__((noinline)) int ba_pass1_project(const BaView& v, const
   return nvalid;
 }
 
+// pass 1 right after an accepted step: the committed cameras / points are the trial state FindNewError has just
+// projected, so v3Cam, the radial factor (the atan) and the residual are taken from its stores instead of being
+// recomputed -- the same values, bit for bit; only the camera derivatives are still to do.
+__device__ __attribute__((noinline)) int ba_pass1_cached(const BaView& v, const BaConfig& cfg, int nm) {
+  int nvalid = 0;
+  for (int i0 = threadIdx.x; i0 < nm; i0 += BA_ILP * BA_THREADS) {
+    int st[BA_ILP]; double c[BA_ILP][3], fac[BA_ILP], e0[BA_ILP], e1[BA_ILP];
+    _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) {
+      const int i = i0 + u * BA_THREADS, ic = i < nm ? i : nm - 1;
+      st[u] = v.ms_state[ic];
+      c[u][0] = MS(ms_tcam, 0, ic); c[u][1] = MS(ms_tcam, 1, ic); c[u][2] = MS(ms_tcam, 2, ic);
+      fac[u] = v.ms_tfac[ic]; e0[u] = MS(ms_teps, 0, ic); e1[u] = MS(ms_teps, 1, ic);
+    }
+    _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) {
+      const int i = i0 + u * BA_THREADS;
+      if (i >= nm) continue;
+      double e2 = __builtin_huge_val();
+      if (st[u] != MS_ERASED) {
+        MS(ms_cam, 0, i) = c[u][0]; MS(ms_cam, 1, i) = c[u][1]; MS(ms_cam, 2, i) = c[u][2];
+        if (c[u][2] <= 0) v.ms_state[i] = MS_BAD;
+        else {
+          v.ms_state[i] = MS_OK;
+          CamProj pr;                                               // cam_project minus its atan
+          pr.cam[0] = c[u][0] / c[u][2]; pr.cam[1] = c[u][1] / c[u][2];
+          pr.r = sqrt(pr.cam[0] * pr.cam[0] + pr.cam[1] * pr.cam[1]);
+          pr.factor = fac[u]; pr.invalid = 0; pr.im[0] = 0; pr.im[1] = 0;
+          double dd[4];
+          cam_derivs(cfg.cam, pr, dd);
+          MS(ms_derivs, 0, i) = dd[0]; MS(ms_derivs, 1, i) = dd[1]; MS(ms_derivs, 2, i) = dd[2]; MS(ms_derivs, 3, i) = dd[3];
+          MS(ms_eps, 0, i) = e0[u]; MS(ms_eps, 1, i) = e1[u];
+          e2 = e0[u] * e0[u] + e1[u] * e1[u];
+          v.ms_err2[i] = e2;
+          nvalid++;
+        }
+      }
+      v.scratch[i] = e2;
+    }
+  }
+  return nvalid;
+}
+
 // FindNewError (jni/Bundle.cc:537-561): this thread's share of the objective at the trial state.
 __device__ __attribute__((noinline)) double ba_find_new_error(const BaView& v, const BaConfig& cfg, int nm, double sigma2) {
   double ne = 0.0;
@@ -282,11 +324,14 @@ __device__ __attribute__((noinline)) double ba_find_new_error(const BaView& v, c
     }
     _Pragma("unroll") for (int u = 0; u < BA_ILP_PROJ; u++) {
       if (st[u] == MS_ERASED) continue;
+      const int i = i0 + u * BA_THREADS;
       double c[3];
       pose_xform(T[u], X[u], c);
+      MS(ms_tcam, 0, i) = c[0]; MS(ms_tcam, 1, i) = c[1]; MS(ms_tcam, 2, i) = c[2];
       if (c[2] <= 0) { ne += 1.0; continue; }
       const CamProj pr = cam_project(cfg.cam, c[0] / c[2], c[1] / c[2]);
       const double e0 = (f0[u] - pr.im[0]) * sn[u], e1 = (f1[u] - pr.im[1]) * sn[u];
+      v.ms_tfac[i] = pr.factor; MS(ms_teps, 0, i) = e0; MS(ms_teps, 1, i) = e1;
       ne += tukey_objective(e0 * e0 + e1 * e1, sigma2);
     }
   }
@@ -479,7 +524,7 @@ DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
   __shared__ unsigned long long sel[1];
   __shared__ double sh_lambda, sh_factor, sh_sigma2, sh_cur_err, sh_new_err;
   __shared__ double lds_A[BA_LDS_N * (BA_LDS_N + 1)];
-  __shared__ int sh_converged, sh_hitmax, sh_counter, sh_accepted, sh_error, sh_nout;
+  __shared__ int sh_converged, sh_hitmax, sh_counter, sh_accepted, sh_error, sh_nout, sh_cache_valid;
   BaResult* R = v.res;
   const int nc = R->n_cams, np = R->n_pts, nm = R->n_meas;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -490,7 +535,7 @@ DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
     }
     R->n_free = nf;
     sh_lambda = 0.0001; sh_factor = 2.0;      // :144-145
-    sh_converged = 0; sh_hitmax = 0; sh_counter = 0; sh_accepted = 0; sh_error = 0; sh_nout = 0; sh_sigma2 = 0;
+    sh_converged = 0; sh_hitmax = 0; sh_counter = 0; sh_accepted = 0; sh_error = 0; sh_nout = 0; sh_sigma2 = 0; sh_cache_valid = 0;
     R->trials = 0;
   }
   __syncthreads();
@@ -502,7 +547,7 @@ DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
   while (!sh_converged && !sh_hitmax && !sh_error) {             // :153 (no abort signal: the map-maker runs synchronously)
     // ================= Do_LM_Step =================
     // pass 1 (:209-215): project every measurement still in the list
-    int nvalid = ba_pass1_project(v, cfg, nm);
+    int nvalid = sh_cache_valid ? ba_pass1_cached(v, cfg, nm) : ba_pass1_project(v, cfg, nm);
     nvalid = ba_block_sum_i(nvalid, ired);
     BA_STAMP(1);
     if (nvalid == 0) { if (threadIdx.x == 0) sh_error = 1; __syncthreads(); break; }
@@ -603,8 +648,8 @@ DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
     if (sh_new_err < sh_cur_err) {                                     // :503-514
       for (int j = threadIdx.x; j < nc; j += BA_THREADS) v.cam_pose[j] = v.cam_new[j];
       for (int t = threadIdx.x; t < 3 * np; t += BA_THREADS) v.pt_pos[t] = v.pt_new[t];
-      if (threadIdx.x == 0) { sh_factor = 2.0; sh_lambda *= 0.3; sh_accepted++; }   // ModifyLambda_GoodStep :609-612
-    }
+      if (threadIdx.x == 0) { sh_factor = 2.0; sh_lambda *= 0.3; sh_accepted++; sh_cache_valid = 1; }   // ModifyLambda_GoodStep :609-612
+    } else if (threadIdx.x == 0) sh_cache_valid = 0;
     __syncthreads();
     BA_STAMP(11);
     // erase the outliers in list order (:517-528): ordered compaction of the (p, c) pairs
