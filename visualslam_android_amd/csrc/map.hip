@@ -69,7 +69,9 @@ extern "C" int vslam_map_add_point(vslam_system* sys, int s, const double pos[3]
   mp.src_kf = src_keyframe; mp.src_level = src_level; mp.irx = ir_x; mp.iry = ir_y;
   TrackData td; memset(&td, 0, sizeof(td));
   td.last_warp[0] = 9999.9; td.last_warp[3] = 9999.9;   // jni/PatchFinder.cc:23
-  td.level = -1;
+  const int lvl0[2] = {-1, 0};
+  HIPCHK(hipMemcpyAsync(sys->map.pt_level + (size_t)s * P + i, &lvl0[0], sizeof(int), hipMemcpyHostToDevice, sys->stream));
+  HIPCHK(hipMemcpyAsync(sys->map.pt_flags + (size_t)s * P + i, &lvl0[1], sizeof(int), hipMemcpyHostToDevice, sys->stream));
   HIPCHK(hipMemcpyAsync(sys->map.pts + (size_t)s * P + i, &mp, sizeof(mp), hipMemcpyHostToDevice, sys->stream));
   HIPCHK(hipMemcpyAsync(sys->map.td + (size_t)s * P + i, &td, sizeof(td), hipMemcpyHostToDevice, sys->stream));
   st.n_points = i + 1;
@@ -138,10 +140,15 @@ extern "C" int vslam_map_add_points(vslam_system* sys, int s, int n, const doubl
     if (src_keyframe[i] < 0 || src_keyframe[i] >= st.n_kf || src_level[i] < 0 || src_level[i] >= NLEV) { vslam_set_error("map_add_points: bad entry %d", i); return VSLAM_E_INVALID; }
     for (int q = 0; q < 3; q++) { mp[i].pos[q] = pos[3 * i + q]; mp[i].right[q] = right[3 * i + q]; mp[i].down[q] = down[3 * i + q]; }
     mp[i].src_kf = src_keyframe[i]; mp[i].src_level = src_level[i]; mp[i].irx = ir_xy[2 * i]; mp[i].iry = ir_xy[2 * i + 1];
-    td[i].last_warp[0] = 9999.9; td[i].last_warp[3] = 9999.9; td[i].level = -1;   // jni/PatchFinder.cc:23
+    td[i].last_warp[0] = 9999.9; td[i].last_warp[3] = 9999.9;   // jni/PatchFinder.cc:23
   }
   HIPCHK(hipMemcpy(sys->map.pts + (size_t)s * P + st.n_points, mp.data(), sizeof(MapPointDev) * n, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(sys->map.td + (size_t)s * P + st.n_points, td.data(), sizeof(TrackData) * n, hipMemcpyHostToDevice));
+  {
+    std::vector<int> lv(n, -1), fl(n, 0);
+    HIPCHK(hipMemcpy(sys->map.pt_level + (size_t)s * P + st.n_points, lv.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(sys->map.pt_flags + (size_t)s * P + st.n_points, fl.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+  }
   st.n_points += n;
   r = put_state(sys, s, &st); if (r) return r;
   return st.n_points;
@@ -304,12 +311,17 @@ extern "C" int vslam_get_point_tracks(vslam_system* sys, int s, int* found, int*
   int r = get_state(sys, s, &st); if (r) return r;
   const int n = st.n_points < cap ? st.n_points : cap;
   std::vector<TrackData> td(n > 0 ? n : 1);
-  if (n > 0) HIPCHK(hipMemcpy(td.data(), sys->map.td + (size_t)s * sys->p.max_points, sizeof(TrackData) * n, hipMemcpyDeviceToHost));
+  std::vector<int> lv(n > 0 ? n : 1), fl(n > 0 ? n : 1);
+  if (n > 0) {
+    HIPCHK(hipMemcpy(td.data(), sys->map.td + (size_t)s * sys->p.max_points, sizeof(TrackData) * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(lv.data(), sys->map.pt_level + (size_t)s * sys->p.max_points, sizeof(int) * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(fl.data(), sys->map.pt_flags + (size_t)s * sys->p.max_points, sizeof(int) * n, hipMemcpyDeviceToHost));
+  }
   for (int i = 0; i < n; i++) {
-    if (found) found[i] = (td[i].flags & TDF_FOUND) ? 1 : 0;
-    if (searched) searched[i] = (td[i].flags & TDF_SEARCHED) ? 1 : 0;
-    if (level) level[i] = td[i].level;
-    if (subpix) subpix[i] = (td[i].flags & TDF_SUBPIX) ? 1 : 0;
+    if (found) found[i] = (fl[i] & TDF_FOUND) ? 1 : 0;
+    if (searched) searched[i] = (fl[i] & TDF_SEARCHED) ? 1 : 0;
+    if (level) level[i] = lv[i];
+    if (subpix) subpix[i] = (fl[i] & TDF_SUBPIX) ? 1 : 0;
     if (vfound) { vfound[2 * i] = td[i].vfound[0]; vfound[2 * i + 1] = td[i].vfound[1]; }
     if (image) { image[2 * i] = td[i].image[0]; image[2 * i + 1] = td[i].image[1]; }
   }
@@ -375,6 +387,8 @@ extern "C" int vslam_get_template(vslam_system* sys, int s, int point, uint8_t* 
   if (tmpl) HIPCHK(hipMemcpy(tmpl, sys->map.tmpl + ((size_t)s * P + point) * TMPL_PITCH, PS * PS, hipMemcpyDeviceToHost));
   if (sum) *sum = td.tsum;
   if (sumsq) *sumsq = td.tsumsq;
-  if (bad) *bad = (td.flags & TDF_TMPL_BAD) ? 1 : 0;
-  return (td.flags & TDF_HAVE_LAST) ? 1 : 0;
+  int fl = 0;
+  HIPCHK(hipMemcpy(&fl, sys->map.pt_flags + (size_t)s * P + point, sizeof(int), hipMemcpyDeviceToHost));
+  if (bad) *bad = (fl & TDF_TMPL_BAD) ? 1 : 0;
+  return (fl & TDF_HAVE_LAST) ? 1 : 0;
 }

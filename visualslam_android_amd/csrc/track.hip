@@ -20,8 +20,8 @@
 // ---------------------------------------------------------------------------------------------------------------
 // TrackerData::Project (jni/TrackerData.h:69-87).  Returns true when Cam.Project ran (pr valid).
 template <class T>
-DEVFN bool td_project(T& td, const double* pos, const Pose& pose, const CamModel& cam, CamProj& pr) {
-  td.flags &= ~TDF_IN_IMAGE;
+DEVFN bool td_project(T& td, int& flags, const double* pos, const Pose& pose, const CamModel& cam, CamProj& pr) {
+  flags &= ~TDF_IN_IMAGE;
   double c[3];
   pose_xform(pose, pos, c);
   td.cam[0] = c[0]; td.cam[1] = c[1]; td.cam[2] = c[2];
@@ -32,17 +32,17 @@ DEVFN bool td_project(T& td, const double* pos, const Pose& pose, const CamModel
   td.image[0] = pr.im[0]; td.image[1] = pr.im[1];
   if (pr.invalid) return true;
   if (td.image[0] < 0 || td.image[1] < 0 || td.image[0] > cam.size[0] || td.image[1] > cam.size[1]) return true;
-  td.flags |= TDF_IN_IMAGE;
+  flags |= TDF_IN_IMAGE;
   return true;
 }
 
 // TrackerData::ProjectAndDerivs (:98-102); derivatives refreshed only for found points whose projection ran
 // (see oracle/tracker.cpp td_project_and_derivs for the one deliberate deviation).
 template <class T>
-DEVFN void td_project_and_derivs(T& td, const double* pos, const Pose& pose, const CamModel& cam) {
+DEVFN void td_project_and_derivs(T& td, int& flags, const double* pos, const Pose& pose, const CamModel& cam) {
   CamProj pr;
-  const bool projected = td_project(td, pos, pose, cam, pr);
-  if ((td.flags & TDF_FOUND) && projected) cam_derivs(cam, pr, td.derivs);
+  const bool projected = td_project(td, flags, pos, pose, cam, pr);
+  if ((flags & TDF_FOUND) && projected) cam_derivs(cam, pr, td.derivs);
 }
 
 // TrackerData::CalcJacobian (:107-122)
@@ -82,11 +82,14 @@ __global__ __launch_bounds__(TRK_THREADS) void k_pvs(MapDev m, TrackParams tp) {
   if (i >= st->n_points) return;
   const MapPointDev& p = m.pts[(size_t)s * tp.max_points + i];
   TrackData& td = m.td[(size_t)s * tp.max_points + i];
-  td.level = -1;
+  int& tdlevel = m.pt_level[(size_t)s * tp.max_points + i];
+  tdlevel = -1;
   if (p.bad) return;
+  int flags = m.pt_flags[(size_t)s * tp.max_points + i];
+  int& tdflags = flags;
   CamProj pr;
-  td_project(td, p.pos, pred, tp.cam, pr);                             // :379-381
-  if (!(td.flags & TDF_IN_IMAGE)) return;
+  td_project(td, flags, p.pos, pred, tp.cam, pr);                      // :379-381
+  if (!(flags & TDF_IN_IMAGE)) { m.pt_flags[(size_t)s * tp.max_points + i] = flags; return; }
   cam_derivs(tp.cam, pr, td.derivs);                               // :384 GetDerivsUnsafe
   // CalcSearchLevelAndWarpMatrix, jni/PatchFinder.cc:31-68
   const double ooz = 1.0 / td.cam[2];
@@ -101,9 +104,9 @@ __global__ __launch_bounds__(TRK_THREADS) void k_pvs(MapDev m, TrackParams tp) {
   double det = td.warp_inv[0] * td.warp_inv[3] - td.warp_inv[1] * td.warp_inv[2];
   int level = 0;
   while (det > 3 && level < NLEV - 1) { level++; det *= 0.25; }
-  if (det > 3 || det < 0.25) { td.flags |= TDF_TMPL_BAD; return; }   // mbTemplateBad = true; return -1
-  td.flags &= ~(TDF_SEARCHED | TDF_FOUND);                         // :389-390
-  td.level = level;
+  if (det > 3 || det < 0.25) { m.pt_flags[(size_t)s * tp.max_points + i] = tdflags | TDF_TMPL_BAD; return; }   // mbTemplateBad = true; return -1
+  m.pt_flags[(size_t)s * tp.max_points + i] = tdflags & ~(TDF_SEARCHED | TDF_FOUND);   // :389-390
+  tdlevel = level;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(TRK_THREADS) void k_plan(MapDev m, TrackParams tp, 
     const int n = st->n_points;
     for (int base = 0; base < n; base += TRK_THREADS) {             // avPVS[l] in map order (:369-392)
       const int i = base + threadIdx.x;
-      const int lvl = i < n ? td[i].level : -1;
+      const int lvl = i < n ? m.pt_level[(size_t)s * P + i] : -1;
       unsigned long long b[NLEV];
       for (int l = 0; l < NLEV; l++) { b[l] = __ballot(lvl == l); if (lane == 0) wcnt[wave][l] = __popcll(b[l]); }
       __syncthreads();
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(TRK_THREADS) void k_plan(MapDev m, TrackParams tp, 
         else idx = pvs[0 * P + (k - r2 - r1)];
         its = 0;
       }
-      if (e < n3 || did_coarse) td_project_and_derivs(td[idx], pts[idx].pos, pose, tp.cam);   // :503-504, :529-532
+      if (e < n3 || did_coarse) td_project_and_derivs(td[idx], m.pt_flags[(size_t)s * P + idx], pts[idx].pos, pose, tp.cam);   // :503-504, :529-532
       slist[e] = make_int2(idx, its);
       ilist[nit + e] = idx;
     }
@@ -233,12 +236,14 @@ __global__ __launch_bounds__(64) void k_search(MapDev m, TrackParams tp, SearchA
   const int idx = ent.x, nSubPixIts = ent.y;
   const int nRangeL0 = stage == 0 ? st->coarse_range : st->fine_range;
   TrackData& td = m.td[(size_t)s * tp.max_points + idx];
+  int& tdlevel = m.pt_level[(size_t)s * tp.max_points + idx];
+  int& tdflags = m.pt_flags[(size_t)s * tp.max_points + idx];
   const MapPointDev& p = m.pts[(size_t)s * tp.max_points + idx];
   uint8_t* gtmpl = m.tmpl + ((size_t)s * tp.max_points + idx) * TMPL_PITCH;
   __shared__ uint8_t tmpl[TMPL_PITCH];
   __shared__ int cand[64];
-  const int level = td.level, scale = 1 << level;
-  int flags = td.flags;
+  const int level = tdlevel, scale = 1 << level;
+  int flags = tdflags;
 
   // ---- MakeTemplateCoarseCont, jni/PatchFinder.cc:79-125 ----
   double inv[4];
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(64) void k_search(MapDev m, TrackParams tp, SearchA
   }
   __syncthreads();
   if (flags & TDF_TMPL_BAD) {                                        // jni/Tracker.cc:637-640
-    if (lane == 0) td.flags = flags & ~(TDF_IN_IMAGE | TDF_FOUND);
+    if (lane == 0) tdflags = flags & ~(TDF_IN_IMAGE | TDF_FOUND);
     return;
   }
   if (lane == 0) atomicAdd(&st->attempted[level], 1);               // :641
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(64) void k_search(MapDev m, TrackParams tp, SearchA
   flags |= TDF_SEARCHED;                                             // :645
   if (lane == 0 && nEval) atomicAdd(&st->n_zmssd, (unsigned long long)nEval);
   if (!(nBestSSD < tp.max_ssd)) {                                    // :646-649
-    if (lane == 0) td.flags = flags & ~TDF_FOUND;
+    if (lane == 0) tdflags = flags & ~TDF_FOUND;
     return;
   }
   const uint32_t bc = corners[bestIdx];
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(64) void k_search(MapDev m, TrackParams tp, SearchA
   if (nSubPixIts <= 0) {                                             // :668-671
     flags &= ~TDF_SUBPIX;
     if (lane == 0) {
-      td.flags = flags; td.sqrt_inv_noise = 1.0 / scale; td.vfound[0] = coarse[0]; td.vfound[1] = coarse[1];
+      tdflags = flags; td.sqrt_inv_noise = 1.0 / scale; td.vfound[0] = coarse[0]; td.vfound[1] = coarse[1];
       atomicAdd(&st->found[level], 1);
     }
     return;
@@ -441,9 +446,9 @@ __global__ __launch_bounds__(64) void k_search(MapDev m, TrackParams tp, SearchA
     if (u0 * u0 + u1 * u1 < 0.03 * 0.03) { converged = true; break; }
   }
   if (lane == 0) {
-    if (!converged) td.flags = flags & ~TDF_FOUND;                   // :658-666 un-finds the point
+    if (!converged) tdflags = flags & ~TDF_FOUND;                   // :658-666 un-finds the point
     else {
-      td.flags = flags; td.sqrt_inv_noise = 1.0 / scale; td.vfound[0] = sub0; td.vfound[1] = sub1;
+      tdflags = flags; td.sqrt_inv_noise = 1.0 / scale; td.vfound[0] = sub0; td.vfound[1] = sub1;
       atomicAdd(&st->found[level], 1);
     }
   }
@@ -474,10 +479,12 @@ __global__ __launch_bounds__(64) void k_search8(MapDev m, TrackParams tp, Search
   const int idx = ent.x, nSubPixIts = ent.y;
   const int nRangeL0 = stage == 0 ? st->coarse_range : st->fine_range;
   TrackData& td = m.td[(size_t)s * tp.max_points + idx];
+  int& tdlevel = m.pt_level[(size_t)s * tp.max_points + idx];
+  int& tdflags = m.pt_flags[(size_t)s * tp.max_points + idx];
   const MapPointDev& p = m.pts[(size_t)s * tp.max_points + idx];
   uint8_t* gtmpl = m.tmpl + ((size_t)s * tp.max_points + idx) * TMPL_PITCH;
-  const int level = act ? td.level : 0, scale = 1 << level;
-  int flags = td.flags;
+  const int level = act ? tdlevel : 0, scale = 1 << level;
+  int flags = tdflags;
 
   // ---- MakeTemplateCoarseCont, jni/PatchFinder.cc:79-125 ----
   double inv[4];
@@ -541,7 +548,7 @@ __global__ __launch_bounds__(64) void k_search8(MapDev m, TrackParams tp, Search
     tsum = td.tsum; tsumsq = td.tsumsq;
   }
   if (act && (flags & TDF_TMPL_BAD)) {                               // jni/Tracker.cc:637-640
-    if (lead) td.flags = flags & ~(TDF_IN_IMAGE | TDF_FOUND);
+    if (lead) tdflags = flags & ~(TDF_IN_IMAGE | TDF_FOUND);
     act = false;
   }
   for (int l = 0; l < NLEV; l++) {                                   // manMeasAttempted[level]++ (:641), one atomic per wave
@@ -618,14 +625,14 @@ __global__ __launch_bounds__(64) void k_search8(MapDev m, TrackParams tp, Search
     if (lane == 0 && tot) atomicAdd(&st->n_zmssd, (unsigned long long)tot);
   }
   bool found = act && nBestSSD < tp.max_ssd;
-  if (act && !found && lead) td.flags = flags & ~TDF_FOUND;          // :646-649
+  if (act && !found && lead) tdflags = flags & ~TDF_FOUND;          // :646-649
   const uint32_t bc = found ? corners[bestIdx] : 0u;
   const double coarse[2] = {level_zero_pos((double)(bc & 0xFFFF), level), level_zero_pos((double)(bc >> 16), level)};
   if (found) flags |= TDF_FOUND;
   const bool dosub = found && nSubPixIts > 0;                        // refined by k_subpix8, which also counts it as found
   if (found) {                                                       // :668-671
     flags = dosub ? (flags | TDF_SUBPIX) : (flags & ~TDF_SUBPIX);
-    if (lead) { td.flags = flags; td.sqrt_inv_noise = 1.0 / scale; td.vfound[0] = coarse[0]; td.vfound[1] = coarse[1]; }
+    if (lead) { tdflags = flags; td.sqrt_inv_noise = 1.0 / scale; td.vfound[0] = coarse[0]; td.vfound[1] = coarse[1]; }
   }
   for (int l = 0; l < NLEV; l++) {                                   // manMeasFound[level]++ (:652)
     const int c = __popcll(__ballot(found && !dosub && lead && level == l));
@@ -650,10 +657,12 @@ __global__ __launch_bounds__(64) void k_subpix8(MapDev m, TrackParams tp, Search
   const int2 ent = e < nsub ? m.search_list[(size_t)s * tp.max_points + e] : make_int2(0, 0);
   const int idx = ent.x, nSubPixIts = ent.y;
   TrackData& td = m.td[(size_t)s * tp.max_points + idx];
-  int flags = td.flags;
+  int& tdlevel = m.pt_level[(size_t)s * tp.max_points + idx];
+  int& tdflags = m.pt_flags[(size_t)s * tp.max_points + idx];
+  int flags = tdflags;
   const bool dosub = e < nsub && nSubPixIts > 0 && (flags & TDF_FOUND) && (flags & TDF_SUBPIX);
   if (!__any(dosub)) return;
-  const int level = dosub ? td.level : 0, scale = 1 << level;
+  const int level = dosub ? tdlevel : 0, scale = 1 << level;
   const int rows = a.h[level], cols = a.w[level];
   const uint8_t* img = a.img[level] + (size_t)s * a.img_sstride[level];
   const int ip = a.img_pitch[level];
@@ -714,7 +723,7 @@ __global__ __launch_bounds__(64) void k_subpix8(MapDev m, TrackParams tp, Search
     }
   }
   if (dosub && lead) {
-    if (!converged) td.flags = flags & ~TDF_FOUND;                   // :658-666 un-finds the point
+    if (!converged) tdflags = flags & ~TDF_FOUND;                   // :658-666 un-finds the point
     else { td.vfound[0] = sub0; td.vfound[1] = sub1; }
   }
   for (int l = 0; l < NLEV; l++) {                                   // manMeasFound[level]++ (:652)
@@ -890,7 +899,7 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose(MapDev m, TrackParams tp,
   for (int e = threadIdx.x; e < n; e += POSE_THREADS) {             // gather
     const int idx = ilist[e];
     const TrackData& t = td[idx];
-    ws.i[e] = t.flags; ws.i[P + e] = idx;
+    ws.i[e] = m.pt_flags[(size_t)s * P + idx]; ws.i[P + e] = idx;
     for (int i = 0; i < 3; i++) ws.d[(0 + i) * P + e] = t.cam[i];
     for (int i = 0; i < 2; i++) { ws.d[(3 + i) * P + e] = t.image[i]; ws.d[(9 + i) * P + e] = t.vfound[i]; }
     for (int i = 0; i < 4; i++) ws.d[(5 + i) * P + e] = t.derivs[i];
@@ -907,7 +916,7 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose(MapDev m, TrackParams tp,
         PoseItem t;
         item_load(t, ws, e);
         if (iter != 0) {
-          if (nonlinear) td_project_and_derivs(t, pts[t.idx].pos, pose, tp.cam);
+          if (nonlinear) td_project_and_derivs(t, t.flags, pts[t.idx].pos, pose, tp.cam);
           else {                                                     // LinearUpdate, jni/TrackerData.h:125-131
             double jac[12], a = 0, b = 0;
             td_calc_jacobian(t, jac);                                // m26Jacobian of the last non-linear iteration
@@ -935,7 +944,7 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose(MapDev m, TrackParams tp,
   POSE_STAMP(8);
   for (int e = threadIdx.x; e < n; e += POSE_THREADS) {             // scatter what the iterations changed
     TrackData& t = td[ws.i[P + e]];
-    t.flags = ws.i[e];
+    m.pt_flags[(size_t)s * P + ws.i[P + e]] = ws.i[e];
     for (int i = 0; i < 3; i++) t.cam[i] = ws.d[(0 + i) * P + e];
     for (int i = 0; i < 2; i++) t.image[i] = ws.d[(3 + i) * P + e];
     for (int i = 0; i < 4; i++) t.derivs[i] = ws.d[(5 + i) * P + e];
@@ -952,10 +961,11 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose(MapDev m, TrackParams tp,
   for (int e = threadIdx.x; e < n; e += POSE_THREADS) {
     const int idx = ilist[e];
     const TrackData& t = td[idx];
-    if (!(t.flags & TDF_FOUND)) continue;
+    const int tflags = m.pt_flags[(size_t)s * P + idx];
+    if (!(tflags & TDF_FOUND)) continue;
     MeasDev mm;
     mm.root[0] = t.vfound[0]; mm.root[1] = t.vfound[1];
-    mm.valid = 1; mm.level = (signed char)t.level; mm.subpix = (t.flags & TDF_SUBPIX) ? 1 : 0; mm.source = 0 /* SRC_TRACKER */; mm.pad = 0;
+    mm.valid = 1; mm.level = (signed char)m.pt_level[(size_t)s * P + idx]; mm.subpix = (tflags & TDF_SUBPIX) ? 1 : 0; mm.source = 0 /* SRC_TRACKER */; mm.pad = 0;
     cm[idx] = mm;
     const double z = t.cam[2];
     dSum += z; dSumSq += z * z; nNum++;
@@ -1044,7 +1054,7 @@ int trk_alloc(vslam_system* sys) {
   TALLOC(m.kf_meas, S * K * P); TALLOC(m.cur_meas, S * P);
   TALLOC(m.kf_pose, S * K); TALLOC(m.kf_fixed, S * K); TALLOC(m.kf_depth, S * K * 2);
   for (int l = 0; l < NLEV; l++) TALLOC(m.kf_img[l], S * K * (size_t)sys->geom[l].pitch * sys->geom[l].h);
-  TALLOC(m.st, S); TALLOC(m.pvs_list, S * NLEV * P); TALLOC(m.search_list, S * P); TALLOC(m.iter_list, S * P);
+  TALLOC(m.st, S); TALLOC(m.pvs_list, S * NLEV * P); TALLOC(m.search_list, S * P); TALLOC(m.iter_list, S * P); TALLOC(m.pt_level, S * P); TALLOC(m.pt_flags, S * P);
   TALLOC(m.pose_ws, S * POSE_WS_COMPS * P); TALLOC(m.pose_wsi, S * 2 * P);
   trk_fill_params(p, sys->tp);
   return VSLAM_OK;

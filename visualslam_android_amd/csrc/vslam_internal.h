@@ -70,7 +70,7 @@ struct TrackData {          // TrackerData (jni/TrackerData.h:36-66) + persisten
   double cam[3], image[2], derivs[4];
   double vfound[2], sqrt_inv_noise;      // the 2x6 Jacobian and the residual live in k_pose's registers only
   double warp_inv[4], last_warp[4];
-  int level, flags, tsum, tsumsq;
+  int tsum, tsumsq;                      // nSearchLevel and the TDF_* flags live in MapDev::pt_level / pt_flags (coalesced)
 };
 
 struct MeasDev {            // Measurement, jni/KeyFrame.h:46-51 (one slot per keyframe x map point)
@@ -121,6 +121,8 @@ struct MapDev {             // device pointers of the map + tracker of all strea
   TrackerState* st;         // [S]
   int* pvs_list;            // [S][NLEV][max_points]
   int2* search_list;        // [S][max_points]  (point index, sub-pixel iterations)
+  int* pt_level;            // [S][max_points]  PatchFinder::mnSearchLevel of the frame, -1 = not in the PVS (read by every planning pass)
+  int* pt_flags;            // [S][max_points]  TDF_* flags
   int* iter_list;           // [S][max_points]  vIterationSet
   double* pose_ws;          // [S][POSE_WS_COMPS][max_points]  k_pose working set, component-major, indexed by iteration-set entry
   int* pose_wsi;            // [S][2][max_points]  flags, map point index
