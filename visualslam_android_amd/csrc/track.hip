@@ -774,16 +774,11 @@ DEVFN void item_store(const PoseItem& it, const PoseWs& w, int e, bool all) {   
 }
 
 // CalcPoseUpdate, jni/Tracker.cc:683-774 (Tukey).  All threads of the workgroup call it; result in up[6] (LDS).
-DEVFN void calc_pose_update(const PoseWs& ws, MapPointDev* pts, int n, int nvalid_thread, const TrackParams& tp,
+DEVFN void calc_pose_update(const PoseWs& ws, MapPointDev* pts, int n, int nvalid, const TrackParams& tp,
                             double dOverrideSigma, bool bMarkOutliers, double* sortbuf, double* red /* [waves][28] */,
                             double* up /* [6] */, int* icnt, int* hist /* [768] */, unsigned long long* sel /* [1] */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int nvalid = nvalid_thread;                                        // residuals are already in sortbuf (k_pose)
-  nvalid = wave_sum_i(nvalid);
-  if (lane == 0) icnt[wave] = nvalid;
-  __syncthreads();
-  nvalid = 0;
-  for (int w = 0; w < POSE_WAVES; w++) nvalid += icnt[w];
+  // nvalid = number of found entries: fixed for the whole launch, counted once by k_pose; residuals are in sortbuf
   if (nvalid == 0) {                                                // :712-716
     if (threadIdx.x < 6) up[threadIdx.x] = 0.0;
     __syncthreads();
@@ -896,6 +891,7 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose(MapDev m, TrackParams tp,
   if (blockIdx.x == 0 && threadIdx.x == 0) g_pose_prof[15] = clock64();
 #endif
   const PoseWs ws = {m.pose_ws + (size_t)s * POSE_WS_COMPS * P, m.pose_wsi + (size_t)s * 2 * P, P};
+  int nfound_thread = 0;
   for (int e = threadIdx.x; e < n; e += POSE_THREADS) {             // gather
     const int idx = ilist[e];
     const TrackData& t = td[idx];
@@ -904,12 +900,16 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose(MapDev m, TrackParams tp,
     for (int i = 0; i < 2; i++) { ws.d[(3 + i) * P + e] = t.image[i]; ws.d[(9 + i) * P + e] = t.vfound[i]; }
     for (int i = 0; i < 4; i++) ws.d[(5 + i) * P + e] = t.derivs[i];
     ws.d[11 * P + e] = t.sqrt_inv_noise;
+    if (ws.i[e] & TDF_FOUND) nfound_thread++;
   }
+  nfound_thread = wave_sum_i(nfound_thread);
+  if ((threadIdx.x & 63) == 0) icnt[threadIdx.x >> 6] = nfound_thread;
   __syncthreads();
+  int nvalid_total = 0;
+  for (int w = 0; w < POSE_WAVES; w++) nvalid_total += icnt[w];
   POSE_STAMP(0);
   for (int iter = 0; iter < 10; iter++) {                            // coarse :466-488, fine :543-577
     const bool nonlinear = stage == 0 || iter == 0 || iter == 4 || iter == 9;
-    int nvalid = 0;
     for (int e = threadIdx.x; e < n; e += POSE_THREADS) {
       double e2 = __builtin_huge_val();
       if (ws.i[e] & TDF_FOUND) {
@@ -929,13 +929,12 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose(MapDev m, TrackParams tp,
         const double e0 = (t.vfound[0] - t.image[0]) * t.sqrt_inv_noise;   // v2Error_CovScaled, :707
         const double e1 = (t.vfound[1] - t.image[1]) * t.sqrt_inv_noise;
         e2 = e0 * e0 + e1 * e1;
-        nvalid++;
       }
       sortbuf[e] = e2;
     }
     POSE_STAMP(1);
     const double override_sigma = iter > 5 ? (stage == 0 ? 1.0 : 16.0) : 0.0;
-    calc_pose_update(ws, pts, n, nvalid, tp, override_sigma, stage == 1 && iter == 9, sortbuf, red, up, icnt, hist, sel);
+    calc_pose_update(ws, pts, n, nvalid_total, tp, override_sigma, stage == 1 && iter == 9, sortbuf, red, up, icnt, hist, sel);
     if (threadIdx.x == 0) pose = pose_mul(se3_exp(up), pose);        // :487 / :573
     if (threadIdx.x < 6) last_up[threadIdx.x] = up[threadIdx.x];
     __syncthreads();
