@@ -1,4 +1,5 @@
 """ctypes binding of include/vslam_c.h (libvslam_hip.so).  No compute happens in Python."""
+import threading
 import ctypes as C
 import os
 
@@ -107,8 +108,19 @@ SYMBOLS = {
 }
 
 
+_load_lock = threading.RLock()
+
+
 def load_library(path=None):
     """Load libvslam_hip.so and bind every declared symbol.  Raises if the extension is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    with _load_lock:                           # feeders are created from a thread pool: bind exactly one CDLL object
+        return _load_library_locked(path)
+
+
+def _load_library_locked(path):
     global _lib
     if _lib is not None and path is None:
         return _lib

@@ -2,13 +2,14 @@
 
 The feeder replaces the reference's camera/UI plumbing and map bootstrap (both out of scope); it is host code.
 """
+import threading
 import ctypes as C
 
 import numpy as np
 
 from . import capi
 
-_bound = False
+_bound = None
 FEEDER_SYMBOLS = {
     "vslam_feeder_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double), C.c_uint64, C.c_int, C.POINTER(C.c_void_p)]),
     "vslam_feeder_destroy": (C.c_int, [C.c_void_p]),
@@ -21,15 +22,19 @@ FEEDER_SYMBOLS = {
 REF_CAM = (0.841906, 1.10893, 0.505171, 0.470265, -0.0133843)  # jni/ATANCamera.cc:20-24
 
 
+_bind_lock = threading.Lock()
+
+
 def _lib():
     global _bound
     lib = capi.load_library()
-    if not _bound:
-        for name, (res, args) in FEEDER_SYMBOLS.items():
-            fn = getattr(lib, name)
-            fn.restype = res
-            fn.argtypes = args
-        _bound = True
+    with _bind_lock:                           # Feeder objects are built from thread pools (bench.py)
+        if _bound is not lib:
+            for name, (res, args) in FEEDER_SYMBOLS.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _bound = lib
     return lib
 
 
