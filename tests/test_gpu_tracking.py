@@ -51,7 +51,7 @@ def compare_frame(o, g, s, tag, drift=None, tight=None):
     assert np.abs(np.array(so.velocity[:]) - np.array(sg.velocity[:])).max() < tight
 
 
-@pytest.mark.parametrize("w,h,patch,n_frames", [(640, 480, 11, 24), (640, 480, 8, 6), (320, 240, 11, 6)])
+@pytest.mark.parametrize("w,h,patch,n_frames", [(640, 480, 11, 24), (640, 480, 8, 6), (320, 240, 11, 6), (1280, 720, 8, 3)])
 def test_track_frame_sequence_matches_oracle(w, h, patch, n_frames):
     f, m, frames = make_scene(w, h, seed=1234, n_frames=n_frames)
     vp = capi.default_params(w, h, 1, patch_size=patch)
