@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--ba-delay", type=int, default=int(os.environ.get("VSLAM_BENCH_BA_DELAY", 12)),
                     help="vslam_params.ba_delay_frames: 0 = synchronous map-maker; D > 0 = Bundle::Compute on its own HIP stream, applied D frames later")
+    ap.add_argument("--use-sbi", type=int, default=int(os.environ.get("VSLAM_BENCH_USE_SBI", 0)),
+                    help="vslam_params.use_sbi: 1 = SmallBlurryImage rotation prior in the motion model (the reference's gvnUseSBI)")
     ap.add_argument("--no-events", action="store_true", help="skip the per-stage HIP events in the timed region")
     args = ap.parse_args()
     rank, world, local_rank = dist_env()
@@ -140,7 +142,7 @@ def main():
     NS = max(1, min(args.systems, S))
     assert S % NS == 0, "--streams must be a multiple of --systems"
     Sk = S // NS
-    vpk = capi.default_params(W, H, Sk, patch_size=args.patch, device=local_rank, ba_delay_frames=args.ba_delay)
+    vpk = capi.default_params(W, H, Sk, patch_size=args.patch, device=local_rank, ba_delay_frames=args.ba_delay, use_sbi=args.use_sbi)
     systems = [capi.System(vpk) for _ in range(NS)]
 
     def sys_of(s):
@@ -201,6 +203,23 @@ def main():
             for k_, v_ in ms.items():
                 stage_ms[k_] = stage_ms.get(k_, 0.0) + v_
     st1 = [state(s) for s in range(S)]
+
+    # ---- SURVEY 8(f) row 1, outside the timed region: MakeKeyFrame_Rest (non-max + Shi-Tomasi candidates) and
+    #      ThinCandidates of the last frame, all streams; not part of `value` (nothing on the built path consumes them yet)
+    rest_ms = None
+    try:
+        sync_all()
+        t_r = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            for sy in systems:
+                sy.make_keyframe_rest(70.0)
+                sy.thin_candidates(-1)
+        sync_all()
+        rest_ms = 1e3 * (time.perf_counter() - t_r) / reps
+        n_cand = [len(systems[0].read_candidates(0, l)[0]) for l in range(4)]
+    except Exception as e:                     # noqa: BLE001 - extra information only
+        n_cand = str(e)
 
     # ---- per-stream workload statistics (for the algorithmic-byte formulas) ---------------------------------------------
     zm = float(np.mean([(b.n_zmssd - a.n_zmssd) / K for a, b in zip(st0, st1)]))
@@ -263,7 +282,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: %dx%d 4-level FAST-10 + %dx%d PatchFinder ZMSSD search, TrackMap pose update, "
                                    "AddKeyFrame + BundleAdjustRecent on keyframe frames" % (W, H, args.patch, args.patch),
-                       "streams_per_gpu": S, "systems_per_gpu": NS, "ba_delay_frames": args.ba_delay, "patch_size": args.patch, "corners_l0_per_frame": ncorn,
+                       "streams_per_gpu": S, "systems_per_gpu": NS, "ba_delay_frames": args.ba_delay, "use_sbi": args.use_sbi, "patch_size": args.patch, "corners_l0_per_frame": ncorn,
                        "patches_attempted_per_frame": round(att, 1), "patches_found_per_frame": round(fnd, 1),
                        "zmssd_evals_per_frame": round(zm, 1), "keyframes_added_per_stream": kf_adds,
                        "ba_trials_per_stream": ba_trials, "streams_tracking_good": good, "setup_seconds": round(setup_s, 1)},
@@ -272,6 +291,8 @@ def main():
                              "sample": "oracle TrackFrame+BA on the first %d frames of stream 0 (same frames, same map)" % n_cpu},
             "stages": stages,
             "parity_pose_maxdiff_stream0": pose_diff,
+            "next_rows": {"make_keyframe_rest_plus_thin_ms_per_launch": None if rest_ms is None else round(rest_ms, 4),
+                          "candidates_left_stream0": n_cand},
         }
         print(json.dumps(out))
     if world > 1:

@@ -60,7 +60,7 @@ typedef struct vslam_params {
   double coarse_min_vel;           /* jni/Tracker.cc:410: 0.006 */
   int fine_subpix_its;             /* jni/Tracker.cc:505: 8 (level 3 only) */
   double wls_prior;                /* jni/Tracker.cc:734: 100 */
-  int use_sbi;                     /* jni/Tracker.cc:88 gvnUseSBI: reference 1; 0 here (SBI is a "next" row) */
+  int use_sbi;                     /* jni/Tracker.cc:88 gvnUseSBI (reference 1): SmallBlurryImage rotation prior in the motion model; default 0 */
   int min_frames_between_kf;       /* jni/Tracker.cc:128: 20 */
   double max_kf_dist_wiggle_mult;  /* jni/MapMaker.cc:768: 0.2 */
   double wiggle_scale;             /* jni/MapMaker.cc:57: 0.1 */
@@ -119,6 +119,9 @@ int vslam_make_keyframe_rest(vslam_system* sys, double min_shi_tomasi_score);
 int vslam_thin_candidates(vslam_system* sys, int keyframe);
 /* Candidate::irLevelPos (packed x | y<<16) and dSTScore of one level, raster order; *n = count (may exceed cap). */
 int vslam_read_candidates(vslam_system* sys, int stream, int level, uint32_t* pos, double* score, int cap, int* n);
+/* use_sbi = 1: the SmallBlurryImage of the current frame (jni/SmallBlurryImage.cc:20-55: (w/16) x (h/16) u8 image and its
+ * zero-mean blurred fp32 template) and rot8 = { mv6SBIRot[6] (jni/Tracker.cc:885-893), final ESM score, 0 }. */
+int vslam_read_sbi(vslam_system* sys, int stream, uint8_t* small_img, float* tmpl, double rot8[8]);
 
 /* ---- MiniPatch (jni/MiniPatch.cc), the primitives of the reference's trail tracking ------------- */
 /* MiniPatch::SampleFromImage (:71-83): 9x9 patches around n integer positions of the current frame's level 0

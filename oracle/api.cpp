@@ -22,6 +22,7 @@ void* orc_sys_create(const orc_params* q) {
   for (int i = 0; i < 5; i++) p.cam[i] = q->cam[i];
   p.quirks = q->quirks;
   p.ba_delay_frames = q->ba_delay_frames;
+  p.use_sbi = q->use_sbi;
   return new System(p);
 }
 void orc_sys_destroy(void* s) { delete (System*)s; }

@@ -93,6 +93,23 @@ def thin_candidates(pos, score, level, meas_root, meas_level):
     return op[:n].copy(), os_[:n].copy()
 
 
+def sbi_make(level3, blur=0.75):
+    """SmallBlurryImage::MakeFromKF on a level-3 image -> (small u8 image, zero-mean blurred fp32 template)."""
+    l3 = np.ascontiguousarray(level3, np.uint8)
+    h3, w3 = l3.shape
+    small = np.empty((h3 // 2, w3 // 2), np.uint8); tmpl = np.empty((h3 // 2, w3 // 2), np.float32)
+    lib().orc_sbi_make(_p(l3), w3, h3, C.c_double(blur), _p(small), _p(tmpl))
+    return small, tmpl
+
+
+def sbi_rotation(cur_l3, last_l3, cam5, quirks=0, blur=0.75):
+    """Tracker::CalcSBIRotation between two level-3 images -> (6-vector ln of the SE3 adjustment, final ESM score)."""
+    a = np.ascontiguousarray(cur_l3, np.uint8); b = np.ascontiguousarray(last_l3, np.uint8)
+    cam = (C.c_double * 5)(*cam5); out = (C.c_double * 6)(); score = C.c_double(0)
+    lib().orc_sbi_rotation(_p(a), _p(b), a.shape[1], a.shape[0], C.c_double(blur), cam, int(quirks), out, C.byref(score))
+    return np.array(out[:]), score.value
+
+
 def shi_tomasi(img, nsize, px, py):
     img = np.ascontiguousarray(img)
     return lib().orc_shi_tomasi(_p(img), img.shape[1], nsize, px, py)
@@ -141,7 +158,7 @@ class OrcParams(C.Structure):
                 ("min_frames_between_kf", C.c_int), ("max_kf_dist_wiggle_mult", C.c_double), ("wiggle_scale", C.c_double),
                 ("ba_max_iterations", C.c_int), ("ba_convergence_limit", C.c_double), ("ba_min_tukey_sigma", C.c_double),
                 ("ba_window", C.c_int), ("ba_min_keyframes", C.c_int), ("cam", C.c_double * 5), ("quirks", C.c_int),
-                ("ba_delay_frames", C.c_int)]
+                ("ba_delay_frames", C.c_int), ("use_sbi", C.c_int)]
 
 
 class TrackState(C.Structure):
@@ -163,7 +180,7 @@ def params_from_vslam(vp):
     for f in ("coarse_min", "coarse_max", "coarse_range", "coarse_subpix_its", "coarse_disabled", "coarse_min_vel",
               "fine_subpix_its", "wls_prior", "min_frames_between_kf", "max_kf_dist_wiggle_mult", "wiggle_scale",
               "ba_max_iterations", "ba_convergence_limit", "ba_min_tukey_sigma", "ba_window", "ba_min_keyframes", "quirks",
-              "ba_delay_frames"):
+              "ba_delay_frames", "use_sbi"):
         setattr(p, f, getattr(vp, f))
     for i in range(5):
         p.cam[i] = vp.cam[i]

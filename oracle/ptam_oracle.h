@@ -93,6 +93,7 @@ typedef struct orc_params {           /* mirrors the hot-path fields of vslam_pa
   int ba_max_iterations; double ba_convergence_limit, ba_min_tukey_sigma; int ba_window, ba_min_keyframes;
   double cam[5]; int quirks;
   int ba_delay_frames;
+  int use_sbi;                        /* gvnUseSBI, jni/Tracker.cc:88 */
 } orc_params;
 
 typedef struct orc_track_state {      /* same fields as vslam_track_state */
@@ -123,6 +124,13 @@ int orc_sys_get_keyframe_meas(void* sys, int kf, int* pt, int* level, double* ro
 int orc_sys_get_template(void* sys, int pt, uint8_t* tmpl, int* sum, int* sumsq, int* bad);
 int orc_sys_bundle_adjust_recent(void* sys);   /* MapMaker::BundleAdjustRecent, jni/MapMaker.cc:801-851 */
 int orc_sys_bundle_adjust_all(void* sys);      /* MapMaker::BundleAdjustAll,    jni/MapMaker.cc:776-798 */
+
+/* ---- SmallBlurryImage rotation prior (jni/SmallBlurryImage.cc, jni/Tracker.cc:885-893); third-party arithmetic restated, see sbi.cpp */
+/* MakeFromKF on a level-3 image: small image (w3/2 x h3/2) and the zero-mean blurred template; returns w | h << 16 */
+int orc_sbi_make(const uint8_t* level3, int w3, int h3, double blur, uint8_t* small_out, float* tmpl_out);
+/* CalcSBIRotation between the level-3 images of this and the last frame: ln(SE3fromSE2(IteratePosRelToTarget(6))) */
+void orc_sbi_rotation(const uint8_t* cur_l3, const uint8_t* last_l3, int w3, int h3, double blur, const double cam5[5],
+                      int quirks, double out6[6], double* score);
 
 /* ---- stand-alone Bundle (jni/Bundle.h:111-121) --------------------------------------------------- */
 void* orc_ba_create(const double cam5[5], int width, int height, int quirks, int max_iterations, double convergence_limit, double min_sigma);

@@ -72,7 +72,14 @@ struct Params {
   int ba_max_iterations; double ba_convergence_limit, ba_min_tukey_sigma; int ba_window, ba_min_keyframes;
   double cam[5]; int quirks;
   int ba_delay_frames = 0;   // 0: results applied at once; D > 0: applied at the start of the D-th following frame
+  int use_sbi = 0;           // gvnUseSBI, jni/Tracker.cc:88 (reference: 1)
 };
+
+// SmallBlurryImage (jni/SmallBlurryImage.h): mimSmall, mimTemplate (zero-mean, blurred), mimImageJacs (x, y interleaved)
+struct SBI { int w = 0, h = 0; std::vector<uint8_t> small; std::vector<float> tmpl, jacs; bool made_jacs = false; };
+void sbi_make(SBI& s, const uint8_t* level3, int w3, int h3, double blur);
+void sbi_make_jacs(SBI& s);
+void calc_sbi_rotation(const SBI& cur, SBI& last, const Camera& cam, bool quirk_int_radius, double out6[6], double* score);
 
 // ---- Bundle (jni/Bundle.{h,cc}) --------------------------------------------------------------------------------
 struct BCamera { bool fixed; SE3 pose, pose_new; double U[36]; double ea[6]; int start_row; };
@@ -112,6 +119,7 @@ struct System {
   // tracker
   KeyFrame cur;
   SE3 pose, start_pose; double velocity[6] = {0, 0, 0, 0, 0, 0};
+  SBI sbi_this, sbi_last; bool have_sbi = false; double sbi_rot[6] = {0, 0, 0, 0, 0, 0}; double sbi_score = 0;   // mpSBIThisFrame / mpSBILastFrame / mv6SBIRot
   double msd_vel = 0; bool did_coarse = false; bool just_recovered = false;
   int frame = 0, last_kf_dropped = -20, lost_frames = 0; int quality = 2;  // 0 BAD 1 DODGY 2 GOOD
   int attempted[4], found[4];

@@ -130,9 +130,20 @@ void System::TrackFrame(const uint8_t* gray, int stride) {
   if (pending && --pending->countdown == 0) { ApplyBundle(*pending); delete pending; pending = nullptr; HandleBadPoints(); }   // deferred map-maker results
   cur.meas.clear();
   make_keyframe_lite(cur, gray, p.width, p.height, stride, p.thr);
+  if (p.use_sbi) {                           // :86-97: the small images of the rotation estimator
+    if (!have_sbi) {
+      sbi_make(sbi_this, cur.im[3].data(), cur.w[3], cur.h[3], 0.75);
+      sbi_last = sbi_this;
+      have_sbi = true;
+    } else {
+      sbi_last = sbi_this;
+      sbi_make(sbi_this, cur.im[3].data(), cur.w[3], cur.h[3], 0.75);
+    }
+  }
   frame++;
   if (map_good) {
     if (lost_frames < 3) {
+      if (p.use_sbi) calc_sbi_rotation(sbi_this, sbi_last, camera, (p.quirks & ORC_Q_CAM_INT_RADIUS) != 0, sbi_rot, &sbi_score);   // :104-105
       ApplyMotionModel();
       TrackMap();
       UpdateMotionModel();
@@ -148,9 +159,12 @@ void System::TrackFrame(const uint8_t* gray, int stride) {
 }
 
 void System::ApplyMotionModel() {
-  // jni/Tracker.cc:781-798 with mbUseSBIInit == false
+  // jni/Tracker.cc:781-798
   start_pose = pose;
-  pose = mul(se3_exp(velocity), start_pose);
+  double v[6];
+  for (int i = 0; i < 6; i++) v[i] = velocity[i];
+  if (p.use_sbi) { v[0] = 0.0; v[1] = 0.0; v[3] = sbi_rot[3]; v[4] = sbi_rot[4]; v[5] = sbi_rot[5]; }   // :788-794
+  pose = mul(se3_exp(v), start_pose);
 }
 
 void System::UpdateMotionModel() {

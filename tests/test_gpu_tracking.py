@@ -251,3 +251,32 @@ def test_thin_candidates_matches_oracle():
             removed += len(cands[l][0]) - len(want)
         assert removed > 0                                  # the map's own points sit on corners: thinning must bite
     g.close()
+
+
+def test_small_blurry_image_rotation_prior():
+    """use_sbi = 1 (the reference's gvnUseSBI): SmallBlurryImage template bit-exact, rotation prior and the tracked poses
+    against the oracle configured alike (jni/SmallBlurryImage.cc, jni/Tracker.cc:86-105, 781-798, 885-893)."""
+    from oracle import binding as orc
+    w, h = 640, 480
+    f, m, frames = make_scene(w, h, seed=31, n_frames=8)
+    vp = capi.default_params(w, h, 2, patch_size=8, use_sbi=1)
+    g = capi.System(vp)
+    for s in range(2):
+        g.load_map(s, m); g.set_pose(s, f.pose(-1))
+    o = make_oracle(capi.default_params(w, h, 1, patch_size=8, use_sbi=1), m, f.pose(-1))
+    o_plain = make_oracle(capi.default_params(w, h, 1, patch_size=8), m, f.pose(-1))
+    drift, changed = Drift(), False
+    prev_l3 = None
+    for t in range(8):
+        g.track_frame(np.stack([frames[t]] * 2)); o.track_frame(frames[t]); o_plain.track_frame(frames[t])
+        l3 = orc.make_keyframe_lite(frames[t])[3][0]
+        small, tmpl, rot, score = g.read_sbi(1)
+        wsmall, wtmpl = orc.sbi_make(l3)
+        assert np.array_equal(small, wsmall) and np.array_equal(tmpl, wtmpl), t          # same float expressions, same order
+        wrot, wscore = orc.sbi_rotation(l3, prev_l3 if prev_l3 is not None else l3, vp.cam[:])
+        assert np.abs(rot - wrot).max() < 1e-10 and abs(score - wscore) <= 1e-9 * max(1.0, wscore), (t, rot, wrot)
+        prev_l3 = l3
+        compare_frame(o, g, 0, "sbi frame %d" % t, drift)
+        changed |= pose_err(o.state().pose, o_plain.state().pose) > 0
+    assert changed
+    g.close()

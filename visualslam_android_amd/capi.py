@@ -63,6 +63,7 @@ SYMBOLS = {
     "vslam_read_corners": (_i, [_sys, _i, _i, _vp, _i, _ip]),
     "vslam_read_row_lut": (_i, [_sys, _i, _i, _vp]),
     "vslam_read_max_corners": (_i, [_sys, _i, _i, _vp, _vp, _i, _ip]),
+    "vslam_read_sbi": (_i, [_sys, _i, _vp, _vp, _vp]),
     "vslam_make_keyframe_rest": (_i, [_sys, C.c_double]),
     "vslam_thin_candidates": (_i, [_sys, _i]),
     "vslam_read_candidates": (_i, [_sys, _i, _i, _vp, _vp, _i, _ip]),
@@ -320,6 +321,12 @@ class System:
         pos = np.zeros((n, 3)); bad, nin, nout = (np.zeros(n, np.int32) for _ in range(3))
         _check(self.lib.vslam_get_points(self.h, stream, pos.ctypes.data, bad.ctypes.data, nin.ctypes.data, nout.ctypes.data, n))
         return {"pos": pos, "bad": bad, "n_in": nin, "n_out": nout}
+
+    def read_sbi(self, stream):
+        hs, ws = self.params.height // 16, self.params.width // 16
+        small = np.zeros((hs, ws), np.uint8); tmpl = np.zeros((hs, ws), np.float32); rot = np.zeros(8)
+        _check(self.lib.vslam_read_sbi(self.h, stream, small.ctypes.data, tmpl.ctypes.data, rot.ctypes.data))
+        return small, tmpl, rot[:6].copy(), float(rot[6])
 
     def make_keyframe_rest(self, min_score=70.0):
         _check(self.lib.vslam_make_keyframe_rest(self.h, float(min_score)))

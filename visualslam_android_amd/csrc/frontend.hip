@@ -513,6 +513,11 @@ int fe_make_keyframe_lite(vslam_system* sys, const uint8_t* gray, size_t row_str
   hipLaunchKernelGGL(k_fast_lvl, dim3(nb, sys->S), dim3(FE_THREADS), lds1, fs, a);
   prof_mark(sys, 2);
   hipLaunchKernelGGL(k_compact, dim3(NLEV, sys->S), dim3(COMPACT_THREADS), 0, fs, a);
+  if (sys->p.use_sbi) {                                           // jni/Tracker.cc:86-97, 104-105
+    int r = fe_sbi(sys, sys->have_sbi ? sys->frbuf[b ^ 1] : sys->fr);
+    if (r) return r;
+    sys->have_sbi = true;
+  }
   prof_mark(sys, PROF_FE_END);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(sys->ev_fe_done[b], fs));

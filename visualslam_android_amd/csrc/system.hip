@@ -111,6 +111,10 @@ extern "C" int vslam_create(const vslam_params* p, vslam_system** out) {
       fr.img_sstride[l] = (size_t)g.pitch * g.h;
       fr.img_pitch[l] = g.pitch;
     }
+    {
+      const size_t ns = (size_t)(sys->geom[3].w / 2) * (sys->geom[3].h / 2);
+      ALLOC(fr.sbi_small, (size_t)S * ns); ALLOC(fr.sbi_tmpl, (size_t)S * ns); ALLOC(fr.sbi_jacs, (size_t)S * ns * 2); ALLOC(fr.sbi_rot, (size_t)S * 8);
+    }
     ALLOC(fr.ncorners, (size_t)S * NLEV);
     ALLOC(fr.nmax, (size_t)S * NLEV);
     ALLOC(fr.overflow, 1);
@@ -118,6 +122,7 @@ extern "C" int vslam_create(const vslam_params* p, vslam_system** out) {
   for (int l = 0; l < NLEV; l++) { ALLOC(sys->cand[l], (size_t)S * sys->geom[l].cap); ALLOC(sys->cand_score[l], (size_t)S * sys->geom[l].cap); }
   ALLOC(sys->ncand, (size_t)S * NLEV);
   sys->have_candidates = false;
+  sys->have_sbi = false;
   if (p->ba_delay_frames > 0) {
     if (hipStreamCreateWithFlags(&sys->ba_stream, hipStreamNonBlocking) != hipSuccess) { vslam_set_error("create: hipStreamCreate failed"); vslam_destroy(sys); return VSLAM_E_HIP; }
     for (int i = 0; i < p->ba_delay_frames + 2; i++) {
@@ -221,6 +226,17 @@ extern "C" int vslam_read_row_lut(vslam_system* sys, int stream, int level, int*
   const int h = sys->geom[level].h;
   HIPCHK(hipMemcpyAsync(lut, sys->fr.rowlut[level] + (size_t)stream * (h + 1), (size_t)h * 4, hipMemcpyDeviceToHost, sys->stream));
   HIPCHK(hipStreamSynchronize(sys->stream));
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_read_sbi(vslam_system* sys, int stream, uint8_t* small_img, float* tmpl, double rot8[8]) {
+  int r = check_sl(sys, stream, 0); if (r) return r;
+  if (!sys->p.use_sbi || !sys->have_sbi) { vslam_set_error("read_sbi: use_sbi is off or no frame yet"); return VSLAM_E_STATE; }
+  HIPCHK(hipStreamSynchronize(sys->fe_stream));
+  const size_t ns = (size_t)(sys->geom[3].w / 2) * (sys->geom[3].h / 2);
+  if (small_img) HIPCHK(hipMemcpy(small_img, sys->fr.sbi_small + stream * ns, ns, hipMemcpyDeviceToHost));
+  if (tmpl) HIPCHK(hipMemcpy(tmpl, sys->fr.sbi_tmpl + stream * ns, ns * sizeof(float), hipMemcpyDeviceToHost));
+  if (rot8) HIPCHK(hipMemcpy(rot8, sys->fr.sbi_rot + (size_t)stream * 8, 8 * sizeof(double), hipMemcpyDeviceToHost));
   return VSLAM_OK;
 }
 

@@ -61,12 +61,17 @@ DEVFN void td_calc_jacobian(const T& td, double* jac) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TRK_THREADS) void k_pvs(MapDev m, TrackParams tp) {
+__global__ __launch_bounds__(TRK_THREADS) void k_pvs(MapDev m, TrackParams tp, const double* sbi_rot /* [S][8] or null */) {
   const int s = blockIdx.y;
   TrackerState* st = &m.st[s];
   const bool tracking = st->map_good && st->lost_frames < 3;       // jni/Tracker.cc:103-104
   __shared__ Pose pred;
-  if (threadIdx.x == 0 && tracking) pred = pose_mul(se3_exp(st->velocity), st->pose_final);   // ApplyMotionModel, mbUseSBIInit = false
+  if (threadIdx.x == 0 && tracking) {                              // ApplyMotionModel, jni/Tracker.cc:781-798
+    double v[6];
+    for (int i = 0; i < 6; i++) v[i] = st->velocity[i];
+    if (sbi_rot) { v[0] = 0.0; v[1] = 0.0; for (int i = 3; i < 6; i++) v[i] = sbi_rot[(size_t)s * 8 + i]; }   // mbUseSBIInit :788-794
+    pred = pose_mul(se3_exp(v), st->pose_final);
+  }
   __syncthreads();
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     st->frame++;                                                   // :100
@@ -1059,31 +1064,33 @@ int trk_alloc(vslam_system* sys) {
   return VSLAM_OK;
 }
 
-// device parameter block; camera per ATANCamera::RefreshParams (jni/ATANCamera.cc:37-82)
-void trk_fill_params(const vslam_params& p, TrackParams& t) {
-  {
-  CamModel& c = t.cam;
-  c.size[0] = p.width; c.size[1] = p.height;
-  c.focal[0] = c.size[0] * p.cam[0]; c.focal[1] = c.size[1] * p.cam[1];
-  c.center[0] = c.size[0] * p.cam[2] - 0.5; c.center[1] = c.size[1] * p.cam[3] - 0.5;
-  c.w = p.cam[4];
+// device camera block per ATANCamera::SetImageSize + RefreshParams (jni/ATANCamera.cc:31-82)
+void cam_fill(CamModel& c, const double cam5[5], double width, double height, int quirks) {
+  c.size[0] = width; c.size[1] = height;
+  c.focal[0] = c.size[0] * cam5[0]; c.focal[1] = c.size[1] * cam5[1];
+  c.center[0] = c.size[0] * cam5[2] - 0.5; c.center[1] = c.size[1] * cam5[3] - 0.5;
+  c.w = cam5[4];
   double one_over_2tan = 0;
   if (c.w != 0.0) { c.two_tan = 2.0 * tan(c.w / 2.0); one_over_2tan = 1.0 / c.two_tan; c.winv = 1.0 / c.w; c.distortion_enabled = 1.0; }
   else { c.winv = 0; c.two_tan = 0; c.distortion_enabled = 0; }
   double v2[2];
-  if (p.quirks & VSLAM_Q_CAM_INT_RADIUS) {   // :70-78 int-typed operands (quirk #5)
-    int m1 = (int)p.cam[2], m2 = (int)(1.0 - p.cam[2]);
-    v2[0] = (m1 > m2 ? m1 : m2) / p.cam[0];
-    m1 = (int)p.cam[3]; m2 = (int)(1.0 - p.cam[3]);
-    v2[1] = (m1 > m2 ? m1 : m2) / p.cam[1];
+  if (quirks & VSLAM_Q_CAM_INT_RADIUS) {   // :70-78 int-typed operands (quirk #5)
+    int m1 = (int)cam5[2], m2 = (int)(1.0 - cam5[2]);
+    v2[0] = (m1 > m2 ? m1 : m2) / cam5[0];
+    m1 = (int)cam5[3]; m2 = (int)(1.0 - cam5[3]);
+    v2[1] = (m1 > m2 ? m1 : m2) / cam5[1];
   } else {
-    v2[0] = (p.cam[2] > 1.0 - p.cam[2] ? p.cam[2] : 1.0 - p.cam[2]) / p.cam[0];
-    v2[1] = (p.cam[3] > 1.0 - p.cam[3] ? p.cam[3] : 1.0 - p.cam[3]) / p.cam[1];
+    v2[0] = (cam5[2] > 1.0 - cam5[2] ? cam5[2] : 1.0 - cam5[2]) / cam5[0];
+    v2[1] = (cam5[3] > 1.0 - cam5[3] ? cam5[3] : 1.0 - cam5[3]) / cam5[1];
   }
   const double rr = sqrt(v2[0] * v2[0] + v2[1] * v2[1]);
   c.largest_radius = c.w == 0.0 ? rr : tan(rr * c.w) * one_over_2tan;   // invrtrans, jni/ATANCamera.h:145-150
   c.max_r = 1.5 * c.largest_radius;
-  }
+}
+
+// device parameter block
+void trk_fill_params(const vslam_params& p, TrackParams& t) {
+  cam_fill(t.cam, p.cam, p.width, p.height, p.quirks);
   t.P = p.patch_size; t.max_ssd = 500 * p.patch_size * p.patch_size;
   t.max_patches = p.max_patches_per_frame; t.coarse_min = p.coarse_min; t.coarse_max = p.coarse_max; t.coarse_range = p.coarse_range;
   t.coarse_subpix_its = p.coarse_subpix_its; t.coarse_disabled = p.coarse_disabled; t.fine_subpix_its = p.fine_subpix_its;
@@ -1109,7 +1116,8 @@ int trk_track_map(vslam_system* sys) {
   a.ncorners = sys->fr.ncorners;
   const int maxSearch = tp.max_patches + 2 * tp.coarse_max < P ? tp.max_patches + 2 * tp.coarse_max : P;
   prof_mark(sys, 3);
-  hipLaunchKernelGGL(k_pvs, dim3((P + TRK_THREADS - 1) / TRK_THREADS, S), dim3(TRK_THREADS), 0, sys->stream, m, tp);
+  hipLaunchKernelGGL(k_pvs, dim3((P + TRK_THREADS - 1) / TRK_THREADS, S), dim3(TRK_THREADS), 0, sys->stream, m, tp,
+                     sys->p.use_sbi ? (const double*)sys->fr.sbi_rot : (const double*)nullptr);
   prof_mark(sys, 4);
   hipLaunchKernelGGL(k_plan, dim3(S), dim3(TRK_THREADS), 0, sys->stream, m, tp, 0);
   prof_mark(sys, 5);

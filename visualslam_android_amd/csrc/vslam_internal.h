@@ -46,6 +46,11 @@ struct FrameDev {
   int* scores[NLEV];                // [S][cap]
   uint32_t* maxcorners[NLEV];       // [S][cap]
   int* nmax;                        // [S][NLEV]
+  // SmallBlurryImage of the frame (jni/SmallBlurryImage.h) and the rotation prior computed against the previous frame's
+  uint8_t* sbi_small;               // [S][hs*ws]       mimSmall
+  float* sbi_tmpl;                  // [S][hs*ws]       mimTemplate (zero-mean, blurred)
+  float* sbi_jacs;                  // [S][hs*ws][2]    mimImageJacs
+  double* sbi_rot;                  // [S][8]           mv6SBIRot (6), final ESM score, spare
 };
 
 
@@ -148,6 +153,7 @@ struct vslam_system {
   long frame_no = 0;
   std::vector<void*> allocs;   // everything to hipFree
   bool have_frame;
+  bool have_sbi;            // a SmallBlurryImage of a previous frame exists (mpSBILastFrame)
   // KeyFrame::Level::vCandidates of the current frame (jni/KeyFrame.h:62-70), filled by vslam_make_keyframe_rest
   uint32_t* cand[NLEV]; double* cand_score[NLEV]; int* ncand; bool have_candidates;
   TrackParams tp;
@@ -174,6 +180,8 @@ static inline void prof_mark(vslam_system* sys, int k) {
 int fe_make_keyframe_lite(vslam_system* sys, const uint8_t* gray, size_t row_stride, size_t stream_stride,
                           int on_device);
 int fe_fast_nonmax(vslam_system* sys);
+int fe_sbi(vslam_system* sys, const FrameDev& last);   // k_sbi on the front-end stream: this frame's SBI + rotation prior against `last`
+void cam_fill(CamModel& c, const double cam5[5], double width, double height, int quirks);
 int fe_make_keyframe_rest(vslam_system* sys, double min_score);
 int fe_thin_candidates(vslam_system* sys, int keyframe);
 // track.hip
