@@ -5,12 +5,14 @@
 //              (jni/TrackerData.h:69-95) + PatchFinder::CalcSearchLevelAndWarpMatrix (jni/PatchFinder.cc:31-68)
 //   k_plan     potentially-visible-set lists per level in map order (the reference's random_shuffle is the
 //              identity permutation here), coarse-stage selection (:399-461) / fine-stage selection (:493-535)
-//   k_search   one wavefront per patch: warped template (MakeTemplateCoarseCont, transform_image), ZMSSD at the
-//              FAST corners of the row-LUT window (FindPatchCoarse/ZMSSDAtPoint) with 8 lanes per candidate and
-//              __shfl reductions, optional inverse-compositional sub-pixel refinement (IterateSubPix*)
+//   k_searchN  4 (11x11) or 8 (8x8) patches per wavefront, one lane per template row: warped template
+//              (MakeTemplateCoarseCont, transform_image), ZMSSD at the FAST corners of the row-LUT window
+//              (FindPatchCoarse/ZMSSDAtPoint) with packed-byte dot products and group shuffles
+//   k_subpixN  inverse-compositional sub-pixel refinement (MakeSubPixTemplate, IterateSubPix*) of the found patches
+//              that carry a sub-pixel budget
 //   k_pose     one workgroup per stream: the 10 Gauss-Newton iterations of a stage (:466-488 / :543-577):
-//              re-projection, 2x6 Jacobians, Tukey sigma (bitonic sort in LDS for the median), weighted normal
-//              equations reduced with wave shuffles, 6x6 solve, SE3 exp; then measurement export, scene depth,
+//              re-projection, 2x6 Jacobians, Tukey sigma (radix select for the median), weighted normal equations
+//              reduced with wave shuffles, 6x6 solve, SE3 exp; then measurement export, scene depth,
 //              UpdateMotionModel, AssessTrackingQuality and the new-keyframe decision (:594-625, :802-878, :128-132)
 #include "vslam_internal.h"
 
@@ -229,255 +231,35 @@ struct SearchArgs {
   int kf_pitch[NLEV];
 };
 
-// One wavefront per patch (jni/Tracker.cc:629-674 SearchForPoints body).
-template <int PS>
-__global__ __launch_bounds__(64) void k_search(MapDev m, TrackParams tp, SearchArgs a, int stage) {
-  const int s = blockIdx.y, e = blockIdx.x;
-  TrackerState* st = &m.st[s];
-  if (!(st->map_good && st->lost_frames < 3) || e >= st->n_search) return;
-  constexpr int NPIX = PS * PS, HALF = PS / 2, Q = PS - 2;
-  const int lane = threadIdx.x;
-  const int2 ent = m.search_list[(size_t)s * tp.max_points + e];
-  const int idx = ent.x, nSubPixIts = ent.y;
-  const int nRangeL0 = stage == 0 ? st->coarse_range : st->fine_range;
-  TrackData& td = m.td[(size_t)s * tp.max_points + idx];
-  int& tdlevel = m.pt_level[(size_t)s * tp.max_points + idx];
-  int& tdflags = m.pt_flags[(size_t)s * tp.max_points + idx];
-  const MapPointDev& p = m.pts[(size_t)s * tp.max_points + idx];
-  uint8_t* gtmpl = m.tmpl + ((size_t)s * tp.max_points + idx) * TMPL_PITCH;
-  __shared__ uint8_t tmpl[TMPL_PITCH];
-  __shared__ int cand[64];
-  const int level = tdlevel, scale = 1 << level;
-  int flags = tdflags;
-
-  // ---- MakeTemplateCoarseCont, jni/PatchFinder.cc:79-125 ----
-  double inv[4];
-  inv2(td.warp_inv, inv);
-  const double m2[4] = {inv[0] * scale, inv[1] * scale, inv[2] * scale, inv[3] * scale};
-  bool refresh = !(flags & TDF_HAVE_LAST);
-  for (int i = 0; !refresh && i < 2; i++) {
-    const double dx = m2[i] - td.last_warp[i], dy = m2[2 + i] - td.last_warp[2 + i];
-    if (dx * dx + dy * dy > 0.07 * 0.07) refresh = true;
-  }
-  int tsum, tsumsq;
-  if (refresh) {
-    // transform_image (jni/vision/ImageHandler.cpp:21-113): same accumulated stepping of the sample position
-    const int sl = p.src_level;
-    const uint8_t* src = m.kf_img[sl] + ((size_t)s * tp.max_keyframes + p.src_kf) * a.kf_stride[sl];
-    const int sp = a.kf_pitch[sl], iw = a.w[sl], ih = a.h[sl];
-    const double across[2] = {m2[0], m2[2]}, down[2] = {m2[1], m2[3]};
-    double px = (double)p.irx - (m2[0] * HALF + m2[1] * HALF), py = (double)p.iry - (m2[2] * HALF + m2[3] * HALF);
-    const double cr[2] = {down[0] - PS * across[0], down[1] - PS * across[1]};
-    double myx[2] = {0, 0}, myy[2] = {0, 0};
-#pragma unroll 1
-    for (int i = 0; i < PS; i++) {
-#pragma unroll 1
-      for (int j = 0; j < PS; j++) {
-        const int k = i * PS + j;
-        if ((k & 63) == lane) { myx[k >> 6] = px; myy[k >> 6] = py; }
-        px += across[0]; py += across[1];
-      }
-      px += cr[0]; py += cr[1];
-    }
-    int nOutside = 0, sum = 0, sumsq = 0;
-    const float x_bound = (float)(iw - 1), y_bound = (float)(ih - 1);
-    for (int q = 0; q < (NPIX + 63) / 64; q++) {
-      const int k = q * 64 + lane;
-      if (k < NPIX) {
-        double x = myx[q], y = myy[q];
-        int v = 0;
-        if (0 <= x && 0 <= y && x < x_bound && y < y_bound) {
-          const int lx = (int)x, ly = (int)y;                        // sample(), ImageHandler.cpp:12-19
-          x -= lx; y -= ly;
-          const uint8_t* q0 = src + (size_t)ly * sp + lx;
-          v = (uint8_t)((1 - y) * ((1 - x) * q0[0] + x * q0[1]) + y * ((1 - x) * q0[sp] + x * q0[sp + 1]));
-        } else nOutside++;
-        tmpl[k] = (uint8_t)v; gtmpl[k] = (uint8_t)v;
-        sum += v; sumsq += v * v;
-      }
-    }
-    nOutside = wave_sum_i(nOutside);
-    tsum = wave_sum_i(sum); tsumsq = wave_sum_i(sumsq);             // MakeTemplateSums :152-164
-    flags = nOutside ? (flags | TDF_TMPL_BAD) : (flags & ~TDF_TMPL_BAD);
-    flags |= TDF_HAVE_LAST;
-    if (lane == 0) { td.tsum = tsum; td.tsumsq = tsumsq; for (int i = 0; i < 4; i++) td.last_warp[i] = m2[i]; }
-  } else {
-    for (int k = lane; k < NPIX; k += 64) tmpl[k] = gtmpl[k];
-    tsum = td.tsum; tsumsq = td.tsumsq;
-  }
-  __syncthreads();
-  if (flags & TDF_TMPL_BAD) {                                        // jni/Tracker.cc:637-640
-    if (lane == 0) tdflags = flags & ~(TDF_IN_IMAGE | TDF_FOUND);
-    return;
-  }
-  if (lane == 0) atomicAdd(&st->attempted[level], 1);               // :641
-
-  // ---- FindPatchCoarse, jni/PatchFinder.cc:170-235 ----
-  const double irx = td.image[0] / scale, iry = td.image[1] / scale;
-  const unsigned nRange = ((unsigned)nRangeL0 + scale - 1) / scale;
-  int nTop = (int)(iry - nRange);
-  const int nBottomPlusOne = (int)(iry + nRange + 1);
-  const int nLeft = (int)(irx - nRange), nRight = (int)(irx + nRange);
-  const int rows = a.h[level], cols = a.w[level];
-  if (nTop < 0) nTop = 0;
-  int nBestSSD = tp.max_ssd + 1;
-  int bestIdx = 0x7fffffff;
-  unsigned nEval = 0;
-  const uint32_t* corners = a.corners[level] + (size_t)s * a.cap[level];
-  if (!(nTop >= rows) && !(nBottomPlusOne <= 0)) {
-    const int* lut = a.rowlut[level] + (size_t)s * (rows + 1);
-    const int i0 = lut[nTop];
-    const int i1 = nBottomPlusOne >= rows ? a.ncorners[s * NLEV + level] : lut[nBottomPlusOne];
-    const uint8_t* img = a.img[level] + (size_t)s * a.img_sstride[level];
-    const int ip = a.img_pitch[level];
-    const double r2max = (double)(nRange * nRange);
-    const int grp = lane >> 3, sub = lane & 7;
-    for (int base = i0; base < i1; base += 64) {
-      // filter 64 corners at a time (:216-219), compact the survivors in raster order
-      const int ci = base + lane;
-      bool ok = false;
-      if (ci < i1) {
-        const uint32_t c = corners[ci];
-        const int cx = c & 0xFFFF, cy = c >> 16;
-        if (!(cx < nLeft || cx > nRight)) {
-          const double dx = irx - cx, dy = iry - cy;
-          ok = !(dx * dx + dy * dy > r2max);
-        }
-      }
-      const unsigned long long bm = __ballot(ok);
-      const int nc = __popcll(bm);
-      if (ok) cand[__popcll(bm & ((1ull << lane) - 1ull))] = ci;
-      __syncthreads();
-      nEval += nc;
-      // ZMSSDAtPoint (:352-380): 8 candidates at a time, 8 lanes per candidate
-      for (int c0 = 0; c0 < nc; c0 += 8) {
-        const int k = c0 + grp;
-        int ssd = 0x7fffffff, cidx = 0x7fffffff;
-        if (k < nc) {
-          cidx = cand[k];
-          const uint32_t c = corners[cidx];
-          const int cx = c & 0xFFFF, cy = c >> 16;
-          int sA = 0, sQ = 0, sX = 0;
-          const bool inside = cx >= HALF && cy >= HALF && cx < cols - HALF && cy < rows - HALF;   // in_image_with_border
-          if (inside) {
-            const uint8_t* ibase = img + (size_t)(cy - HALF) * ip + (cx - HALF);
-            for (int q = sub; q < NPIX; q += 8) {
-              const int r = q / PS, cc = q - r * PS;
-              const int n = ibase[r * ip + cc], t = tmpl[q];
-              sA += n; sQ += n * n; sX += n * t;
-            }
-          }
-          for (int d = 1; d < 8; d <<= 1) { sA += __shfl_xor(sA, d); sQ += __shfl_xor(sQ, d); sX += __shfl_xor(sX, d); }
-          if (inside) {
-            const int SA = tsum, SB = sA;
-            ssd = ((2 * SA * SB - SA * SA - SB * SB) / NPIX + sQ + tsumsq - 2 * sX);
-          } else ssd = tp.max_ssd + 1;
-        }
-        // first strict minimum in raster order (:223): lexicographic (ssd, corner index) minimum
-        for (int d = 8; d < 64; d <<= 1) {
-          const int os = __shfl_xor(ssd, d), oi = __shfl_xor(cidx, d);
-          if (os < ssd || (os == ssd && oi < cidx)) { ssd = os; cidx = oi; }
-        }
-        if (ssd < nBestSSD) { nBestSSD = ssd; bestIdx = cidx; }
-      }
-      __syncthreads();
-    }
-  }
-  flags |= TDF_SEARCHED;                                             // :645
-  if (lane == 0 && nEval) atomicAdd(&st->n_zmssd, (unsigned long long)nEval);
-  if (!(nBestSSD < tp.max_ssd)) {                                    // :646-649
-    if (lane == 0) tdflags = flags & ~TDF_FOUND;
-    return;
-  }
-  const uint32_t bc = corners[bestIdx];
-  const double coarse[2] = {level_zero_pos((double)(bc & 0xFFFF), level), level_zero_pos((double)(bc >> 16), level)};
-  flags |= TDF_FOUND;
-  if (nSubPixIts <= 0) {                                             // :668-671
-    flags &= ~TDF_SUBPIX;
-    if (lane == 0) {
-      tdflags = flags; td.sqrt_inv_noise = 1.0 / scale; td.vfound[0] = coarse[0]; td.vfound[1] = coarse[1];
-      atomicAdd(&st->found[level], 1);
-    }
-    return;
-  }
-  // ---- MakeSubPixTemplate (:242-271) + IterateSubPixToConvergence (:273-350) ----
-  flags |= TDF_SUBPIX;
-  double gx[2], gy[2];
-  double h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0;
-  for (int q = 0; q < (Q * Q + 63) / 64; q++) {
-    const int k = q * 64 + lane;
-    gx[q] = 0; gy[q] = 0;
-    if (k < Q * Q) {
-      const int x = k / Q + 1, y = k % Q + 1;
-      gx[q] = 0.5 * (tmpl[y * PS + x + 1] - tmpl[y * PS + x - 1]);
-      gy[q] = 0.5 * (tmpl[(y + 1) * PS + x] - tmpl[(y - 1) * PS + x]);
-      h00 += gx[q] * gx[q]; h01 += gx[q] * gy[q]; h02 += gx[q]; h11 += gy[q] * gy[q]; h12 += gy[q]; h22 += 1.0;
-    }
-  }
-  h00 = wave_sum_d(h00); h01 = wave_sum_d(h01); h02 = wave_sum_d(h02);     // quarter-integers: exact in any order
-  h11 = wave_sum_d(h11); h12 = wave_sum_d(h12); h22 = wave_sum_d(h22);
-  const double H[9] = {h00, h01, h02, h01, h11, h12, h02, h12, h22};
-  double Hinv[9];
-  inv3(H, Hinv);
-  double sub0 = coarse[0], sub1 = coarse[1], meanDiff = 0.0;
-  const uint8_t* img = a.img[level] + (size_t)s * a.img_sstride[level];
-  const int ip = a.img_pitch[level];
-  bool converged = false;
-  for (int it = 0; it < nSubPixIts; it++) {
-    const double cx = level_n_pos(sub0, level), cy = level_n_pos(sub1, level);
-    const int xb = (int)(cx > 0.0 ? cx + 0.5 : cx - 0.5), yb = (int)(cy > 0.0 ? cy + 0.5 : cy - 0.5);
-    const int b = HALF + 1;
-    if (!(xb >= b && yb >= b && xb < cols - b && yb < rows - b)) break;         // went off edge -> fail
-    const double bx = cx - HALF, by = cy - HALF;
-    const double dX = bx - floor(bx), dY = by - floor(by);
-    const float fTL = (float)((1.0 - dX) * (1.0 - dY)), fTR = (float)((dX) * (1.0 - dY));
-    const float fBL = (float)((1.0 - dX) * (dY)), fBR = (float)((dX) * (dY));
-    double a0 = 0, a1 = 0, a2 = 0;
-    for (int q = 0; q < (Q * Q + 63) / 64; q++) {
-      const int k = q * 64 + lane;
-      if (k < Q * Q) {
-        const int x = k / Q + 1, y = k % Q + 1;
-        const uint8_t* tl = img + (size_t)((int)by + y) * ip + (int)bx + x;
-        const float fPixel = fTL * tl[0] + fTR * tl[1] + fBL * tl[ip] + fBR * tl[ip + 1];
-        const double dDiff = (fPixel - (float)tmpl[y * PS + x]) + meanDiff;
-        a0 += dDiff * gx[q]; a1 += dDiff * gy[q]; a2 += dDiff;
-      }
-    }
-    a0 = wave_sum_d(a0); a1 = wave_sum_d(a1); a2 = wave_sum_d(a2);
-    const double u0 = Hinv[0] * a0 + Hinv[1] * a1 + Hinv[2] * a2;
-    const double u1 = Hinv[3] * a0 + Hinv[4] * a1 + Hinv[5] * a2;
-    const double u2 = Hinv[6] * a0 + Hinv[7] * a1 + Hinv[8] * a2;
-    sub0 -= u0 * scale; sub1 -= u1 * scale; meanDiff -= u2;
-    if (u0 * u0 + u1 * u1 < 0.03 * 0.03) { converged = true; break; }
-  }
-  if (lane == 0) {
-    if (!converged) tdflags = flags & ~TDF_FOUND;                   // :658-666 un-finds the point
-    else {
-      tdflags = flags; td.sqrt_inv_noise = 1.0 / scale; td.vfound[0] = sub0; td.vfound[1] = sub1;
-      atomicAdd(&st->found[level], 1);
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// 8x8 patches (the PTAM default): eight patches per wavefront, eight lanes per patch, lane r owns template row r as
-// two packed dwords.  Same arithmetic per pixel / per candidate as k_search<PS>; no LDS, 8x fewer wavefronts, and
-// the dependent global loads of eight patches overlap.  ZMSSD sums use v_dot4_u32_u8.
-DEVFN int grp_sum_i(int v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); return v; }
-DEVFN double grp_sum_d(double v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); return v; }
-DEVFN uint2 load_row8(const uint8_t* p) { uint2 v; __builtin_memcpy(&v, p, 8); return v; }
-DEVFN int row_byte(const uint2& r, int x) { return x < 4 ? (int)((r.x >> (8 * x)) & 255u) : (int)((r.y >> (8 * (x - 4))) & 255u); }
+// SearchForPoints body (jni/Tracker.cc:629-674).  Several patches per wavefront: G lanes per patch (8 for the 8x8 BASELINE patches -> 8 patches per wave, 16 for the
+// reference's 11x11 default -> 4 per wave), lane r < PS owns template row r as packed dwords (unused bytes zero).  Same
+// arithmetic per pixel / per candidate as the reference; no LDS, and the dependent global loads of the patches of a wave
+// overlap (a one-patch-per-wavefront version of this kernel was 2.4x slower at 8x8 and 2.7x slower at 11x11).  ZMSSD sums use v_dot4_u32_u8.
+template <int PS> struct PRow { unsigned w[(PS + 3) / 4]; };
+template <int PS> DEVFN PRow<PS> load_row(const uint8_t* p) {
+  PRow<PS> r;
+#pragma unroll
+  for (int k = 0; k < (PS + 3) / 4; k++) r.w[k] = 0u;
+  __builtin_memcpy(&r, p, PS);
+  return r;
+}
+template <int PS> DEVFN int row_byte(const PRow<PS>& r, int x) { return (int)((r.w[x >> 2] >> (8 * (x & 3))) & 255u); }
+template <int G> DEVFN int grp_sum_i(int v) { for (int d = 1; d < G; d <<= 1) v += __shfl_xor(v, d); return v; }
+template <int G> DEVFN double grp_sum_d(double v) { for (int d = 1; d < G; d <<= 1) v += __shfl_xor(v, d); return v; }
 DEVFN unsigned udot4(unsigned a, unsigned b, unsigned c) { return __builtin_amdgcn_udot4(a, b, c, false); }
 
-__global__ __launch_bounds__(64) void k_search8(MapDev m, TrackParams tp, SearchArgs a, int stage) {
-  constexpr int PS = 8, NPIX = 64, HALF = 4;
+template <int PS, int G>
+__global__ __launch_bounds__(64) void k_searchN(MapDev m, TrackParams tp, SearchArgs a, int stage) {
+  constexpr int NPIX = PS * PS, HALF = PS / 2, PPW = 64 / G, NW = (PS + 3) / 4;
   const int s = blockIdx.y;
   TrackerState* st = &m.st[s];
   if (!(st->map_good && st->lost_frames < 3)) return;
   const int nsearch = st->n_search;
-  if ((int)blockIdx.x * 8 >= nsearch) return;
-  const int lane = threadIdx.x, grp = lane >> 3, sub = lane & 7;
-  const int e = blockIdx.x * 8 + grp;
+  if ((int)blockIdx.x * PPW >= nsearch) return;
+  const int lane = threadIdx.x, grp = lane / G, sub = lane % G;
+  const bool rowact = sub < PS;                                      // this lane owns a template row
+  const int e = blockIdx.x * PPW + grp;
   bool act = e < nsearch;                                            // this lane group has a patch
   const bool lead = sub == 0;
   const int2 ent = act ? m.search_list[(size_t)s * tp.max_points + e] : make_int2(0, 0);
@@ -501,7 +283,9 @@ __global__ __launch_bounds__(64) void k_search8(MapDev m, TrackParams tp, Search
     if (dx * dx + dy * dy > 0.07 * 0.07) refresh = true;
   }
   refresh = refresh && act;
-  uint2 trow;                                                        // template row `sub`
+  PRow<PS> trow;                                                     // template row `sub`
+#pragma unroll
+  for (int k = 0; k < NW; k++) trow.w[k] = 0u;
   int tsum, tsumsq;
   if (__any(refresh)) {
     // transform_image (jni/vision/ImageHandler.cpp:21-113): same accumulated stepping of the sample position
@@ -524,7 +308,7 @@ __global__ __launch_bounds__(64) void k_search8(MapDev m, TrackParams tp, Search
     if (refresh) {
       int nOutside = 0, sum = 0, sumsq = 0;
       const float x_bound = (float)(iw - 1), y_bound = (float)(ih - 1);
-      unsigned w0 = 0, w1 = 0;
+      if (rowact) {
 #pragma unroll
       for (int j = 0; j < PS; j++) {
         double x = px, y = py;
@@ -536,20 +320,20 @@ __global__ __launch_bounds__(64) void k_search8(MapDev m, TrackParams tp, Search
           const uint8_t* q0 = src + (size_t)ly * sp + lx;
           v = (uint8_t)((1 - y) * ((1 - x) * q0[0] + x * q0[1]) + y * ((1 - x) * q0[sp] + x * q0[sp + 1]));
         } else nOutside++;
-        if (j < 4) w0 |= (unsigned)v << (8 * j); else w1 |= (unsigned)v << (8 * (j - 4));
+        trow.w[j >> 2] |= (unsigned)v << (8 * (j & 3));
         sum += v; sumsq += v * v;
       }
-      trow = make_uint2(w0, w1);
-      *(uint2*)(gtmpl + sub * PS) = trow;
-      nOutside = grp_sum_i(nOutside);
-      tsum = grp_sum_i(sum); tsumsq = grp_sum_i(sumsq);              // MakeTemplateSums :152-164
+      __builtin_memcpy(gtmpl + sub * PS, &trow, PS);
+      }
+      nOutside = grp_sum_i<G>(nOutside);
+      tsum = grp_sum_i<G>(sum); tsumsq = grp_sum_i<G>(sumsq);        // MakeTemplateSums :152-164
       flags = nOutside ? (flags | TDF_TMPL_BAD) : (flags & ~TDF_TMPL_BAD);
       flags |= TDF_HAVE_LAST;
       if (lead) { td.tsum = tsum; td.tsumsq = tsumsq; for (int i = 0; i < 4; i++) td.last_warp[i] = m2[i]; }
     }
   }
   if (!refresh) {
-    trow = *(const uint2*)(gtmpl + sub * PS);
+    if (rowact) trow = load_row<PS>(gtmpl + sub * PS);
     tsum = td.tsum; tsumsq = td.tsumsq;
   }
   if (act && (flags & TDF_TMPL_BAD)) {                               // jni/Tracker.cc:637-640
@@ -582,9 +366,8 @@ __global__ __launch_bounds__(64) void k_search8(MapDev m, TrackParams tp, Search
     i1 = nBottomPlusOne >= rows ? a.ncorners[s * NLEV + level] : lut[nBottomPlusOne];
   }
   const double r2max = (double)(nRange * nRange);
-  const unsigned tl = trow.x, th = trow.y;
-  for (int base = i0; __any(base < i1); base += 8) {
-    // filter 8 corners of the row-LUT window at a time (:216-219); survivors are evaluated in raster order
+  for (int base = i0; __any(base < i1); base += G) {
+    // filter G corners of the row-LUT window at a time (:216-219); survivors are evaluated in raster order
     const int ci = base + sub;
     bool ok = false;
     uint32_t cval = 0;
@@ -596,24 +379,27 @@ __global__ __launch_bounds__(64) void k_search8(MapDev m, TrackParams tp, Search
         ok = !(dx * dx + dy * dy > r2max);
       }
     }
-    unsigned gm = (unsigned)(__ballot(ok) >> (grp * 8)) & 255u;
+    unsigned gm = (unsigned)(__ballot(ok) >> (grp * G)) & ((1u << G) - 1u);
     nEval += __popc(gm);
     while (__any(gm != 0)) {
       const bool has = gm != 0;
       const int k = has ? __ffs(gm) - 1 : 0;
-      const uint32_t c = __shfl(cval, grp * 8 + k);
+      const uint32_t c = __shfl(cval, grp * G + k);
       gm &= gm - 1;
       // ZMSSDAtPoint (:352-380): one image row per lane
       const int cx = c & 0xFFFF, cy = c >> 16;
       const bool inside = has && cx >= HALF && cy >= HALF && cx < cols - HALF && cy < rows - HALF;   // in_image_with_border
       unsigned sA = 0, sQ = 0, sX = 0;
-      if (inside) {
-        const uint2 n = load_row8(img + (size_t)(cy - HALF + sub) * ip + (cx - HALF));
-        sA = udot4(n.x, 0x01010101u, udot4(n.y, 0x01010101u, 0u));
-        sQ = udot4(n.x, n.x, udot4(n.y, n.y, 0u));
-        sX = udot4(n.x, tl, udot4(n.y, th, 0u));
+      if (inside && rowact) {
+        const PRow<PS> n = load_row<PS>(img + (size_t)(cy - HALF + sub) * ip + (cx - HALF));
+#pragma unroll
+        for (int k = 0; k < NW; k++) {                               // the pad bytes of both rows are zero
+          sA = udot4(n.w[k], 0x01010101u, sA);
+          sQ = udot4(n.w[k], n.w[k], sQ);
+          sX = udot4(n.w[k], trow.w[k], sX);
+        }
       }
-      sA = grp_sum_i(sA); sQ = grp_sum_i(sQ); sX = grp_sum_i(sX);
+      sA = grp_sum_i<G>(sA); sQ = grp_sum_i<G>(sQ); sX = grp_sum_i<G>(sX);
       if (has) {
         int ssd = tp.max_ssd + 1;
         if (inside) {
@@ -634,7 +420,7 @@ __global__ __launch_bounds__(64) void k_search8(MapDev m, TrackParams tp, Search
   const uint32_t bc = found ? corners[bestIdx] : 0u;
   const double coarse[2] = {level_zero_pos((double)(bc & 0xFFFF), level), level_zero_pos((double)(bc >> 16), level)};
   if (found) flags |= TDF_FOUND;
-  const bool dosub = found && nSubPixIts > 0;                        // refined by k_subpix8, which also counts it as found
+  const bool dosub = found && nSubPixIts > 0;                        // refined by k_subpixN, which also counts it as found
   if (found) {                                                       // :668-671
     flags = dosub ? (flags | TDF_SUBPIX) : (flags & ~TDF_SUBPIX);
     if (lead) { tdflags = flags; td.sqrt_inv_noise = 1.0 / scale; td.vfound[0] = coarse[0]; td.vfound[1] = coarse[1]; }
@@ -645,19 +431,20 @@ __global__ __launch_bounds__(64) void k_search8(MapDev m, TrackParams tp, Search
   }
 }
 
-// MakeSubPixTemplate (jni/PatchFinder.cc:242-271) + IterateSubPixToConvergence (:273-350) for the patches k_search8 found
+// MakeSubPixTemplate (jni/PatchFinder.cc:242-271) + IterateSubPixToConvergence (:273-350) for the patches k_searchN found
 // with a sub-pixel budget (level-3 points in the fine stage, every point in the coarse stage).  A kernel of its own so
 // that its registers (gradients, 3x3 inverse) do not halve the occupancy of the search proper.  Eight patches per
-// wavefront, lane y owns interior row y of the 8x8 template.
-__global__ __launch_bounds__(64) void k_subpix8(MapDev m, TrackParams tp, SearchArgs a, int stage) {
-  constexpr int PS = 8, HALF = 4;
+// wavefront, lane y owns interior row y of the template.
+template <int PS, int G>
+__global__ __launch_bounds__(64) void k_subpixN(MapDev m, TrackParams tp, SearchArgs a, int stage) {
+  constexpr int HALF = PS / 2, PPW = 64 / G, NW = (PS + 3) / 4, Q = PS - 2;
   const int s = blockIdx.y;
   TrackerState* st = &m.st[s];
   if (!(st->map_good && st->lost_frames < 3)) return;
   const int nsub = stage == 0 ? st->n_search : st->n_l3;             // entries that carry a sub-pixel budget
-  if ((int)blockIdx.x * 8 >= nsub) return;
-  const int lane = threadIdx.x, grp = lane >> 3, sub = lane & 7;
-  const int e = blockIdx.x * 8 + grp;
+  if ((int)blockIdx.x * PPW >= nsub) return;
+  const int lane = threadIdx.x, grp = lane / G, sub = lane % G;
+  const int e = blockIdx.x * PPW + grp;
   const bool lead = sub == 0;
   const int2 ent = e < nsub ? m.search_list[(size_t)s * tp.max_points + e] : make_int2(0, 0);
   const int idx = ent.x, nSubPixIts = ent.y;
@@ -671,14 +458,17 @@ __global__ __launch_bounds__(64) void k_subpix8(MapDev m, TrackParams tp, Search
   const int rows = a.h[level], cols = a.w[level];
   const uint8_t* img = a.img[level] + (size_t)s * a.img_sstride[level];
   const int ip = a.img_pitch[level];
-  const uint2 trow = *(const uint2*)(m.tmpl + ((size_t)s * tp.max_points + idx) * TMPL_PITCH + sub * PS);
-  const bool rowok = sub >= 1 && sub <= 6;
-  const uint2 rup = make_uint2(__shfl(trow.x, lane - 1), __shfl(trow.y, lane - 1));
-  const uint2 rdn = make_uint2(__shfl(trow.x, lane + 1), __shfl(trow.y, lane + 1));
-  double gx[6], gy[6];
+  PRow<PS> trow, rup, rdn;
+#pragma unroll
+  for (int k = 0; k < NW; k++) trow.w[k] = 0u;
+  if (sub < PS) trow = load_row<PS>(m.tmpl + ((size_t)s * tp.max_points + idx) * TMPL_PITCH + sub * PS);
+  const bool rowok = sub >= 1 && sub <= Q;
+#pragma unroll
+  for (int k = 0; k < NW; k++) { rup.w[k] = __shfl(trow.w[k], lane - 1); rdn.w[k] = __shfl(trow.w[k], lane + 1); }
+  double gx[Q], gy[Q];
   double h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0;
 #pragma unroll
-  for (int x = 1; x <= 6; x++) {
+  for (int x = 1; x <= Q; x++) {
     gx[x - 1] = 0; gy[x - 1] = 0;
     if (rowok) {
       gx[x - 1] = 0.5 * (row_byte(trow, x + 1) - row_byte(trow, x - 1));
@@ -687,12 +477,12 @@ __global__ __launch_bounds__(64) void k_subpix8(MapDev m, TrackParams tp, Search
       h11 += gy[x - 1] * gy[x - 1]; h12 += gy[x - 1]; h22 += 1.0;
     }
   }
-  h00 = grp_sum_d(h00); h01 = grp_sum_d(h01); h02 = grp_sum_d(h02);     // quarter-integers: exact in any order
-  h11 = grp_sum_d(h11); h12 = grp_sum_d(h12); h22 = grp_sum_d(h22);
+  h00 = grp_sum_d<G>(h00); h01 = grp_sum_d<G>(h01); h02 = grp_sum_d<G>(h02);     // quarter-integers: exact in any order
+  h11 = grp_sum_d<G>(h11); h12 = grp_sum_d<G>(h12); h22 = grp_sum_d<G>(h22);
   const double H[9] = {h00, h01, h02, h01, h11, h12, h02, h12, h22};
   double Hinv[9];
   inv3(H, Hinv);
-  double sub0 = td.vfound[0], sub1 = td.vfound[1], meanDiff = 0.0;      // the coarse position k_search8 left
+  double sub0 = td.vfound[0], sub1 = td.vfound[1], meanDiff = 0.0;      // the coarse position k_searchN left
   bool running = dosub, converged = false;
   for (int it = 0; __any(running); it++) {
     if (it >= nSubPixIts) running = false;
@@ -710,15 +500,15 @@ __global__ __launch_bounds__(64) void k_subpix8(MapDev m, TrackParams tp, Search
       const float fTL = (float)((1.0 - dX) * (1.0 - dY)), fTR = (float)((dX) * (1.0 - dY));
       const float fBL = (float)((1.0 - dX) * (dY)), fBR = (float)((dX) * (dY));
       const uint8_t* r0 = img + (size_t)((int)by + sub) * ip + (int)bx + 1;
-      const uint2 p0 = load_row8(r0), p1 = load_row8(r0 + ip);
+      const PRow<PS> p0 = load_row<PS>(r0), p1 = load_row<PS>(r0 + ip);
 #pragma unroll
-      for (int x = 1; x <= 6; x++) {
+      for (int x = 1; x <= Q; x++) {
         const float fPixel = fTL * row_byte(p0, x - 1) + fTR * row_byte(p0, x) + fBL * row_byte(p1, x - 1) + fBR * row_byte(p1, x);
         const double dDiff = (fPixel - (float)row_byte(trow, x)) + meanDiff;
         a0 += dDiff * gx[x - 1]; a1 += dDiff * gy[x - 1]; a2 += dDiff;
       }
     }
-    a0 = grp_sum_d(a0); a1 = grp_sum_d(a1); a2 = grp_sum_d(a2);
+    a0 = grp_sum_d<G>(a0); a1 = grp_sum_d<G>(a1); a2 = grp_sum_d<G>(a2);
     if (running) {
       const double u0 = Hinv[0] * a0 + Hinv[1] * a1 + Hinv[2] * a2;
       const double u1 = Hinv[3] * a0 + Hinv[4] * a1 + Hinv[5] * a2;
@@ -1124,10 +914,12 @@ int trk_track_map(vslam_system* sys) {
   if (!tp.coarse_disabled) {
     const int nc = 2 * tp.coarse_max;
     if (tp.P == 8) {
-      hipLaunchKernelGGL(k_search8, dim3((nc + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 0);
-      if (tp.coarse_subpix_its > 0) hipLaunchKernelGGL(k_subpix8, dim3((nc + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 0);
+      hipLaunchKernelGGL((k_searchN<8, 8>), dim3((nc + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 0);
+      if (tp.coarse_subpix_its > 0) hipLaunchKernelGGL((k_subpixN<8, 8>), dim3((nc + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 0);
+    } else {
+      hipLaunchKernelGGL((k_searchN<11, 16>), dim3((nc + 3) / 4, S), dim3(64), 0, sys->stream, m, tp, a, 0);
+      if (tp.coarse_subpix_its > 0) hipLaunchKernelGGL((k_subpixN<11, 16>), dim3((nc + 3) / 4, S), dim3(64), 0, sys->stream, m, tp, a, 0);
     }
-    else hipLaunchKernelGGL(k_search<11>, dim3(nc, S), dim3(64), 0, sys->stream, m, tp, a, 0);
     prof_mark(sys, 6);
     hipLaunchKernelGGL(k_pose, dim3(S), dim3(POSE_THREADS), 0, sys->stream, m, tp, 0);
   } else prof_mark(sys, 6);
@@ -1135,10 +927,12 @@ int trk_track_map(vslam_system* sys) {
   hipLaunchKernelGGL(k_plan, dim3(S), dim3(TRK_THREADS), 0, sys->stream, m, tp, 1);
   prof_mark(sys, 8);
   if (tp.P == 8) {
-    hipLaunchKernelGGL(k_search8, dim3((maxSearch + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 1);
-    if (tp.fine_subpix_its > 0) hipLaunchKernelGGL(k_subpix8, dim3((maxSearch + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 1);
+    hipLaunchKernelGGL((k_searchN<8, 8>), dim3((maxSearch + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 1);
+    if (tp.fine_subpix_its > 0) hipLaunchKernelGGL((k_subpixN<8, 8>), dim3((maxSearch + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 1);
+  } else {
+    hipLaunchKernelGGL((k_searchN<11, 16>), dim3((maxSearch + 3) / 4, S), dim3(64), 0, sys->stream, m, tp, a, 1);
+    if (tp.fine_subpix_its > 0) hipLaunchKernelGGL((k_subpixN<11, 16>), dim3((maxSearch + 3) / 4, S), dim3(64), 0, sys->stream, m, tp, a, 1);
   }
-  else hipLaunchKernelGGL(k_search<11>, dim3(maxSearch, S), dim3(64), 0, sys->stream, m, tp, a, 1);
   prof_mark(sys, 9);
   hipLaunchKernelGGL(k_pose, dim3(S), dim3(POSE_THREADS), 0, sys->stream, m, tp, 1);
   HIPCHK(hipGetLastError());
