@@ -2,7 +2,9 @@
 //   * vslam_bundle_*  : stand-alone, batched Bundle (jni/Bundle.h:111-121), one persistent workgroup per problem
 //   * MapMaker::AddKeyFrame (jni/MapMaker.cc:470-506) + BundleAdjustRecent/All (:776-851) + BundleAdjust (:854-960)
 //     + HandleBadPoints (:140-164) for every stream of a system, driven by the tracker's device-side decision
-//     (kf_pending) -- no host synchronisation between TrackFrame and the local bundle adjustment.
+//     (kf_pending) -- no host synchronisation between TrackFrame and the local bundle adjustment.  With
+//     vslam_params.ba_delay_frames = D > 0 Bundle::Compute runs on the map-maker stream and its result is applied at the
+//     start of frame t + D (ba_frame_start), the deterministic stand-in for PTAM's map-maker thread.
 #include "vslam_internal.h"
 #include "ba_device.h"
 #include <string.h>

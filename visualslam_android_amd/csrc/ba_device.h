@@ -7,7 +7,9 @@
 //   measurements in AddMeas order: (p, c), found, sqrt-inv-noise, state, v3Cam, weighted camera derivatives, epsilon.
 //   The Jacobians A (2x6), B (2x3) and W = A^T B (6x3) are NOT stored: every consumer re-derives them from v3Cam, the
 //   weighted derivatives and the camera rotation (about 150 flops instead of 288 B written and up to 1 KB re-read per
-//   measurement and LM trial -- at 256 concurrent problems the kernel is HBM-bound, not flop-bound).
+//   measurement and LM trial).  At 256-512 concurrent problems the kernel is bound by dependent-load latency and fp64
+//   issue at 2 waves per SIMD, not by HBM or flops (profiles/README.md): hence the batched loads and the per-phase
+//   functions below.
 //   lut[c][p] -> measurement index (GenerateMeasLUTs :566-575)
 // Reductions are deterministic: "segmented" per-camera / per-camera-pair sums are taken by one wavefront each
 // (lanes stride over the points, then __shfl_xor butterflies), per-point sums by one lane in camera order.

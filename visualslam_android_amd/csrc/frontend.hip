@@ -1,7 +1,7 @@
 // Frame front-end on gfx950: KeyFrame::MakeKeyFrame_Lite (jni/KeyFrame.cc:5-51) and fast_nonmax
 // (jni/vision/cvfast.cpp:9243-9400) for all streams of a system at once.
 //
-// Kernels (all HBM-bound byte/integer work; one pass over each level image):
+// Kernels (byte/integer work, one pass over each level image; measured LDS-issue bound):
 //   k_pyr_fast0   one workgroup per 16-row band of level 0: the band (+3-row halo) is staged in LDS
 //                 with 16-B coalesced loads, levels 1..3 of the band are produced from LDS
 //                 ((a+b+c+d+2)>>2) and written, and FAST-10 runs on the staged rows in two phases: a 5-read
@@ -12,6 +12,8 @@
 //                 thread expands its words at its scanned offset -> bit-exact raster-ordered corner list
 //                 and row LUT (jni/KeyFrame.cc:43-49) without ordered atomics.
 //   k_score / k_nonmax   compute_fast_score_old + nonmax_suppression, one lane per corner.
+//   k_candidates / k_thin_candidates   MakeKeyFrame_Rest's Shi-Tomasi candidates (jni/KeyFrame.cc:66-95) and
+//                 MapMaker::ThinCandidates (jni/MapMaker.cc:393-422), ordered block compaction.
 #include "vslam_internal.h"
 
 #define BAND 16          // level-0 rows per workgroup (multiple of 8: three halvings stay inside a band)
