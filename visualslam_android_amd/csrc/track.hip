@@ -540,6 +540,7 @@ __device__ unsigned long long g_pose_prof[16];
 #define POSE_STAMP(id) do { } while (0)
 #endif
 #define POSE_WAVES (POSE_THREADS / 64)
+#define POSE_ILP 2
 
 struct PoseItem {            // TrackerData fields used by the pose iterations (jni/TrackerData.h:36-66)
   double cam[3], image[2], derivs[4], vfound[2], sqrt_inv_noise;   // the 2x6 Jacobian is re-derived from cam + derivs where used
@@ -591,10 +592,18 @@ DEVFN void calc_pose_update(const PoseWs& ws, MapPointDev* pts, int n, int nvali
   double acc[27];
 #pragma unroll
   for (int i = 0; i < 27; i++) acc[i] = 0.0;
-  for (int e = threadIdx.x; e < n; e += POSE_THREADS) {
-    if (!(ws.i[e] & TDF_FOUND)) continue;
-    PoseItem t;
-    item_load(t, ws, e);
+  for (int e0 = threadIdx.x; e0 < n; e0 += POSE_ILP * POSE_THREADS) {
+    PoseItem tt[POSE_ILP];
+#pragma unroll
+    for (int u = 0; u < POSE_ILP; u++) {
+      const int e = e0 + u * POSE_THREADS;
+      item_load(tt[u], ws, e < n ? e : n - 1);
+      if (e >= n) tt[u].flags = 0;
+    }
+#pragma unroll
+    for (int u = 0; u < POSE_ILP; u++) {
+    const PoseItem& t = tt[u];
+    if (!(t.flags & TDF_FOUND)) continue;
     const double err[2] = {(t.vfound[0] - t.image[0]) * t.sqrt_inv_noise, (t.vfound[1] - t.image[1]) * t.sqrt_inv_noise};
     const double es = err[0] * err[0] + err[1] * err[1];
     const double w = tukey_weight(es, sigma2);
@@ -616,6 +625,7 @@ DEVFN void calc_pose_update(const PoseWs& ws, MapPointDev* pts, int n, int nvali
 #pragma unroll
         for (int c = r; c < 6; c++) acc[q++] += Jw * J[c];
       }
+    }
     }
   }
   POSE_STAMP(4);
@@ -659,7 +669,7 @@ DEVFN double kf_linear_dist(const Pose& a, const Pose& b) {
 }
 
 // stage 0: coarse GN iterations (:463-490); stage 1: fine GN iterations + end of TrackMap/TrackFrame.
-__global__ __launch_bounds__(POSE_THREADS) void k_pose(MapDev m, TrackParams tp, int stage) {
+__global__ __launch_bounds__(POSE_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pose(MapDev m, TrackParams tp, int stage) {
   const int s = blockIdx.x;
   TrackerState* st = &m.st[s];
   if (!(st->map_good && st->lost_frames < 3)) return;
@@ -705,27 +715,44 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose(MapDev m, TrackParams tp,
   POSE_STAMP(0);
   for (int iter = 0; iter < 10; iter++) {                            // coarse :466-488, fine :543-577
     const bool nonlinear = stage == 0 || iter == 0 || iter == 4 || iter == 9;
-    for (int e = threadIdx.x; e < n; e += POSE_THREADS) {
-      double e2 = __builtin_huge_val();
-      if (ws.i[e] & TDF_FOUND) {
-        PoseItem t;
-        item_load(t, ws, e);
-        if (iter != 0) {
-          if (nonlinear) td_project_and_derivs(t, t.flags, pts[t.idx].pos, pose, tp.cam);
-          else {                                                     // LinearUpdate, jni/TrackerData.h:125-131
-            double jac[12], a = 0, b = 0;
-            td_calc_jacobian(t, jac);                                // m26Jacobian of the last non-linear iteration
+    // POSE_ILP entries per thread in flight: all their loads are issued (index clamped, no branch in between) before any
+    // of them is advanced -- the loop is latency-bound at one workgroup of four waves per stream
+    for (int e0 = threadIdx.x; e0 < n; e0 += POSE_ILP * POSE_THREADS) {
+      PoseItem t[POSE_ILP]; double pos[POSE_ILP][3];
 #pragma unroll
-            for (int k = 0; k < 6; k++) { a += jac[k] * last_up[k]; b += jac[6 + k] * last_up[k]; }
-            t.image[0] += a; t.image[1] += b;
-          }
-          item_store(t, ws, e, nonlinear);
-        }
-        const double e0 = (t.vfound[0] - t.image[0]) * t.sqrt_inv_noise;   // v2Error_CovScaled, :707
-        const double e1 = (t.vfound[1] - t.image[1]) * t.sqrt_inv_noise;
-        e2 = e0 * e0 + e1 * e1;
+      for (int u = 0; u < POSE_ILP; u++) {
+        const int e = e0 + u * POSE_THREADS;
+        item_load(t[u], ws, e < n ? e : n - 1);
       }
-      sortbuf[e] = e2;
+      if (nonlinear && iter != 0) {
+#pragma unroll
+        for (int u = 0; u < POSE_ILP; u++)
+#pragma unroll
+          for (int k = 0; k < 3; k++) pos[u][k] = pts[t[u].idx].pos[k];
+      }
+#pragma unroll
+      for (int u = 0; u < POSE_ILP; u++) {
+        const int e = e0 + u * POSE_THREADS;
+        if (e >= n) continue;
+        double e2 = __builtin_huge_val();
+        if (t[u].flags & TDF_FOUND) {
+          if (iter != 0) {
+            if (nonlinear) td_project_and_derivs(t[u], t[u].flags, pos[u], pose, tp.cam);
+            else {                                                   // LinearUpdate, jni/TrackerData.h:125-131
+              double jac[12], a = 0, b = 0;
+              td_calc_jacobian(t[u], jac);                           // m26Jacobian of the last non-linear iteration
+#pragma unroll
+              for (int k = 0; k < 6; k++) { a += jac[k] * last_up[k]; b += jac[6 + k] * last_up[k]; }
+              t[u].image[0] += a; t[u].image[1] += b;
+            }
+            item_store(t[u], ws, e, nonlinear);
+          }
+          const double r0 = (t[u].vfound[0] - t[u].image[0]) * t[u].sqrt_inv_noise;   // v2Error_CovScaled, :707
+          const double r1 = (t[u].vfound[1] - t[u].image[1]) * t[u].sqrt_inv_noise;
+          e2 = r0 * r0 + r1 * r1;
+        }
+        sortbuf[e] = e2;
+      }
     }
     POSE_STAMP(1);
     const double override_sigma = iter > 5 ? (stage == 0 ? 1.0 : 16.0) : 0.0;
