@@ -17,6 +17,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
 
@@ -95,7 +96,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("VSLAM_BENCH_STREAMS", 512)), help="sequences per GPU")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("VSLAM_BENCH_STREAMS", 1024)), help="sequences per GPU")
     ap.add_argument("--systems", type=int, default=int(os.environ.get("VSLAM_BENCH_SYSTEMS", 1)),
                     help="split the streams over this many vslam_system handles (one HIP stream each) so their kernels overlap")
     ap.add_argument("--width", type=int, default=640)
@@ -132,12 +133,16 @@ def main():
     vp = capi.default_params(W, H, S, patch_size=args.patch, device=local_rank)
     fe = capi.System(capi.default_params(W, H, 1, patch_size=args.patch, device=local_rank))   # front-end used to pick map corners
 
-    def corner_fn(gray):
-        fe.make_keyframe_lite(gray[None])
-        fe.fast_nonmax()
-        return [fe.read_max_corners(0, l)[0] for l in range(4)]
+    fe_lock = threading.Lock()
 
-    maps = [feeder.build_map(f, corner_fn) for f in feeders]
+    def corner_fn(gray):
+        with fe_lock:                          # one front-end system; the renders and the numpy of build_map run in parallel
+            fe.make_keyframe_lite(gray[None])
+            fe.fast_nonmax()
+            return [fe.read_max_corners(0, l)[0] for l in range(4)]
+
+    with ThreadPoolExecutor(nthreads) as ex:
+        maps = list(ex.map(lambda f: feeder.build_map(f, corner_fn), feeders))
     fe.close()
     NS = max(1, min(args.systems, S))
     assert S % NS == 0, "--streams must be a multiple of --systems"

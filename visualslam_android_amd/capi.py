@@ -267,18 +267,27 @@ class System:
         """m: dict from visualslam_android_amd.feeder.build_map"""
         for k in m["keyframes"]:
             self.add_keyframe(stream, k["pose"], k["fixed"], k["image"], k["depth_mean"], k["depth_sigma"])
-        pts = m["points"]
-        if pts:
-            pos = np.array([q["pos"] for q in pts], np.float64); right = np.array([q["right"] for q in pts], np.float64)
-            down = np.array([q["down"] for q in pts], np.float64); kf_ = np.array([q["src_kf"] for q in pts], np.int32)
-            lv_ = np.array([q["level"] for q in pts], np.int32); ir = np.array([[q["irx"], q["iry"]] for q in pts], np.int32)
-            _check(self.lib.vslam_map_add_points(self.h, stream, len(pts), pos.ctypes.data, kf_.ctypes.data, lv_.ctypes.data,
+        pk = m.get("packed") if hasattr(m, "get") else None
+        if pk is not None and "points" not in dict.keys(m) and "meas" not in dict.keys(m):   # untouched build_map output: no per-item Python
+            pos, right, down = (np.ascontiguousarray(pk[k_], np.float64) for k_ in ("pos", "right", "down"))
+            kf_, lv_, ir = (np.ascontiguousarray(pk[k_], np.int32) for k_ in ("src_kf", "level", "ir"))
+            npts = len(pos)
+            kf, pt, lv, sp, src = (np.ascontiguousarray(pk[k_], np.int32) for k_ in ("m_kf", "m_pt", "m_level", "m_subpix", "m_source"))
+            root = np.ascontiguousarray(pk["m_root"], np.float64)
+        else:
+            pts = m["points"]
+            npts = len(pts)
+            pos = np.array([q["pos"] for q in pts], np.float64).reshape(-1, 3); right = np.array([q["right"] for q in pts], np.float64).reshape(-1, 3)
+            down = np.array([q["down"] for q in pts], np.float64).reshape(-1, 3); kf_ = np.array([q["src_kf"] for q in pts], np.int32)
+            lv_ = np.array([q["level"] for q in pts], np.int32); ir = np.array([[q["irx"], q["iry"]] for q in pts], np.int32).reshape(-1, 2)
+            ms = m["meas"]
+            kf = np.array([x[0] for x in ms], np.int32); pt = np.array([x[1] for x in ms], np.int32)
+            lv = np.array([x[2] for x in ms], np.int32); root = np.array([[x[3], x[4]] for x in ms], np.float64).reshape(-1, 2)
+            sp = np.array([x[5] for x in ms], np.int32); src = np.array([x[6] for x in ms], np.int32)
+        if npts:
+            _check(self.lib.vslam_map_add_points(self.h, stream, npts, pos.ctypes.data, kf_.ctypes.data, lv_.ctypes.data,
                                                  ir.ctypes.data, right.ctypes.data, down.ctypes.data))
-        ms = m["meas"]
-        n = len(ms)
-        kf = np.array([x[0] for x in ms], np.int32); pt = np.array([x[1] for x in ms], np.int32)
-        lv = np.array([x[2] for x in ms], np.int32); root = np.array([[x[3], x[4]] for x in ms], np.float64)
-        sp = np.array([x[5] for x in ms], np.int32); src = np.array([x[6] for x in ms], np.int32)
+        n = len(kf)
         _check(self.lib.vslam_map_add_measurements(self.h, stream, n, kf.ctypes.data, pt.ctypes.data, lv.ctypes.data,
                                                    root.ctypes.data, sp.ctypes.data, src.ctypes.data))
         _check(self.lib.vslam_map_set_good(self.h, stream))

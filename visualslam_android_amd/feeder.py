@@ -137,7 +137,7 @@ def build_map(feeder, corner_fn, n_keyframes=8, kf_spacing=20, per_level=(260, 9
     rng = np.random.default_rng(seed)
     W, H = feeder.w, feeder.h
     times = [-kf_spacing * (n_keyframes - k) for k in range(n_keyframes)]
-    kfs, points, meas = [], [], []
+    kfs = []
     poses = [feeder.pose(t) for t in times]
     Rs = [p[:9].reshape(3, 3) for p in poses]
     ts = [p[9:] for p in poses]
@@ -145,6 +145,9 @@ def build_map(feeder, corner_fn, n_keyframes=8, kf_spacing=20, per_level=(260, 9
         img = feeder.render_pose(poses[k], key=1000 + k)
         kfs.append({"pose": poses[k].copy(), "fixed": k == 0, "image": img, "depth_mean": 1.0, "depth_sigma": 0.1})
     depth_acc = [[] for _ in range(n_keyframes)]
+    n_points = 0
+    P = {k_: [] for k_ in ("pos", "right", "down", "src_kf", "level", "ir")}
+    M = {k_: [] for k_ in ("kf", "pt", "level", "root", "subpix", "source")}
     for k in range(n_keyframes):
         corners = corner_fn(kfs[k]["image"])
         R, t = Rs[k], ts[k]
@@ -186,15 +189,22 @@ def build_map(feeder, corner_fn, n_keyframes=8, kf_spacing=20, per_level=(260, 9
             dop = dwn * (camh / np.abs(dwn[:, 2]))[:, None]
             right_w = (rop - cop) @ R                             # R^T * v for row vectors
             down_w = (dop - cop) @ R
-            base = len(points)
             idx = np.flatnonzero(good)
-            for j in idx:
-                points.append({"pos": pos[j].copy(), "src_kf": k, "level": level, "irx": int(xs[j]), "iry": int(ys[j]),
-                               "right": right_w[j].copy(), "down": down_w[j].copy()})
+            base = n_points
             pid = base + np.arange(len(idx))
-            for j, q in zip(idx, pid):
-                meas.append((k, int(q), level, float(rx[j]), float(ry[j]), 1, 2))   # SRC_ROOT
-            depth_acc[k].extend(pc[idx, 2].tolist())
+            n_points += len(idx)
+            P["pos"].append(pos[idx]); P["right"].append(right_w[idx]); P["down"].append(down_w[idx])
+            P["src_kf"].append(np.full(len(idx), k, np.int32)); P["level"].append(np.full(len(idx), level, np.int32))
+            P["ir"].append(np.stack([xs[idx], ys[idx]], 1).astype(np.int32))
+
+            def add_meas(kf_id, pts_, u_, v_, source):
+                n_ = len(pts_)
+                M["kf"].append(np.full(n_, kf_id, np.int32)); M["pt"].append(np.asarray(pts_, np.int32))
+                M["level"].append(np.full(n_, level, np.int32)); M["root"].append(np.stack([u_, v_], 1).astype(np.float64))
+                M["subpix"].append(np.ones(n_, np.int32)); M["source"].append(np.full(n_, source, np.int32))
+
+            add_meas(k, pid, rx[idx], ry[idx], 2)                  # SRC_ROOT
+            depth_acc[k].append(pc[idx, 2])
             for k2 in range(n_keyframes):
                 if k2 == k:
                     continue
@@ -204,18 +214,40 @@ def build_map(feeder, corner_fn, n_keyframes=8, kf_spacing=20, per_level=(260, 9
                 u, v = _project_np(cam, W, H, pc2[:, 0] / zz, pc2[:, 1] / zz)
                 b = 12 * s
                 ins = (z > 0.001) & (u >= b) & (v >= b) & (u < W - b) & (v < H - b)
-                for q, uu, vv, zq in zip(pid[ins], u[ins], v[ins], z[ins]):
-                    meas.append((k2, int(q), level, float(uu), float(vv), 1, 0))    # SRC_TRACKER
-                depth_acc[k2].extend(z[ins].tolist())
+                add_meas(k2, pid[ins], u[ins], v[ins], 0)          # SRC_TRACKER
+                depth_acc[k2].append(z[ins])
+    packed = {key: (np.concatenate(val) if val else np.zeros((0,) + shp, dt)) for (key, val, shp, dt) in (
+        ("pos", P["pos"], (3,), np.float64), ("right", P["right"], (3,), np.float64), ("down", P["down"], (3,), np.float64),
+        ("src_kf", P["src_kf"], (), np.int32), ("level", P["level"], (), np.int32), ("ir", P["ir"], (2,), np.int32),
+        ("m_kf", M["kf"], (), np.int32), ("m_pt", M["pt"], (), np.int32), ("m_level", M["level"], (), np.int32),
+        ("m_root", M["root"], (2,), np.float64), ("m_subpix", M["subpix"], (), np.int32), ("m_source", M["source"], (), np.int32))}
     # scene depth per keyframe (MapMaker::RefreshSceneDepth, jni/MapMaker.cc:1236-1252)
     for k in range(n_keyframes):
-        zs = np.array(depth_acc[k])
+        zs = np.concatenate(depth_acc[k]) if depth_acc[k] else np.ones(1)
         kfs[k]["depth_mean"] = float(zs.mean())
         kfs[k]["depth_sigma"] = float(np.sqrt(max(0.0, (zs ** 2).mean() - zs.mean() ** 2)))
     if point_noise > 0:
-        for p in points:
-            p["pos"] = p["pos"] + rng.normal(0, point_noise, 3)
+        packed["pos"] = packed["pos"] + rng.normal(0, point_noise, packed["pos"].shape)
     if pose_noise[0] > 0 or pose_noise[1] > 0:
         for k in range(1, n_keyframes):
             kfs[k]["pose"] = se3_perturb(kfs[k]["pose"], rng, pose_noise[0], pose_noise[1])
-    return {"keyframes": kfs, "points": points, "meas": meas, "times": times}
+    return MapData(keyframes=kfs, packed=packed, times=times)
+
+
+class MapData(dict):
+    """The map as build_map leaves it: "keyframes" (list of dicts), "times", and "packed" numpy arrays of the points and
+    measurements.  "points" (list of dicts) and "meas" (list of tuples) -- the form the tests read -- are derived from
+    the packed arrays on first access."""
+
+    def __missing__(self, key):
+        pk = dict.__getitem__(self, "packed")
+        if key == "points":
+            val = [{"pos": pk["pos"][i].copy(), "src_kf": int(pk["src_kf"][i]), "level": int(pk["level"][i]), "irx": int(pk["ir"][i, 0]),
+                    "iry": int(pk["ir"][i, 1]), "right": pk["right"][i].copy(), "down": pk["down"][i].copy()} for i in range(len(pk["pos"]))]
+        elif key == "meas":
+            val = list(zip(pk["m_kf"].tolist(), pk["m_pt"].tolist(), pk["m_level"].tolist(), pk["m_root"][:, 0].tolist(),
+                           pk["m_root"][:, 1].tolist(), pk["m_subpix"].tolist(), pk["m_source"].tolist()))
+        else:
+            raise KeyError(key)
+        self[key] = val
+        return val
