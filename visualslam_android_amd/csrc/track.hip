@@ -366,47 +366,67 @@ __global__ __launch_bounds__(64) void k_searchN(MapDev m, TrackParams tp, Search
     i1 = nBottomPlusOne >= rows ? a.ncorners[s * NLEV + level] : lut[nBottomPlusOne];
   }
   const double r2max = (double)(nRange * nRange);
-  for (int base = i0; __any(base < i1); base += G) {
-    // filter G corners of the row-LUT window at a time (:216-219); survivors are evaluated in raster order
-    const int ci = base + sub;
-    bool ok = false;
-    uint32_t cval = 0;
-    if (ci < i1) {
-      cval = corners[ci];
-      const int cx = cval & 0xFFFF, cy = cval >> 16;
-      if (!(cx < nLeft || cx > nRight)) {
-        const double dx = irx - cx, dy = iry - cy;
-        ok = !(dx * dx + dy * dy > r2max);
-      }
-    }
-    unsigned gm = (unsigned)(__ballot(ok) >> (grp * G)) & ((1u << G) - 1u);
-    nEval += __popc(gm);
-    while (__any(gm != 0)) {
-      const bool has = gm != 0;
-      const int k = has ? __ffs(gm) - 1 : 0;
-      const uint32_t c = __shfl(cval, grp * G + k);
-      gm &= gm - 1;
-      // ZMSSDAtPoint (:352-380): one image row per lane
-      const int cx = c & 0xFFFF, cy = c >> 16;
-      const bool inside = has && cx >= HALF && cy >= HALF && cx < cols - HALF && cy < rows - HALF;   // in_image_with_border
-      unsigned sA = 0, sQ = 0, sX = 0;
-      if (inside && rowact) {
-        const PRow<PS> n = load_row<PS>(img + (size_t)(cy - HALF + sub) * ip + (cx - HALF));
+  // Filter 4 G corners of the row-LUT window per step (:216-219: x window, then the circular range test): lane `sub` takes
+  // corners base + j G + sub, j < 4, so the group's survivors form one bit mask in raster order.  Survivors are scored two
+  // at a time (both image rows are in flight before either is used) and compared in raster order (:223).
+  constexpr int CPL = 4;
+  for (int base = i0; __any(base < i1); base += CPL * G) {
+    uint32_t cval[CPL];
+    unsigned long long gm = 0;
 #pragma unroll
-        for (int k = 0; k < NW; k++) {                               // the pad bytes of both rows are zero
-          sA = udot4(n.w[k], 0x01010101u, sA);
-          sQ = udot4(n.w[k], n.w[k], sQ);
-          sX = udot4(n.w[k], trow.w[k], sX);
+    for (int j = 0; j < CPL; j++) {
+      const int ci = base + j * G + sub;
+      cval[j] = ci < i1 ? corners[ci] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < CPL; j++) {
+      const int ci = base + j * G + sub;
+      bool ok = false;
+      if (ci < i1) {
+        const int cx = cval[j] & 0xFFFF, cy = cval[j] >> 16;
+        if (!(cx < nLeft || cx > nRight)) {
+          const double dx = irx - cx, dy = iry - cy;
+          ok = !(dx * dx + dy * dy > r2max);
         }
       }
-      sA = grp_sum_i<G>(sA); sQ = grp_sum_i<G>(sQ); sX = grp_sum_i<G>(sX);
-      if (has) {
-        int ssd = tp.max_ssd + 1;
-        if (inside) {
-          const int SA = tsum, SB = (int)sA;
-          ssd = ((2 * SA * SB - SA * SA - SB * SB) / NPIX + (int)sQ + tsumsq - 2 * (int)sX);
+      gm |= (unsigned long long)((unsigned)(__ballot(ok) >> (grp * G)) & ((1u << G) - 1u)) << (j * G);
+    }
+    nEval += __popcll(gm);
+    while (__any(gm != 0)) {
+      int kk[2]; bool has[2], inside[2]; uint32_t c[2]; PRow<PS> n[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        has[u] = gm != 0;
+        kk[u] = has[u] ? __ffsll((long long)gm) - 1 : 0;
+        gm &= gm - 1;
+        const int j = kk[u] / G;
+        const uint32_t csel = j == 0 ? cval[0] : (j == 1 ? cval[1] : (j == 2 ? cval[2] : cval[3]));
+        c[u] = __shfl(csel, grp * G + (kk[u] % G));
+        const int cx = c[u] & 0xFFFF, cy = c[u] >> 16;
+        inside[u] = has[u] && cx >= HALF && cy >= HALF && cx < cols - HALF && cy < rows - HALF;   // in_image_with_border
+#pragma unroll
+        for (int k = 0; k < NW; k++) n[u].w[k] = 0u;
+        if (inside[u] && rowact) n[u] = load_row<PS>(img + (size_t)(cy - HALF + sub) * ip + (cx - HALF));
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        // ZMSSDAtPoint (:352-380): one image row per lane; the pad bytes of both rows are zero
+        unsigned sA = 0, sQ = 0, sX = 0;
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+          sA = udot4(n[u].w[k], 0x01010101u, sA);
+          sQ = udot4(n[u].w[k], n[u].w[k], sQ);
+          sX = udot4(n[u].w[k], trow.w[k], sX);
         }
-        if (ssd < nBestSSD) { nBestSSD = ssd; bestIdx = base + k; }    // first strict minimum in raster order (:223)
+        sA = grp_sum_i<G>(sA); sQ = grp_sum_i<G>(sQ); sX = grp_sum_i<G>(sX);
+        if (has[u]) {
+          int ssd = tp.max_ssd + 1;
+          if (inside[u]) {
+            const int SA = tsum, SB = (int)sA;
+            ssd = ((2 * SA * SB - SA * SA - SB * SB) / NPIX + (int)sQ + tsumsq - 2 * (int)sX);
+          }
+          if (ssd < nBestSSD) { nBestSSD = ssd; bestIdx = base + kk[u]; }   // first strict minimum in raster order (:223)
+        }
       }
     }
   }
