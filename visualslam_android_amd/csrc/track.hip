@@ -286,6 +286,8 @@ __global__ __launch_bounds__(64) void k_searchN(MapDev m, TrackParams tp, Search
   PRow<PS> trow;                                                     // template row `sub`
 #pragma unroll
   for (int k = 0; k < NW; k++) trow.w[k] = 0u;
+  if (rowact) trow = load_row<PS>(gtmpl + sub * PS);                 // the cached row, fetched along with the tracker data; a refresh overwrites it
+  const int tsum_cached = td.tsum, tsumsq_cached = td.tsumsq;
   int tsum, tsumsq;
   if (__any(refresh)) {
     // transform_image (jni/vision/ImageHandler.cpp:21-113): same accumulated stepping of the sample position
@@ -310,6 +312,8 @@ __global__ __launch_bounds__(64) void k_searchN(MapDev m, TrackParams tp, Search
       const float x_bound = (float)(iw - 1), y_bound = (float)(ih - 1);
       if (rowact) {
 #pragma unroll
+      for (int k = 0; k < NW; k++) trow.w[k] = 0u;
+#pragma unroll
       for (int j = 0; j < PS; j++) {
         double x = px, y = py;
         px += across[0]; py += across[1];
@@ -332,10 +336,7 @@ __global__ __launch_bounds__(64) void k_searchN(MapDev m, TrackParams tp, Search
       if (lead) { td.tsum = tsum; td.tsumsq = tsumsq; for (int i = 0; i < 4; i++) td.last_warp[i] = m2[i]; }
     }
   }
-  if (!refresh) {
-    if (rowact) trow = load_row<PS>(gtmpl + sub * PS);
-    tsum = td.tsum; tsumsq = td.tsumsq;
-  }
+  if (!refresh) { tsum = tsum_cached; tsumsq = tsumsq_cached; }
   if (act && (flags & TDF_TMPL_BAD)) {                               // jni/Tracker.cc:637-640
     if (lead) tdflags = flags & ~(TDF_IN_IMAGE | TDF_FOUND);
     act = false;
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(64) void k_searchN(MapDev m, TrackParams tp, Search
   const int rows = a.h[level], cols = a.w[level];
   if (nTop < 0) nTop = 0;
   int nBestSSD = tp.max_ssd + 1;
-  int bestIdx = 0;
+  uint32_t bestCorner = 0;                                           // packed position of the best candidate so far
   unsigned nEval = 0;
   const uint32_t* corners = a.corners[level] + (size_t)s * a.cap[level];
   const uint8_t* img = a.img[level] + (size_t)s * a.img_sstride[level];
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(64) void k_searchN(MapDev m, TrackParams tp, Search
             const int SA = tsum, SB = (int)sA;
             ssd = ((2 * SA * SB - SA * SA - SB * SB) / NPIX + (int)sQ + tsumsq - 2 * (int)sX);
           }
-          if (ssd < nBestSSD) { nBestSSD = ssd; bestIdx = base + kk[u]; }   // first strict minimum in raster order (:223)
+          if (ssd < nBestSSD) { nBestSSD = ssd; bestCorner = c[u]; }   // first strict minimum in raster order (:223)
         }
       }
     }
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(64) void k_searchN(MapDev m, TrackParams tp, Search
   }
   bool found = act && nBestSSD < tp.max_ssd;
   if (act && !found && lead) tdflags = flags & ~TDF_FOUND;          // :646-649
-  const uint32_t bc = found ? corners[bestIdx] : 0u;
+  const uint32_t bc = found ? bestCorner : 0u;
   const double coarse[2] = {level_zero_pos((double)(bc & 0xFFFF), level), level_zero_pos((double)(bc >> 16), level)};
   if (found) flags |= TDF_FOUND;
   const bool dosub = found && nSubPixIts > 0;                        // refined by k_subpixN, which also counts it as found
