@@ -457,15 +457,10 @@ __global__ __launch_bounds__(64) void k_searchN(MapDev m, TrackParams tp, Search
 // that its registers (gradients, 3x3 inverse) do not halve the occupancy of the search proper.  Eight patches per
 // wavefront, lane y owns interior row y of the template.
 template <int PS, int G>
-__global__ __launch_bounds__(64) void k_subpixN(MapDev m, TrackParams tp, SearchArgs a, int stage) {
+DEVFN void subpix_block(const MapDev& m, const TrackParams& tp, const SearchArgs& a, TrackerState* st, int s, int nsub, int blk) {
   constexpr int HALF = PS / 2, PPW = 64 / G, NW = (PS + 3) / 4, Q = PS - 2;
-  const int s = blockIdx.y;
-  TrackerState* st = &m.st[s];
-  if (!(st->map_good && st->lost_frames < 3)) return;
-  const int nsub = stage == 0 ? st->n_search : st->n_l3;             // entries that carry a sub-pixel budget
-  if ((int)blockIdx.x * PPW >= nsub) return;
   const int lane = threadIdx.x, grp = lane / G, sub = lane % G;
-  const int e = blockIdx.x * PPW + grp;
+  const int e = blk * PPW + grp;
   const bool lead = sub == 0;
   const int2 ent = e < nsub ? m.search_list[(size_t)s * tp.max_points + e] : make_int2(0, 0);
   const int idx = ent.x, nSubPixIts = ent.y;
@@ -546,6 +541,16 @@ __global__ __launch_bounds__(64) void k_subpixN(MapDev m, TrackParams tp, Search
     const int c = __popcll(__ballot(dosub && converged && lead && level == l));
     if (lane == 0 && c) atomicAdd(&st->found[l], c);
   }
+}
+
+#define SUBPIX_GRID 16     // the entries with a sub-pixel budget are few (level-3 points / the coarse set): a short grid that strides
+template <int PS, int G>
+__global__ __launch_bounds__(64) void k_subpixN(MapDev m, TrackParams tp, SearchArgs a, int stage) {
+  const int s = blockIdx.y;
+  TrackerState* st = &m.st[s];
+  if (!(st->map_good && st->lost_frames < 3)) return;
+  const int nsub = stage == 0 ? st->n_search : st->n_l3;             // entries that carry a sub-pixel budget
+  for (int blk = blockIdx.x; blk * (64 / G) < nsub; blk += gridDim.x) subpix_block<PS, G>(m, tp, a, st, s, nsub, blk);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -963,10 +968,10 @@ int trk_track_map(vslam_system* sys) {
     const int nc = 2 * tp.coarse_max;
     if (tp.P == 8) {
       hipLaunchKernelGGL((k_searchN<8, 8>), dim3((nc + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 0);
-      if (tp.coarse_subpix_its > 0) hipLaunchKernelGGL((k_subpixN<8, 8>), dim3((nc + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 0);
+      if (tp.coarse_subpix_its > 0) hipLaunchKernelGGL((k_subpixN<8, 8>), dim3(SUBPIX_GRID, S), dim3(64), 0, sys->stream, m, tp, a, 0);
     } else {
       hipLaunchKernelGGL((k_searchN<11, 16>), dim3((nc + 3) / 4, S), dim3(64), 0, sys->stream, m, tp, a, 0);
-      if (tp.coarse_subpix_its > 0) hipLaunchKernelGGL((k_subpixN<11, 16>), dim3((nc + 3) / 4, S), dim3(64), 0, sys->stream, m, tp, a, 0);
+      if (tp.coarse_subpix_its > 0) hipLaunchKernelGGL((k_subpixN<11, 16>), dim3(SUBPIX_GRID, S), dim3(64), 0, sys->stream, m, tp, a, 0);
     }
     prof_mark(sys, 6);
     hipLaunchKernelGGL(k_pose, dim3(S), dim3(POSE_THREADS), 0, sys->stream, m, tp, 0);
@@ -976,10 +981,10 @@ int trk_track_map(vslam_system* sys) {
   prof_mark(sys, 8);
   if (tp.P == 8) {
     hipLaunchKernelGGL((k_searchN<8, 8>), dim3((maxSearch + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 1);
-    if (tp.fine_subpix_its > 0) hipLaunchKernelGGL((k_subpixN<8, 8>), dim3((maxSearch + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 1);
+    if (tp.fine_subpix_its > 0) hipLaunchKernelGGL((k_subpixN<8, 8>), dim3(SUBPIX_GRID, S), dim3(64), 0, sys->stream, m, tp, a, 1);
   } else {
     hipLaunchKernelGGL((k_searchN<11, 16>), dim3((maxSearch + 3) / 4, S), dim3(64), 0, sys->stream, m, tp, a, 1);
-    if (tp.fine_subpix_its > 0) hipLaunchKernelGGL((k_subpixN<11, 16>), dim3((maxSearch + 3) / 4, S), dim3(64), 0, sys->stream, m, tp, a, 1);
+    if (tp.fine_subpix_its > 0) hipLaunchKernelGGL((k_subpixN<11, 16>), dim3(SUBPIX_GRID, S), dim3(64), 0, sys->stream, m, tp, a, 1);
   }
   prof_mark(sys, 9);
   hipLaunchKernelGGL(k_pose, dim3(S), dim3(POSE_THREADS), 0, sys->stream, m, tp, 1);
