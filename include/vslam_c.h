@@ -76,6 +76,9 @@ typedef struct vslam_params {
                                       map-maker); D > 0: it runs on its own HIP stream beside the next frames and its results
                                       are applied at the start of the D-th following frame (the reference's map-maker is a
                                       second thread whose results also arrive "a few frames later", jni/MapMaker.cc:80-123) */
+  int grow_map;                    /* 1: every new keyframe also runs MakeKeyFrame_Rest's candidates, ThinCandidates and
+                                      AddSomeMapPoints (epipolar search + triangulation, jni/MapMaker.cc:498-501, 525-703), so the
+                                      map gains points; 0 (default): the map only gains keyframes and measurements */
 } vslam_params;
 
 const char* vslam_last_error(void);

@@ -23,6 +23,7 @@ void* orc_sys_create(const orc_params* q) {
   p.quirks = q->quirks;
   p.ba_delay_frames = q->ba_delay_frames;
   p.use_sbi = q->use_sbi;
+  p.grow_map = q->grow_map;
   return new System(p);
 }
 void orc_sys_destroy(void* s) { delete (System*)s; }

@@ -93,6 +93,13 @@ def thin_candidates(pos, score, level, meas_root, meas_level):
     return op[:n].copy(), os_[:n].copy()
 
 
+def reproject_point(AfromB12, v2A, v2B):
+    """MapMaker::ReprojectPoint: 3-D point in frame B from its z = 1 plane projections in frames A and B."""
+    T = (C.c_double * 12)(*AfromB12); a = (C.c_double * 2)(*v2A); b = (C.c_double * 2)(*v2B); out = (C.c_double * 3)()
+    lib().orc_reproject_point(T, a, b, out)
+    return np.array(out[:])
+
+
 def sbi_make(level3, blur=0.75):
     """SmallBlurryImage::MakeFromKF on a level-3 image -> (small u8 image, zero-mean blurred fp32 template)."""
     l3 = np.ascontiguousarray(level3, np.uint8)
@@ -158,7 +165,7 @@ class OrcParams(C.Structure):
                 ("min_frames_between_kf", C.c_int), ("max_kf_dist_wiggle_mult", C.c_double), ("wiggle_scale", C.c_double),
                 ("ba_max_iterations", C.c_int), ("ba_convergence_limit", C.c_double), ("ba_min_tukey_sigma", C.c_double),
                 ("ba_window", C.c_int), ("ba_min_keyframes", C.c_int), ("cam", C.c_double * 5), ("quirks", C.c_int),
-                ("ba_delay_frames", C.c_int), ("use_sbi", C.c_int)]
+                ("ba_delay_frames", C.c_int), ("use_sbi", C.c_int), ("grow_map", C.c_int)]
 
 
 class TrackState(C.Structure):
@@ -180,7 +187,7 @@ def params_from_vslam(vp):
     for f in ("coarse_min", "coarse_max", "coarse_range", "coarse_subpix_its", "coarse_disabled", "coarse_min_vel",
               "fine_subpix_its", "wls_prior", "min_frames_between_kf", "max_kf_dist_wiggle_mult", "wiggle_scale",
               "ba_max_iterations", "ba_convergence_limit", "ba_min_tukey_sigma", "ba_window", "ba_min_keyframes", "quirks",
-              "ba_delay_frames", "use_sbi"):
+              "ba_delay_frames", "use_sbi", "grow_map"):
         setattr(p, f, getattr(vp, f))
     for i in range(5):
         p.cam[i] = vp.cam[i]

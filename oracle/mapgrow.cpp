@@ -1,0 +1,233 @@
+// ORACLE (test infrastructure only).  Map growth on a new keyframe (first part):
+//   KeyFrame::MakeKeyFrame_Rest candidates        jni/KeyFrame.cc:53-95   (oracle/frontend.cpp orc_candidates)
+//   MapMaker::ThinCandidates                      jni/MapMaker.cc:393-422
+//   MapMaker::AddSomeMapPoints / AddPointEpipolar jni/MapMaker.cc:424-437, 525-703
+//   MapMaker::ReprojectPoint                      jni/MapMaker.cc:174-200
+//   MapPoint::RefreshPixelVectors                 jni/MapPoint.cc:4-29
+//   PatchFinder::MakeTemplateCoarseNoWarp         jni/PatchFinder.cc:130-142
+// Not built (documented in DESIGN.md): ReFindInSingleKeyFrame / ReFindNewlyMade / ReFindFromFailureQueue -- a new point
+// starts with its two stereo measurements and gains more when the tracker measures it in later keyframes.
+// Third-party arithmetic restated (parity unpinned): Eigen::JacobiSVD of the 4x4 triangulation matrix -> smallest
+// eigenvector of A^T A by cyclic Jacobi rotations (the sign of the vector cancels in the projective division).
+#include "ptam_system.hpp"
+
+namespace orc {
+
+// smallest-eigenvalue eigenvector of the symmetric 4x4 matrix S (cyclic Jacobi, fixed number of sweeps)
+void smallest_eigvec4(const double Sin[16], double out[4]) {
+  double S[16], V[16];
+  for (int i = 0; i < 16; i++) { S[i] = Sin[i]; V[i] = (i % 5 == 0) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 16; sweep++)
+    for (int p = 0; p < 3; p++)
+      for (int q = p + 1; q < 4; q++) {
+        const double apq = S[p * 4 + q];
+        if (apq == 0.0) continue;
+        const double theta = (S[q * 4 + q] - S[p * 4 + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 4; k++) {                         // S <- S J
+          const double skp = S[k * 4 + p], skq = S[k * 4 + q];
+          S[k * 4 + p] = c * skp - s * skq; S[k * 4 + q] = s * skp + c * skq;
+        }
+        for (int k = 0; k < 4; k++) {                         // S <- J^T S
+          const double spk = S[p * 4 + k], sqk = S[q * 4 + k];
+          S[p * 4 + k] = c * spk - s * sqk; S[q * 4 + k] = s * spk + c * sqk;
+        }
+        for (int k = 0; k < 4; k++) {                         // V <- V J
+          const double vkp = V[k * 4 + p], vkq = V[k * 4 + q];
+          V[k * 4 + p] = c * vkp - s * vkq; V[k * 4 + q] = s * vkp + c * vkq;
+        }
+      }
+  int best = 0;
+  for (int i = 1; i < 4; i++) if (S[i * 4 + i] < S[best * 4 + best]) best = i;
+  for (int k = 0; k < 4; k++) out[k] = V[k * 4 + best];
+}
+
+// MapMaker::ReprojectPoint, jni/MapMaker.cc:174-200
+V3 reproject_point(const SE3& AfromB, const double v2A[2], const double v2B[2]) {
+  double PD[12];                                                // 3x4 [R | t]
+  for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) PD[r * 4 + c] = AfromB.R[r * 3 + c]; PD[r * 4 + 3] = AfromB.t[r]; }
+  double A[16] = {-1.0, 0.0, v2B[0], 0.0, 0.0, -1.0, v2B[1], 0.0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int c = 0; c < 4; c++) { A[8 + c] = v2A[0] * PD[8 + c] - PD[0 + c]; A[12 + c] = v2A[1] * PD[8 + c] - PD[4 + c]; }
+  double S[16];
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { double s = 0; for (int k = 0; k < 4; k++) s += A[k * 4 + i] * A[k * 4 + j]; S[i * 4 + j] = s; }
+  double v[4];
+  smallest_eigvec4(S, v);
+  if (v[3] == 0.0) v[3] = 0.00001;
+  return v3(v[0] / v[3], v[1] / v[3], v[2] / v[3]);
+}
+
+// ATANCamera::OnePixelDist, jni/ATANCamera.cc:86-91
+static double one_pixel_dist(const Camera& cam) {
+  double a[2], b[2];
+  cam.unproject(cam.size[0] / 2, cam.size[1] / 2, a);
+  cam.unproject(cam.size[0] / 2 + 1, cam.size[1] / 2 + 1, b);
+  const double d0 = a[0] - b[0], d1 = a[1] - b[1];
+  return sqrt(d0 * d0 + d1 * d1) / sqrt(2.0);
+}
+
+void make_keyframe_rest_candidates(KeyFrame& k, double min_score) {
+  // jni/KeyFrame.cc:66-95 on the maximal corners make_keyframe_rest_nonmax left
+  for (int l = 0; l < 4; l++) {
+    const int n = (int)k.maxcorners[l].size();
+    k.cand[l].assign(n > 0 ? n : 1, 0); k.cand_score[l].assign(n > 0 ? n : 1, 0.0);
+    const int m = orc_candidates(k.im[l].data(), k.w[l], k.h[l], k.w[l], k.maxcorners[l].data(), n, min_score, 10, k.cand[l].data(), k.cand_score[l].data(), n > 0 ? n : 1);
+    k.cand[l].resize(m); k.cand_score[l].resize(m);
+  }
+}
+
+void System::ThinCandidates(KeyFrame& k, int level) {
+  // :393-422
+  std::vector<double> root; std::vector<int> lev;
+  for (auto& it : k.meas) { root.push_back(it.second.root[0]); root.push_back(it.second.root[1]); lev.push_back(it.second.level); }
+  const int n = (int)k.cand[level].size();
+  std::vector<uint32_t> op(n > 0 ? n : 1); std::vector<double> os(n > 0 ? n : 1);
+  const int m = orc_thin_candidates(k.cand[level].data(), k.cand_score[level].data(), n, level, root.data(), lev.data(), (int)lev.size(), op.data(), os.data());
+  op.resize(m); os.resize(m);
+  k.cand[level] = op; k.cand_score[level] = os;
+}
+
+int System::ClosestKeyFrame(int kidx) {
+  // :737-758
+  double best = 9999999999.9; int n = -1;
+  for (int i = 0; i < (int)kfs.size(); i++) {
+    if (i == kidx) continue;
+    const double d = KeyFrameLinearDist(kfs[kidx]->pose, kfs[i]->pose);
+    if (d < best) { best = d; n = i; }
+  }
+  return n;
+}
+
+// MapPoint::RefreshPixelVectors, jni/MapPoint.cc:4-29, with v3Normal_NC = (0, 0, -1)
+static void refresh_pixel_vectors(MapPoint& p, const KeyFrame& k, const V3& center, const V3& one_right, const V3& one_down) {
+  const V3 pc = xform(k.pose, p.pos);
+  const double dCamHeight = fabs(-pc[2]);
+  const double dPixelRate = fabs(-center[2]), dOneRightRate = fabs(-one_right[2]), dOneDownRate = fabs(-one_down[2]);
+  V3 cop, rop, dop;
+  for (int i = 0; i < 3; i++) { cop[i] = center[i] * dCamHeight / dPixelRate; rop[i] = one_right[i] * dCamHeight / dOneRightRate; dop[i] = one_down[i] * dCamHeight / dOneDownRate; }
+  p.pix_right = rot_inv(k.pose, v3(rop[0] - cop[0], rop[1] - cop[1], rop[2] - cop[2]));
+  p.pix_down = rot_inv(k.pose, v3(dop[0] - cop[0], dop[1] - cop[1], dop[2] - cop[2]));
+}
+
+static V3 unit_ray(const Camera& cam, double ix, double iy) {
+  double u[2];
+  cam.unproject(ix, iy, u);
+  const double n = sqrt(u[0] * u[0] + u[1] * u[1] + 1.0);
+  return v3(u[0] / n, u[1] / n, 1.0 / n);                      // myUnproject + normalize()
+}
+
+bool System::AddPointEpipolar(int ksrc, int ktgt, int nLevel, int nCandidate) {
+  // :525-703
+  KeyFrame& kSrc = *kfs[ksrc]; KeyFrame& kTarget = *kfs[ktgt];
+  const int nLevelScale = level_scale(nLevel);
+  const uint32_t cpos = kSrc.cand[nLevel][nCandidate];
+  const double irLevelPos[2] = {(double)(cpos & 0xFFFF), (double)(cpos >> 16)};
+  const double v2RootPos[2] = {level_zero_pos(irLevelPos[0], nLevel), level_zero_pos(irLevelPos[1], nLevel)};
+  const V3 v3Ray_SC = unit_ray(camera, v2RootPos[0], v2RootPos[1]);
+  const V3 v3LineDirn_TC = rot(kTarget.pose, rot_inv(kSrc.pose, v3Ray_SC));
+  const double dMean = kSrc.depth_mean, dSigma = kSrc.depth_sigma;
+  const double dStartDepth = std::max(p.wiggle_scale, dMean - dSigma);
+  const double dEndDepth = std::min(40 * p.wiggle_scale, dMean + dSigma);
+  const SE3 srcInv = inverse(kSrc.pose);
+  const V3 v3CamCenter_TC = xform(kTarget.pose, v3(srcInv.t[0], srcInv.t[1], srcInv.t[2]));
+  V3 v3RayStart_TC, v3RayEnd_TC;
+  for (int i = 0; i < 3; i++) { v3RayStart_TC[i] = v3CamCenter_TC[i] + dStartDepth * v3LineDirn_TC[i]; v3RayEnd_TC[i] = v3CamCenter_TC[i] + dEndDepth * v3LineDirn_TC[i]; }
+  if (v3RayEnd_TC[2] <= v3RayStart_TC[2]) return false;
+  if (v3RayEnd_TC[2] <= 0.0) return false;
+  if (v3RayStart_TC[2] <= 0.0) {
+    const double f = 0.001 - v3RayStart_TC[2] / v3LineDirn_TC[2];
+    for (int i = 0; i < 3; i++) v3RayStart_TC[i] += v3LineDirn_TC[i] * f;
+  }
+  const double v2A[2] = {v3RayStart_TC[0] / v3RayStart_TC[2], v3RayStart_TC[1] / v3RayStart_TC[2]};
+  const double v2B[2] = {v3RayEnd_TC[0] / v3RayEnd_TC[2], v3RayEnd_TC[1] / v3RayEnd_TC[2]};
+  double along[2] = {v2A[0] - v2B[0], v2A[1] - v2B[1]};
+  if (along[0] * along[0] + along[1] * along[1] < 0.00000001) return false;
+  { const double n = sqrt(along[0] * along[0] + along[1] * along[1]); along[0] /= n; along[1] /= n; }
+  const double normal[2] = {along[1], -along[0]};
+  const double dNormDist = v2A[0] * normal[0] + v2A[1] * normal[1];
+  if (fabs(dNormDist) > camera.largest_radius) return false;
+  double dMinLen = std::min(along[0] * v2A[0] + along[1] * v2A[1], along[0] * v2B[0] + along[1] * v2B[1]) - 0.05;
+  double dMaxLen = std::max(along[0] * v2A[0] + along[1] * v2A[1], along[0] * v2B[0] + along[1] * v2B[1]) + 0.05;
+  if (dMinLen < -2.0) dMinLen = -2.0;
+  if (dMaxLen < -2.0) dMaxLen = -2.0;
+  if (dMinLen > 2.0) dMinLen = 2.0;
+  if (dMaxLen > 2.0) dMaxLen = 2.0;
+
+  Finder f;
+  f.P = p.patch_size; f.max_ssd = 500 * p.patch_size * p.patch_size;   // jni/PatchFinder.cc:19-20
+  f.level = nLevel;                                                    // MakeTemplateCoarseNoWarp :130-142
+  const int a = (int)irLevelPos[0], b = (int)irLevelPos[1], bord = f.P / 2 + 1;
+  if (!(a >= bord && b >= bord && a < kSrc.w[nLevel] - bord && b < kSrc.h[nLevel] - bord)) return false;   // TemplateBad
+  f.tmpl.resize((size_t)f.P * f.P);
+  for (int y = 0; y < f.P; y++) for (int x = 0; x < f.P; x++) f.tmpl[(size_t)y * f.P + x] = kSrc.im[nLevel][(size_t)(b - f.P / 2 + y) * kSrc.w[nLevel] + (a - f.P / 2 + x)];
+  f.tsum = 0; f.tsumsq = 0;
+  for (size_t i = 0; i < f.tmpl.size(); i++) { f.tsum += f.tmpl[i]; f.tsumsq += f.tmpl[i] * f.tmpl[i]; }   // MakeTemplateSums :152-164
+
+  const std::vector<uint32_t>& vIR = kTarget.corners[nLevel];
+  int nBest = -1, nBestZMSSD = f.max_ssd + 1;
+  const double dMaxDistDiff = one_pixel_dist(camera) * (4.0 + 1.0 * nLevelScale);
+  const double dMaxDistSq = dMaxDistDiff * dMaxDistDiff;
+  for (size_t i = 0; i < vIR.size(); i++) {
+    const int cx = vIR[i] & 0xFFFF, cy = vIR[i] >> 16;
+    // vImplaneCorners (:612-620): UnProject of the level-zero position TRUNCATED to integer pixels (it indexes a cache image)
+    double v2Im[2];
+    camera.unproject((double)(int)level_zero_pos((double)cx, nLevel), (double)(int)level_zero_pos((double)cy, nLevel), v2Im);
+    const double dDistDiff = dNormDist - (v2Im[0] * normal[0] + v2Im[1] * normal[1]);
+    if (dDistDiff * dDistDiff > dMaxDistSq) continue;
+    const double len = v2Im[0] * along[0] + v2Im[1] * along[1];
+    if (len < dMinLen) continue;
+    if (len > dMaxLen) continue;
+    const int nZMSSD = finder_zmssd(f, kTarget.im[nLevel].data(), kTarget.w[nLevel], kTarget.h[nLevel], kTarget.w[nLevel], cx, cy);
+    if (nZMSSD < nBestZMSSD) { nBest = (int)i; nBestZMSSD = nZMSSD; }
+  }
+  if (nBest == -1) return false;
+
+  f.coarse[0] = 0; f.coarse[1] = 0;
+  finder_make_subpix(f);
+  f.subpix[0] = level_zero_pos((double)(vIR[nBest] & 0xFFFF), nLevel);   // SetSubPixPos :661
+  f.subpix[1] = level_zero_pos((double)(vIR[nBest] >> 16), nLevel);
+  if (!finder_iterate_subpix_to_convergence(f, kTarget, 10)) return false;
+
+  double uA[2], uB[2];
+  camera.unproject(v2RootPos[0], v2RootPos[1], uA);
+  camera.unproject(f.subpix[0], f.subpix[1], uB);
+  const V3 pB = reproject_point(mul(kSrc.pose, inverse(kTarget.pose)), uA, uB);
+  const V3 v3New = xform(inverse(kTarget.pose), pB);
+
+  MapPoint* pNew = new MapPoint();
+  pNew->pos = v3New;
+  pNew->src_kf = ksrc; pNew->src_level = nLevel; pNew->irx = a; pNew->iry = b;
+  pNew->finder.P = p.patch_size; pNew->finder.max_ssd = f.max_ssd;
+  refresh_pixel_vectors(*pNew, kSrc, unit_ray(camera, v2RootPos[0], v2RootPos[1]), unit_ray(camera, v2RootPos[0] + nLevelScale, v2RootPos[1]),
+                        unit_ray(camera, v2RootPos[0], v2RootPos[1] + nLevelScale));
+  pts.push_back(pNew);
+  const int pid = (int)pts.size() - 1;
+  Measurement m;
+  m.source = SRC_ROOT; m.root[0] = v2RootPos[0]; m.root[1] = v2RootPos[1]; m.level = nLevel; m.subpix = true;
+  kSrc.meas[pid] = m;
+  m.source = SRC_EPIPOLAR; m.root[0] = f.subpix[0]; m.root[1] = f.subpix[1];
+  kTarget.meas[pid] = m;
+  pNew->meas_kfs.insert(ksrc); pNew->meas_kfs.insert(ktgt);
+  return true;
+}
+
+int System::AddSomeMapPoints(int nLevel) {
+  // :424-437
+  const int ksrc = (int)kfs.size() - 1;
+  const int ktgt = ClosestKeyFrame(ksrc);
+  if (ktgt < 0) return 0;
+  ThinCandidates(*kfs[ksrc], nLevel);
+  int n = 0;
+  for (int i = 0; i < (int)kfs[ksrc]->cand[nLevel].size(); i++) if (AddPointEpipolar(ksrc, ktgt, nLevel, i)) n++;
+  return n;
+}
+
+}  // namespace orc
+
+extern "C" void orc_reproject_point(const double AfromB12[12], const double v2A[2], const double v2B[2], double out3[3]) {
+  orc::SE3 T;
+  for (int i = 0; i < 9; i++) T.R[i] = AfromB12[i];
+  for (int i = 0; i < 3; i++) T.t[i] = AfromB12[9 + i];
+  const orc::V3 r = orc::reproject_point(T, v2A, v2B);
+  for (int i = 0; i < 3; i++) out3[i] = r[i];
+}

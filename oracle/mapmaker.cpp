@@ -31,7 +31,11 @@ void System::AddKeyFrame() {
   kfs.push_back(pK);
   const int kidx = (int)kfs.size() - 1;
   for (auto& it : pK->meas) { pts[it.first]->meas_kfs.insert(kidx); it.second.source = SRC_TRACKER; }   // :491-494
-  // ReFindInSingleKeyFrame / AddSomeMapPoints: "next" rows
+  // ReFindInSingleKeyFrame (:497): not built.  AddSomeMapPoints (:498-501) when the map is allowed to grow:
+  if (p.grow_map) {
+    make_keyframe_rest_candidates(*pK, 70.0);                                                              // rest of MakeKeyFrame_Rest, :488
+    n_points_added = AddSomeMapPoints(3) + AddSomeMapPoints(0) + AddSomeMapPoints(1) + AddSomeMapPoints(2);
+  }
   ba_converged_full = false; ba_converged_recent = false;                                                   // :504-505
   // MapMaker::run :98-99: local bundle adjustment takes priority once the queue is empty
   defer_ba = true;

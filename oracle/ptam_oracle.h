@@ -94,6 +94,7 @@ typedef struct orc_params {           /* mirrors the hot-path fields of vslam_pa
   double cam[5]; int quirks;
   int ba_delay_frames;
   int use_sbi;                        /* gvnUseSBI, jni/Tracker.cc:88 */
+  int grow_map;                       /* AddSomeMapPoints on every new keyframe, jni/MapMaker.cc:498-501 */
 } orc_params;
 
 typedef struct orc_track_state {      /* same fields as vslam_track_state */
@@ -131,6 +132,9 @@ int orc_sbi_make(const uint8_t* level3, int w3, int h3, double blur, uint8_t* sm
 /* CalcSBIRotation between the level-3 images of this and the last frame: ln(SE3fromSE2(IteratePosRelToTarget(6))) */
 void orc_sbi_rotation(const uint8_t* cur_l3, const uint8_t* last_l3, int w3, int h3, double blur, const double cam5[5],
                       int quirks, double out6[6], double* score);
+
+/* MapMaker::ReprojectPoint (jni/MapMaker.cc:174-200): point in frame B from its z = 1 projections in A and B; AfromB 12 doubles */
+void orc_reproject_point(const double AfromB12[12], const double v2A[2], const double v2B[2], double out3[3]);
 
 /* ---- stand-alone Bundle (jni/Bundle.h:111-121) --------------------------------------------------- */
 void* orc_ba_create(const double cam5[5], int width, int height, int quirks, int max_iterations, double convergence_limit, double min_sigma);

@@ -25,6 +25,7 @@ struct KeyFrame {     // jni/KeyFrame.h:73-97 (+ Level :55-69)
   std::vector<uint32_t> corners[4];
   std::vector<int> lut[4];
   std::vector<uint32_t> maxcorners[4];
+  std::vector<uint32_t> cand[4]; std::vector<double> cand_score[4];   // Level::vCandidates (irLevelPos packed, dSTScore)
   std::map<int, Measurement> meas;   // keyed by map-point index (reference: by MapPoint*, address order)
   double depth_mean = 0, depth_sigma = 0;
 };
@@ -73,6 +74,7 @@ struct Params {
   double cam[5]; int quirks;
   int ba_delay_frames = 0;   // 0: results applied at once; D > 0: applied at the start of the D-th following frame
   int use_sbi = 0;           // gvnUseSBI, jni/Tracker.cc:88 (reference: 1)
+  int grow_map = 0;          // AddKeyFrameFromTopOfQueue's AddSomeMapPoints (jni/MapMaker.cc:498-501); 0: the map only gains measurements
 };
 
 // SmallBlurryImage (jni/SmallBlurryImage.h): mimSmall, mimTemplate (zero-mean, blurred), mimImageJacs (x, y interleaved)
@@ -144,6 +146,10 @@ struct System {
   bool NeedNewKeyFrame();
   double KeyFrameLinearDist(const SE3& a, const SE3& b);
   int BundleAdjustRecent(); int BundleAdjustAll(); void HandleBadPoints();
+  // map growth (mapgrow.cpp)
+  void ThinCandidates(KeyFrame& k, int level); int ClosestKeyFrame(int kidx);
+  bool AddPointEpipolar(int ksrc, int ktgt, int level, int candidate); int AddSomeMapPoints(int level);
+  int n_points_added = 0;
   int BundleAdjust(const std::vector<int>& adj, const std::vector<int>& fixed, const std::vector<int>& points, bool recent);
   // a finished Bundle whose results are still to be written to the map (asynchronous map-maker model, see mapmaker.cpp)
   struct PendingBA { Bundle b; std::vector<int> id_view, id_point; bool recent = true; int accepted = 0; int countdown = -1; };
@@ -155,6 +161,9 @@ struct System {
 
 void make_keyframe_lite(KeyFrame& k, const uint8_t* gray, int w, int h, int stride, const int thr[4]);
 void make_keyframe_rest_nonmax(KeyFrame& k, int barrier, bool quirk);
+void make_keyframe_rest_candidates(KeyFrame& k, double min_score);
+V3 reproject_point(const SE3& AfromB, const double v2A[2], const double v2B[2]);
+void smallest_eigvec4(const double S[16], double out[4]);
 
 // PatchFinder pieces exposed for unit tests
 int transform_image(const uint8_t* in, int iw, int ih, int istride, uint8_t* out, int P, const double M[4],

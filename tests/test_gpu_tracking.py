@@ -280,3 +280,37 @@ def test_small_blurry_image_rotation_prior():
         changed |= pose_err(o.state().pose, o_plain.state().pose) > 0
     assert changed
     g.close()
+
+
+@pytest.mark.parametrize("patch", [8, 11])
+def test_map_growth_matches_oracle(patch):
+    """grow_map = 1: every new keyframe runs MakeKeyFrame_Rest's candidates, ThinCandidates and AddSomeMapPoints
+    (epipolar search + triangulation, jni/MapMaker.cc:393-437, 525-703).  The number of points added, their positions,
+    patch vectors and stereo measurements, and the tracking that then uses them, against the oracle configured alike."""
+    w, h = 320, 240
+    f, m, frames = make_scene(w, h, seed=77, n_frames=46, per_level=(120, 50, 20, 8))
+    n0 = len(m["points"])
+    vp = capi.default_params(w, h, 2, patch_size=patch, grow_map=1)
+    g = capi.System(vp)
+    for s in range(2):
+        g.load_map(s, m); g.set_pose(s, f.pose(-1))
+    o = make_oracle(capi.default_params(w, h, 1, patch_size=patch, grow_map=1), m, f.pose(-1))
+    drift = Drift()
+    grew = 0
+    for t in range(46):
+        g.track_frame(np.stack([frames[t]] * 2)); o.track_frame(frames[t])
+        so, sg = o.state(), g.state(1)
+        assert so.n_points == sg.n_points == g.state(0).n_points, (t, so.n_points, sg.n_points)
+        if so.kf_added:
+            grew += 1
+            po, pg = o.points(), g.points(1)
+            n1 = so.n_points
+            assert n1 > n0 or grew > 1
+            assert np.abs(po["pos"][n0:n1] - pg["pos"][n0:n1]).max() < 1e-6, t      # triangulated through a 4x4 Jacobi eigen-solve
+            k_new = so.n_keyframes - 1
+            mo, mg = o.keyframe_meas(k_new), g.keyframe_meas(1, k_new)
+            assert np.array_equal(mo["pt"], mg["pt"]) and np.array_equal(mo["source"], mg["source"]) and np.array_equal(mo["level"], mg["level"]), t
+            assert np.abs(mo["root"] - mg["root"]).max() < 1e-7, t
+        compare_frame(o, g, 1, "grow frame %d" % t, drift, tight=1e-6)
+    assert grew >= 3 and o.state().n_points > n0 + 30
+    g.close()

@@ -35,3 +35,40 @@ def test_quirk_cam_int_radius_disables_tracking():
     o.track_frame(frames[0])
     st = o.state()
     assert sum(st.attempted) == 0 and st.quality == 0
+
+
+def test_reproject_point_recovers_a_known_point():
+    """MapMaker::ReprojectPoint (jni/MapMaker.cc:174-200) on exact projections; the 4x4 SVD is restated as a Jacobi eigen-solve."""
+    from oracle import binding as orc
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        w = rng.normal(0, 0.2, 3)
+        T = orc.se3_exp(np.concatenate([rng.normal(0, 0.3, 3), w]))          # A from B
+        R, t = np.array(T[:9]).reshape(3, 3), np.array(T[9:])
+        XB = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(1.0, 3.0)])
+        XA = R @ XB + t
+        got = orc.reproject_point(T, XA[:2] / XA[2], XB[:2] / XB[2])
+        assert np.abs(got - XB).max() < 1e-9
+
+
+def test_map_growth_adds_points_on_the_scene_plane():
+    """grow_map = 1 (AddSomeMapPoints, jni/MapMaker.cc:424-437, 525-703): new points come from candidates away from the
+    existing measurements, triangulate close to the feeder's z = 0 plane, and are tracked afterwards."""
+    w, h = 320, 240
+    f, m, frames = make_scene(w, h, seed=77, n_frames=46, per_level=(120, 50, 20, 8))
+    n0 = len(m["points"])
+    o = make_oracle(capi.default_params(w, h, 1, grow_map=1), m, f.pose(-1))
+    worst = 0.0
+    for i in range(46):
+        o.track_frame(frames[i])
+        st = o.state()
+        assert st.quality == 2
+        worst = max(worst, pose_err(st.pose, f.pose(i)))
+    assert worst < 6e-3
+    P = o.points()
+    new = P["pos"][n0:]
+    assert len(new) > 30
+    assert np.median(np.abs(new[:, 2])) < 0.05                 # scene depth is about 1: a few per cent from a short baseline
+    assert P["n_in"][n0:].sum() > 3 * len(new) > P["n_out"][n0:].sum()   # the tracker uses them as inliers
+    kf_new = o.keyframe_meas(o.state().n_keyframes - 1)
+    assert (kf_new["source"] == 2).sum() > 0                   # SRC_ROOT measurements of the points this keyframe created

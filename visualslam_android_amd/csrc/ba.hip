@@ -550,6 +550,8 @@ int ba_run(vslam_system* sys, int mode) {
     KfCopyArgs a; fill_kfcopy(sys, a);
     prof_mark(sys, 10);
     hipLaunchKernelGGL(k_add_keyframe, dim3(32, sys->S), dim3(256), 0, sys->stream, sys->map, sys->tp, a);
+    int rg = grow_on_keyframe(sys);                      // AddSomeMapPoints (vslam_params.grow_map), before the bundle adjustment sees the keyframe
+    if (rg) return rg;
   }
   if (mode == 0) prof_mark(sys, 11);
   hipLaunchKernelGGL(k_ba_assemble, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, mode);

@@ -184,6 +184,15 @@ HDFN void cam_derivs(const CamModel& c, const CamProj& p, double d[4]) {   // jn
   d[3] = c.focal[1] * (fy * y + p.factor);
 }
 
+// ATANCamera::UnProject, jni/ATANCamera.cc:149-164
+HDFN void cam_unproject(const CamModel& c, double ix, double iy, double out[2]) {
+  const double dx = (ix - c.center[0]) * (1.0 / c.focal[0]), dy = (iy - c.center[1]) * (1.0 / c.focal[1]);
+  const double dist_r = sqrt(dx * dx + dy * dy);
+  const double r = c.w == 0.0 ? dist_r : tan(dist_r * c.w) * (1.0 / c.two_tan);
+  const double f = dist_r > 0.01 ? r / dist_r : 1.0;
+  out[0] = dx * f; out[1] = dy * f;
+}
+
 // ---- Tukey (jni/MEstimator.h:42-77) --------------------------------------------------------------------------
 HDFN double tukey_sqrt_weight(double e2, double s2) { return e2 > s2 ? 0.0 : 1.0 - (e2 / s2); }
 HDFN double tukey_weight(double e2, double s2) { const double d = tukey_sqrt_weight(e2, s2); return d * d; }

@@ -277,14 +277,15 @@ struct NmArgs {
   const uint32_t* corners[NLEV]; const int* rowlut[NLEV]; const int* ncorners;
   int* scores[NLEV]; uint32_t* maxcorners[NLEV]; int* nmax;
   int barrier, quirk;
+  const TrackerState* gate;   // non-null: only the streams whose tracker asked for a keyframe (kf_pending)
 };
 
 // compute_fast_score_old (cvfast.cpp:9337-9393): one lane per corner.
 __global__ __launch_bounds__(FE_THREADS) void k_score(NmArgs a) {
   const int l = blockIdx.y, s = blockIdx.z;
+  if (a.gate && !a.gate[s].kf_pending) return;
   const int n = a.ncorners[s * NLEV + l];
-  const int i = blockIdx.x * FE_THREADS + threadIdx.x;
-  if (i >= n) return;
+  for (int i = blockIdx.x * FE_THREADS + threadIdx.x; i < n; i += gridDim.x * FE_THREADS) {
   const uint32_t cxy = a.corners[l][(size_t)s * a.cap[l] + i];
   const int x = cxy & 0xFFFF, y = cxy >> 16, lp = a.img_pitch[l];
   const uint8_t* p = a.img[l] + (size_t)s * a.img_sstride[l] + (size_t)y * lp + x;
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(FE_THREADS) void k_score(NmArgs a) {
   SC(0, -3) SC(-1, -3) SC(-2, -2) SC(-3, -1) SC(-3, 0) SC(-3, 1) SC(-2, 2) SC(-1, 3)
 #undef SC
   a.scores[l][(size_t)s * a.cap[l] + i] = sp > sn ? sp : sn;
+  }
 }
 
 // nonmax_suppression (cvfast.cpp:9243-9335): a corner survives unless a corner among its 8 neighbours
@@ -304,6 +306,7 @@ __global__ __launch_bounds__(FE_THREADS) void k_nonmax(NmArgs a) {
   __shared__ int wsum[8];
   __shared__ int carry;
   const int l = blockIdx.x, s = blockIdx.y;
+  if (a.gate && !a.gate[s].kf_pending) return;
   const int n = a.ncorners[s * NLEV + l], cap = a.cap[l], h = a.h[l];
   const uint32_t* cs = a.corners[l] + (size_t)s * cap;
   const int* sc = a.scores[l] + (size_t)s * cap;
@@ -371,6 +374,7 @@ struct CandArgs {
   const uint32_t* maxcorners[NLEV]; const int* nmax;
   uint32_t* cand[NLEV]; double* cand_score[NLEV]; int* ncand;
   double min_score; int border;
+  const TrackerState* gate;
 };
 
 __device__ __forceinline__ double shi_tomasi7(const uint8_t* img, int pitch, int px, int py) {
@@ -409,6 +413,7 @@ __global__ __launch_bounds__(FE_THREADS) void k_candidates(CandArgs a) {
   __shared__ int wsum[FE_THREADS / 64];
   __shared__ int carry;
   const int l = blockIdx.x, s = blockIdx.y;
+  if (a.gate && !a.gate[s].kf_pending) return;
   const int n = a.nmax[s * NLEV + l], cap = a.cap[l];
   const uint32_t* mc = a.maxcorners[l] + (size_t)s * cap;
   const uint8_t* img = a.img[l] + (size_t)s * a.img_sstride[l];
@@ -441,7 +446,10 @@ __global__ __launch_bounds__(FE_THREADS) void k_candidates(CandArgs a) {
 #define THIN_BUSY_CAP 4096
 struct ThinArgs {
   uint32_t* cand[NLEV]; double* cand_score[NLEV]; int* ncand; int cap[NLEV];
-  const MeasDev* meas; size_t meas_sstride; const int* n_points; size_t st_stride;   // measurement row of the keyframe per stream
+  const MeasDev* meas; size_t meas_sstride;   // measurement row of the keyframe per stream
+  int new_kf;       // 1: gated on kf_pending and against the keyframe slot k_add_keyframe has just filled (slot n_kf)
+  int only_level;   // >= 0: this level only
+  size_t kf_row;    // max_points (elements per keyframe row) when new_kf
 };
 
 __global__ __launch_bounds__(FE_THREADS) void k_thin_candidates(ThinArgs a, const TrackerState* st) {
@@ -449,8 +457,9 @@ __global__ __launch_bounds__(FE_THREADS) void k_thin_candidates(ThinArgs a, cons
   __shared__ int nbusy;
   __shared__ int wsum[FE_THREADS / 64];
   __shared__ int carry;
-  const int l = blockIdx.x, s = blockIdx.y;
-  const MeasDev* ms = a.meas + (size_t)s * a.meas_sstride;
+  const int l = a.only_level >= 0 ? a.only_level : blockIdx.x, s = blockIdx.y;
+  if (a.new_kf && !st[s].kf_pending) return;
+  const MeasDev* ms = a.meas + (size_t)s * a.meas_sstride + (a.new_kf ? (size_t)st[s].n_kf * a.kf_row : 0);
   const int np = st[s].n_points;
   if (threadIdx.x == 0) { nbusy = 0; carry = 0; }
   __syncthreads();
@@ -554,7 +563,7 @@ int fe_make_keyframe_lite(vslam_system* sys, const uint8_t* gray, size_t row_str
   return VSLAM_OK;
 }
 
-int fe_fast_nonmax(vslam_system* sys) {
+static int fe_nonmax_impl(vslam_system* sys, bool gated) {
   if (!sys->have_frame) { vslam_set_error("fast_nonmax: no current frame"); return VSLAM_E_STATE; }
   NmArgs a;
   int maxcap = 0;
@@ -568,15 +577,19 @@ int fe_fast_nonmax(vslam_system* sys) {
   a.ncorners = sys->fr.ncorners; a.nmax = sys->fr.nmax;
   a.barrier = sys->p.nonmax_barrier;
   a.quirk = (sys->p.quirks & VSLAM_Q_NONMAX_RIGHT_NEIGHBOUR) ? 1 : 0;
-  hipLaunchKernelGGL(k_score, dim3((maxcap + FE_THREADS - 1) / FE_THREADS, NLEV, sys->S), dim3(FE_THREADS), 0, sys->stream, a);
+  a.gate = gated ? sys->map.st : nullptr;
+  (void)maxcap;
+  hipLaunchKernelGGL(k_score, dim3(16, NLEV, sys->S), dim3(FE_THREADS), 0, sys->stream, a);
   hipLaunchKernelGGL(k_nonmax, dim3(NLEV, sys->S), dim3(FE_THREADS), 0, sys->stream, a);
   HIPCHK(hipGetLastError());
   return VSLAM_OK;
 }
 
+int fe_fast_nonmax(vslam_system* sys) { return fe_nonmax_impl(sys, false); }
+
 // KeyFrame::MakeKeyFrame_Rest (jni/KeyFrame.cc:53-95) for the current frame of every stream: fast_nonmax + candidates.
-int fe_make_keyframe_rest(vslam_system* sys, double min_score) {
-  int r = fe_fast_nonmax(sys);
+static int fe_rest_impl(vslam_system* sys, double min_score, bool gated) {
+  int r = fe_nonmax_impl(sys, gated);
   if (r) return r;
   CandArgs a;
   for (int l = 0; l < NLEV; l++) {
@@ -587,11 +600,14 @@ int fe_make_keyframe_rest(vslam_system* sys, double min_score) {
   }
   a.nmax = sys->fr.nmax; a.ncand = sys->ncand;
   a.min_score = min_score; a.border = 10;                            // gvdCandidateMinSTScore / border, jni/KeyFrame.cc:57,65
+  a.gate = gated ? sys->map.st : nullptr;
   hipLaunchKernelGGL(k_candidates, dim3(NLEV, sys->S), dim3(FE_THREADS), 0, sys->stream, a);
   HIPCHK(hipGetLastError());
   sys->have_candidates = true;
   return VSLAM_OK;
 }
+int fe_make_keyframe_rest(vslam_system* sys, double min_score) { return fe_rest_impl(sys, min_score, false); }
+int fe_keyframe_rest_gated(vslam_system* sys) { return fe_rest_impl(sys, 70.0, true); }   // gvdCandidateMinSTScore, jni/KeyFrame.cc:57
 
 int fe_thin_candidates(vslam_system* sys, int keyframe) {
   if (!sys->have_candidates) { vslam_set_error("thin_candidates: call vslam_make_keyframe_rest first"); return VSLAM_E_STATE; }
@@ -600,9 +616,67 @@ int fe_thin_candidates(vslam_system* sys, int keyframe) {
   for (int l = 0; l < NLEV; l++) { a.cand[l] = sys->cand[l]; a.cand_score[l] = sys->cand_score[l]; a.cap[l] = sys->geom[l].cap; }
   a.ncand = sys->ncand;
   const size_t P = sys->p.max_points, K = sys->p.max_keyframes;
+  a.new_kf = 0; a.only_level = -1; a.kf_row = 0;
   if (keyframe < 0) { a.meas = sys->map.cur_meas; a.meas_sstride = P; }           // the tracker's measurements of this frame
   else { a.meas = sys->map.kf_meas + (size_t)keyframe * P; a.meas_sstride = K * P; }
   hipLaunchKernelGGL(k_thin_candidates, dim3(NLEV, sys->S), dim3(FE_THREADS), 0, sys->stream, a, sys->map.st);
   HIPCHK(hipGetLastError());
+  return VSLAM_OK;
+}
+
+// MapMaker::ThinCandidates(new keyframe, level) inside AddSomeMapPoints (jni/MapMaker.cc:432): against the measurement row of
+// the slot k_add_keyframe has just filled, which also holds the points the earlier levels of this keyframe have added.
+int fe_thin_new_keyframe(vslam_system* sys, int level) {
+  ThinArgs a;
+  for (int l = 0; l < NLEV; l++) { a.cand[l] = sys->cand[l]; a.cand_score[l] = sys->cand_score[l]; a.cap[l] = sys->geom[l].cap; }
+  a.ncand = sys->ncand;
+  const size_t P = sys->p.max_points, K = sys->p.max_keyframes;
+  a.meas = sys->map.kf_meas; a.meas_sstride = K * P; a.new_kf = 1; a.only_level = level; a.kf_row = P;
+  hipLaunchKernelGGL(k_thin_candidates, dim3(1, sys->S), dim3(FE_THREADS), 0, sys->stream, a, sys->map.st);
+  HIPCHK(hipGetLastError());
+  return VSLAM_OK;
+}
+
+// Level::vCorners of a stored keyframe (map upload with grow_map): the front-end kernels on a one-stream view whose level
+// images are the keyframe's own storage; the mask / list scratch is the front-end buffer that is not the current frame's.
+__global__ void k_store_kf_corners(const uint32_t* c0, const uint32_t* c1, const uint32_t* c2, const uint32_t* c3, const int* ncorners,
+                                   uint32_t* d0, uint32_t* d1, uint32_t* d2, uint32_t* d3, int* dn, int k0, int k1, int k2, int k3) {
+  const int l = blockIdx.x;
+  const uint32_t* src = l == 0 ? c0 : (l == 1 ? c1 : (l == 2 ? c2 : c3));
+  uint32_t* dst = l == 0 ? d0 : (l == 1 ? d1 : (l == 2 ? d2 : d3));
+  const int kc = l == 0 ? k0 : (l == 1 ? k1 : (l == 2 ? k2 : k3));
+  const int n = ncorners[l] < kc ? ncorners[l] : kc;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+  if (threadIdx.x == 0) dn[l] = n;
+}
+
+int fe_keyframe_corners(vslam_system* sys, int s, int kf) {
+  const LevelGeom* g = sys->geom;
+  const FrameDev& scr = sys->frbuf[sys->fr_idx ^ 1];
+  const size_t K = sys->p.max_keyframes;
+  FeArgs a;
+  for (int l = 0; l < NLEV; l++) {
+    uint8_t* img = sys->map.kf_img[l] + ((size_t)s * K + kf) * (size_t)g[l].pitch * g[l].h;
+    a.lvl[l] = img; a.lvl_sstride[l] = 0; a.lvl_pitch[l] = g[l].pitch;
+    a.w[l] = g[l].w; a.h[l] = g[l].h; a.nchunk[l] = g[l].nchunk; a.thr[l] = g[l].thr; a.cap[l] = g[l].cap;
+    a.cmask[l] = scr.cmask[l]; a.rowcnt[l] = scr.rowcnt[l]; a.rowlut[l] = scr.rowlut[l]; a.corners[l] = scr.corners[l];
+  }
+  a.ncorners = scr.ncorners; a.overflow = scr.overflow;
+  a.in = a.lvl[0]; a.in_sstride = 0; a.in_pitch = g[0].pitch;
+  const int lp0 = (g[0].w + 15) & ~15, lp1 = (g[1].w + 15) & ~15, lp2 = (g[2].w + 15) & ~15;
+  const size_t lds0 = (size_t)(BAND + 2 * HALO) * lp0 + (BAND / 2) * lp1 + (BAND / 4) * lp2 + 16 + (size_t)BAND * g[0].nchunk * 8 + (size_t)FB_ROWS * lp0 * 2 + 16;
+  hipLaunchKernelGGL(k_pyr_fast0, dim3((g[0].h + BAND - 1) / BAND, 1), dim3(FE_THREADS), lds0, sys->stream, a, lp0, lp1, lp2);
+  int nb = 0;
+  a.band_first[0] = 0;
+  for (int l = 1; l < NLEV; l++) { a.band_first[l] = nb; nb += (g[l].h + BAND - 1) / BAND; }
+  const size_t lds1 = (size_t)(BAND + 2 * HALO) * lp1 + 16 + (size_t)BAND * g[1].nchunk * 8 + (size_t)FB_ROWS * lp1 * 2 + 16;
+  hipLaunchKernelGGL(k_fast_lvl, dim3(nb, 1), dim3(FE_THREADS), lds1, sys->stream, a);
+  hipLaunchKernelGGL(k_compact, dim3(NLEV, 1), dim3(COMPACT_THREADS), 0, sys->stream, a);
+  uint32_t* d[NLEV];
+  for (int l = 0; l < NLEV; l++) d[l] = sys->map.kf_corners[l] + ((size_t)s * K + kf) * sys->tp.kcap[l];
+  hipLaunchKernelGGL(k_store_kf_corners, dim3(NLEV), dim3(256), 0, sys->stream, scr.corners[0], scr.corners[1], scr.corners[2], scr.corners[3], scr.ncorners,
+                     d[0], d[1], d[2], d[3], sys->map.kf_ncorners + ((size_t)s * K + kf) * NLEV, sys->tp.kcap[0], sys->tp.kcap[1], sys->tp.kcap[2], sys->tp.kcap[3]);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(sys->stream));
   return VSLAM_OK;
 }

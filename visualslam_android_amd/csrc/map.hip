@@ -50,6 +50,7 @@ extern "C" int vslam_map_add_keyframe(vslam_system* sys, int s, const double pos
   HIPCHK(hipMemcpyAsync(sys->map.kf_fixed + (size_t)s * K + k, &fx, sizeof(int), hipMemcpyHostToDevice, sys->stream));
   HIPCHK(hipMemcpyAsync(sys->map.kf_depth + ((size_t)s * K + k) * 2, dd, sizeof(dd), hipMemcpyHostToDevice, sys->stream));
   HIPCHK(hipMemsetAsync(sys->map.kf_meas + ((size_t)s * K + k) * sys->p.max_points, 0, sizeof(MeasDev) * sys->p.max_points, sys->stream));
+  if (sys->p.grow_map) { r = fe_keyframe_corners(sys, s, k); if (r) return r; }   // Level::vCorners, needed as an epipolar-search target
   st.n_kf = k + 1;
   r = put_state(sys, s, &st); if (r) return r;
   return k;

@@ -1,0 +1,376 @@
+// Map growth on a new keyframe (first part; vslam_params.grow_map = 1), all streams at once and
+// gated on the tracker's device-side keyframe request (kf_pending), between k_add_keyframe and the bundle adjustment:
+//   MakeKeyFrame_Rest candidates (frontend.hip, gated)                          jni/KeyFrame.cc:53-95
+//   for level in 3, 0, 1, 2 (jni/MapMaker.cc:498-501):
+//     MapMaker::ThinCandidates(new keyframe, level)  (frontend.hip)             jni/MapMaker.cc:393-422
+//     MapMaker::AddPointEpipolar for every remaining candidate  (k_epipolar)    jni/MapMaker.cc:525-703
+//       PatchFinder::MakeTemplateCoarseNoWarp :130-142, ZMSSDAtPoint :352-380, MakeSubPixTemplate / IterateSubPixToConvergence
+//       :242-350, MapMaker::ReprojectPoint :174-200, MapPoint::RefreshPixelVectors jni/MapPoint.cc:4-29
+// One wavefront per candidate; the candidates of a level are independent of each other, new points are appended in
+// candidate order by an ordered commit (the reference's push_back order).  Not built: ReFind* (see DESIGN.md).
+// Eigen::JacobiSVD of the 4x4 triangulation matrix is third-party arithmetic, restated as in oracle/mapgrow.cpp (parity unpinned).
+#include "vslam_internal.h"
+
+#define GROW_THREADS 256
+#define GROW_WAVES (GROW_THREADS / 64)
+
+struct GrowArgs {
+  const uint32_t* cand[NLEV]; const int* ncand; int cap[NLEV];     // current frame's candidate lists [S][cap], counts [S][NLEV]
+  int w[NLEV], h[NLEV], kf_pitch[NLEV]; size_t kf_stride[NLEV];
+};
+
+struct EpiResult { int ok; double pos[3], right[3], down[3], root[2], sub[2]; int irx, iry; };
+
+DEVFN int wsum_i(int v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d); return v; }
+DEVFN double wsum_d(double v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d); return v; }
+
+// smallest-eigenvalue eigenvector of a symmetric 4x4 matrix: cyclic Jacobi, 16 sweeps (same sequence as the oracle)
+DEVFN void smallest_eigvec4(const double Sin[16], double out[4]) {
+  double S[16], V[16];
+  for (int i = 0; i < 16; i++) { S[i] = Sin[i]; V[i] = (i % 5 == 0) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 16; sweep++)
+    for (int p = 0; p < 3; p++)
+      for (int q = p + 1; q < 4; q++) {
+        const double apq = S[p * 4 + q];
+        if (apq == 0.0) continue;
+        const double theta = (S[q * 4 + q] - S[p * 4 + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 4; k++) { const double a = S[k * 4 + p], b = S[k * 4 + q]; S[k * 4 + p] = c * a - s * b; S[k * 4 + q] = s * a + c * b; }
+        for (int k = 0; k < 4; k++) { const double a = S[p * 4 + k], b = S[q * 4 + k]; S[p * 4 + k] = c * a - s * b; S[q * 4 + k] = s * a + c * b; }
+        for (int k = 0; k < 4; k++) { const double a = V[k * 4 + p], b = V[k * 4 + q]; V[k * 4 + p] = c * a - s * b; V[k * 4 + q] = s * a + c * b; }
+      }
+  int best = 0;
+  for (int i = 1; i < 4; i++) if (S[i * 4 + i] < S[best * 4 + best]) best = i;
+  for (int k = 0; k < 4; k++) out[k] = V[k * 4 + best];
+}
+
+// MapMaker::ReprojectPoint, jni/MapMaker.cc:174-200
+DEVFN void reproject_point(const Pose& AfromB, const double v2A[2], const double v2B[2], double out[3]) {
+  double PD[12];
+  for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) PD[r * 4 + c] = AfromB.R[r * 3 + c]; PD[r * 4 + 3] = AfromB.t[r]; }
+  double A[16] = {-1.0, 0.0, v2B[0], 0.0, 0.0, -1.0, v2B[1], 0.0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int c = 0; c < 4; c++) { A[8 + c] = v2A[0] * PD[8 + c] - PD[0 + c]; A[12 + c] = v2A[1] * PD[8 + c] - PD[4 + c]; }
+  double S[16];
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { double s = 0; for (int k = 0; k < 4; k++) s += A[k * 4 + i] * A[k * 4 + j]; S[i * 4 + j] = s; }
+  double v[4];
+  smallest_eigvec4(S, v);
+  if (v[3] == 0.0) v[3] = 0.00001;
+  out[0] = v[0] / v[3]; out[1] = v[1] / v[3]; out[2] = v[2] / v[3];
+}
+
+DEVFN void unit_ray(const CamModel& cam, double ix, double iy, double out[3]) {   // myUnproject + normalize()
+  double u[2];
+  cam_unproject(cam, ix, iy, u);
+  const double n = sqrt(u[0] * u[0] + u[1] * u[1] + 1.0);
+  out[0] = u[0] / n; out[1] = u[1] / n; out[2] = 1.0 / n;
+}
+DEVFN void rot_inv(const Pose& T, const double p[3], double o[3]) {             // R^T p
+  o[0] = T.R[0] * p[0] + T.R[3] * p[1] + T.R[6] * p[2];
+  o[1] = T.R[1] * p[0] + T.R[4] * p[1] + T.R[7] * p[2];
+  o[2] = T.R[2] * p[0] + T.R[5] * p[1] + T.R[8] * p[2];
+}
+
+// MapMaker::AddKeyFrame's deep copy of Level::vCorners for the new keyframe (jni/KeyFrame.cc:104-112)
+__global__ void k_copy_kf_corners(MapDev m, TrackParams tp, const uint32_t* c0, const uint32_t* c1, const uint32_t* c2, const uint32_t* c3,
+                                  const int* ncorners, int cap0, int cap1, int cap2, int cap3) {
+  const int l = blockIdx.x, s = blockIdx.y;
+  const TrackerState* st = &m.st[s];
+  if (!st->kf_pending) return;
+  const uint32_t* src = (l == 0 ? c0 : (l == 1 ? c1 : (l == 2 ? c2 : c3))) + (size_t)s * (l == 0 ? cap0 : (l == 1 ? cap1 : (l == 2 ? cap2 : cap3)));
+  const size_t slot = (size_t)s * tp.max_keyframes + st->n_kf;
+  uint32_t* dst = m.kf_corners[l] + slot * tp.kcap[l];
+  const int n = ncorners[s * NLEV + l] < tp.kcap[l] ? ncorners[s * NLEV + l] : tp.kcap[l];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+  if (threadIdx.x == 0) m.kf_ncorners[slot * NLEV + l] = n;
+}
+
+// ClosestKeyFrame(new keyframe) among the existing ones, jni/MapMaker.cc:737-758 with KeyFrameLinearDist :705-712
+DEVFN int closest_keyframe(const Pose* kfp, int n_old, const Pose& self) {
+  const Pose is = pose_inverse(self);
+  double best = 9999999999.9; int n = -1;
+  for (int i = 0; i < n_old; i++) {
+    const Pose ii = pose_inverse(kfp[i]);
+    const double d0 = ii.t[0] - is.t[0], d1 = ii.t[1] - is.t[1], d2 = ii.t[2] - is.t[2];
+    const double d = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+    if (d < best) { best = d; n = i; }
+  }
+  return n;
+}
+
+template <int PS>
+__global__ __launch_bounds__(GROW_THREADS) void k_epipolar(MapDev m, TrackParams tp, GrowArgs a, int nLevel) {
+  constexpr int NPIX = PS * PS, HALF = PS / 2, Q = PS - 2, NQL = (Q * Q + 63) / 64;
+  const int s = blockIdx.x;
+  TrackerState* st = &m.st[s];
+  if (!st->kf_pending) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int K = tp.max_keyframes, P = tp.max_points;
+  const int ksrc = st->n_kf;                                       // the slot k_add_keyframe has just filled (n_kf advances in k_ba_assemble)
+  __shared__ int sh_tgt;
+  __shared__ EpiResult res[GROW_WAVES];
+  __shared__ uint8_t sh_tmpl[GROW_WAVES][128];
+  const Pose* kfp = m.kf_pose + (size_t)s * K;
+  if (threadIdx.x == 0) sh_tgt = closest_keyframe(kfp, ksrc, kfp[ksrc]);
+  __syncthreads();
+  const int ktgt = sh_tgt;
+  if (ktgt < 0) return;
+  const Pose Tsrc = kfp[ksrc], Ttgt = kfp[ktgt];
+  const int nLevelScale = 1 << nLevel;
+  const int wl = a.w[nLevel], hl = a.h[nLevel], ip = a.kf_pitch[nLevel];
+  const uint8_t* img_src = m.kf_img[nLevel] + ((size_t)s * K + ksrc) * a.kf_stride[nLevel];
+  const uint8_t* img_tgt = m.kf_img[nLevel] + ((size_t)s * K + ktgt) * a.kf_stride[nLevel];
+  const uint32_t* tcorners = m.kf_corners[nLevel] + ((size_t)s * K + ktgt) * tp.kcap[nLevel];
+  const int ntc = m.kf_ncorners[((size_t)s * K + ktgt) * NLEV + nLevel];
+  const uint32_t* cand = a.cand[nLevel] + (size_t)s * a.cap[nLevel];
+  const int ncand = a.ncand[s * NLEV + nLevel];
+  const double dMean = m.kf_depth[((size_t)s * K + ksrc) * 2], dSigma = m.kf_depth[((size_t)s * K + ksrc) * 2 + 1];
+  uint8_t* tmpl = sh_tmpl[wave];
+
+  for (int c0 = 0; c0 < ncand; c0 += GROW_WAVES) {
+    const int ci = c0 + wave;
+    bool alive = ci < ncand;
+    if (lane == 0) res[wave].ok = 0;
+    double irx = 0, iry = 0, root0 = 0, root1 = 0, along0 = 0, along1 = 0, normal0 = 0, normal1 = 0, dNormDist = 0, dMinLen = 0, dMaxLen = 0;
+    int ca = 0, cb = 0;
+    if (alive) {                                                   // ---- geometry of the epipolar line, :544-591 (every lane alike)
+      const uint32_t cpos = cand[ci];
+      irx = (double)(cpos & 0xFFFF); iry = (double)(cpos >> 16);
+      root0 = level_zero_pos(irx, nLevel); root1 = level_zero_pos(iry, nLevel);
+      double ray[3], tmp[3], dirn[3];
+      unit_ray(tp.cam, root0, root1, ray);
+      rot_inv(Tsrc, ray, tmp);
+      pose_rot(Ttgt, tmp, dirn);
+      const double dStartDepth = tp.wiggle_scale > dMean - dSigma ? tp.wiggle_scale : dMean - dSigma;
+      const double dEndDepth = 40 * tp.wiggle_scale < dMean + dSigma ? 40 * tp.wiggle_scale : dMean + dSigma;
+      const Pose srcInv = pose_inverse(Tsrc);
+      double centre[3];
+      pose_xform(Ttgt, srcInv.t, centre);
+      double rs[3], re[3];
+      for (int i = 0; i < 3; i++) { rs[i] = centre[i] + dStartDepth * dirn[i]; re[i] = centre[i] + dEndDepth * dirn[i]; }
+      if (re[2] <= rs[2]) alive = false;
+      if (re[2] <= 0.0) alive = false;
+      if (alive) {
+        if (rs[2] <= 0.0) { const double f = 0.001 - rs[2] / dirn[2]; for (int i = 0; i < 3; i++) rs[i] += dirn[i] * f; }
+        const double v2A[2] = {rs[0] / rs[2], rs[1] / rs[2]}, v2B[2] = {re[0] / re[2], re[1] / re[2]};
+        along0 = v2A[0] - v2B[0]; along1 = v2A[1] - v2B[1];
+        if (along0 * along0 + along1 * along1 < 0.00000001) alive = false;
+        else {
+          const double n = sqrt(along0 * along0 + along1 * along1);
+          along0 /= n; along1 /= n;
+          normal0 = along1; normal1 = -along0;
+          dNormDist = v2A[0] * normal0 + v2A[1] * normal1;
+          if (fabs(dNormDist) > tp.cam.largest_radius) alive = false;
+          const double la = along0 * v2A[0] + along1 * v2A[1], lb = along0 * v2B[0] + along1 * v2B[1];
+          dMinLen = (la < lb ? la : lb) - 0.05; dMaxLen = (la > lb ? la : lb) + 0.05;
+          if (dMinLen < -2.0) dMinLen = -2.0;
+          if (dMaxLen < -2.0) dMaxLen = -2.0;
+          if (dMinLen > 2.0) dMinLen = 2.0;
+          if (dMaxLen > 2.0) dMaxLen = 2.0;
+        }
+      }
+      // ---- MakeTemplateCoarseNoWarp (jni/PatchFinder.cc:130-142) + MakeTemplateSums ----
+      ca = (int)irx; cb = (int)iry;
+      const int bord = HALF + 1;
+      if (!(ca >= bord && cb >= bord && ca < wl - bord && cb < hl - bord)) alive = false;
+    }
+    int tsum = 0, tsumsq = 0;
+    if (alive) {
+      int sa = 0, sq = 0;
+      for (int q = lane; q < NPIX; q += 64) {
+        const int y = q / PS, x = q - y * PS;
+        const int v = img_src[(size_t)(cb - HALF + y) * ip + (ca - HALF + x)];
+        tmpl[q] = (uint8_t)v; sa += v; sq += v * v;
+      }
+      tsum = wsum_i(sa); tsumsq = wsum_i(sq);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- the target keyframe's corners near the epipolar line, :622-641: filter 64 at a time, score the survivors in order ----
+    int nBest = -1, nBestZMSSD = tp.max_ssd + 1;
+    if (alive) {
+      const double dMaxDistDiff = tp.one_pixel_dist * (4.0 + 1.0 * nLevelScale), dMaxDistSq = dMaxDistDiff * dMaxDistDiff;
+      for (int base = 0; base < ntc; base += 64) {
+        bool ok = false;
+        uint32_t cv = 0;
+        if (base + lane < ntc) {
+          cv = tcorners[base + lane];
+          double v2Im[2];   // vImplaneCorners (:612-620): UnProject of the level-zero position truncated to integer pixels
+          cam_unproject(tp.cam, (double)(int)level_zero_pos((double)(cv & 0xFFFF), nLevel), (double)(int)level_zero_pos((double)(cv >> 16), nLevel), v2Im);
+          const double dDistDiff = dNormDist - (v2Im[0] * normal0 + v2Im[1] * normal1);
+          const double len = v2Im[0] * along0 + v2Im[1] * along1;
+          ok = !(dDistDiff * dDistDiff > dMaxDistSq) && !(len < dMinLen) && !(len > dMaxLen);
+        }
+        unsigned long long bm = __ballot(ok);
+        while (bm) {
+          const int k = __ffsll((long long)bm) - 1;
+          bm &= bm - 1;
+          const uint32_t c = __shfl(cv, k);
+          const int cx = c & 0xFFFF, cy = c >> 16;
+          int ssd = tp.max_ssd + 1;
+          if (cx >= HALF && cy >= HALF && cx < wl - HALF && cy < hl - HALF) {   // ZMSSDAtPoint :352-380
+            int sA = 0, sQ = 0, sX = 0;
+            for (int q = lane; q < NPIX; q += 64) {
+              const int y = q / PS, x = q - y * PS;
+              const int n = img_tgt[(size_t)(cy - HALF + y) * ip + (cx - HALF + x)], t = tmpl[q];
+              sA += n; sQ += n * n; sX += n * t;
+            }
+            sA = wsum_i(sA); sQ = wsum_i(sQ); sX = wsum_i(sX);
+            const int SA = tsum, SB = sA;
+            ssd = ((2 * SA * SB - SA * SA - SB * SB) / NPIX + sQ + tsumsq - 2 * sX);
+          }
+          if (ssd < nBestZMSSD) { nBest = base + k; nBestZMSSD = ssd; }
+        }
+      }
+      if (nBest == -1) alive = false;
+    }
+    // ---- MakeSubPixTemplate + SetSubPixPos + IterateSubPixToConvergence(kTarget, 10), :658-664 ----
+    double sub0 = 0, sub1 = 0;
+    if (alive) {
+      const uint32_t bc = tcorners[nBest];
+      sub0 = level_zero_pos((double)(bc & 0xFFFF), nLevel); sub1 = level_zero_pos((double)(bc >> 16), nLevel);
+      double gx[NQL], gy[NQL];
+      double h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0;
+      for (int q = 0; q < NQL; q++) {
+        const int k = q * 64 + lane;
+        gx[q] = 0; gy[q] = 0;
+        if (k < Q * Q) {
+          const int x = k / Q + 1, y = k % Q + 1;
+          gx[q] = 0.5 * (tmpl[y * PS + x + 1] - tmpl[y * PS + x - 1]);
+          gy[q] = 0.5 * (tmpl[(y + 1) * PS + x] - tmpl[(y - 1) * PS + x]);
+          h00 += gx[q] * gx[q]; h01 += gx[q] * gy[q]; h02 += gx[q]; h11 += gy[q] * gy[q]; h12 += gy[q]; h22 += 1.0;
+        }
+      }
+      h00 = wsum_d(h00); h01 = wsum_d(h01); h02 = wsum_d(h02); h11 = wsum_d(h11); h12 = wsum_d(h12); h22 = wsum_d(h22);
+      const double H[9] = {h00, h01, h02, h01, h11, h12, h02, h12, h22};
+      double Hinv[9];
+      inv3(H, Hinv);
+      double meanDiff = 0.0;
+      bool converged = false;
+      for (int it = 0; it < 10; it++) {
+        const double cx = level_n_pos(sub0, nLevel), cy = level_n_pos(sub1, nLevel);
+        const int xb = (int)(cx > 0.0 ? cx + 0.5 : cx - 0.5), yb = (int)(cy > 0.0 ? cy + 0.5 : cy - 0.5);
+        const int b = HALF + 1;
+        if (!(xb >= b && yb >= b && xb < wl - b && yb < hl - b)) break;
+        const double bx = cx - HALF, by = cy - HALF;
+        const double dX = bx - floor(bx), dY = by - floor(by);
+        const float fTL = (float)((1.0 - dX) * (1.0 - dY)), fTR = (float)((dX) * (1.0 - dY));
+        const float fBL = (float)((1.0 - dX) * (dY)), fBR = (float)((dX) * (dY));
+        double a0 = 0, a1 = 0, a2 = 0;
+        for (int q = 0; q < NQL; q++) {
+          const int k = q * 64 + lane;
+          if (k < Q * Q) {
+            const int x = k / Q + 1, y = k % Q + 1;
+            const uint8_t* tl = img_tgt + (size_t)((int)by + y) * ip + (int)bx + x;
+            const float fPixel = fTL * tl[0] + fTR * tl[1] + fBL * tl[ip] + fBR * tl[ip + 1];
+            const double dDiff = (fPixel - (float)tmpl[y * PS + x]) + meanDiff;
+            a0 += dDiff * gx[q]; a1 += dDiff * gy[q]; a2 += dDiff;
+          }
+        }
+        a0 = wsum_d(a0); a1 = wsum_d(a1); a2 = wsum_d(a2);
+        const double u0 = Hinv[0] * a0 + Hinv[1] * a1 + Hinv[2] * a2;
+        const double u1 = Hinv[3] * a0 + Hinv[4] * a1 + Hinv[5] * a2;
+        const double u2 = Hinv[6] * a0 + Hinv[7] * a1 + Hinv[8] * a2;
+        sub0 -= u0 * nLevelScale; sub1 -= u1 * nLevelScale; meanDiff -= u2;
+        if (u0 * u0 + u1 * u1 < 0.03 * 0.03) { converged = true; break; }
+      }
+      if (!converged) alive = false;
+    }
+    // ---- triangulation and the new point's patch vectors, :666-702 (lane 0) ----
+    if (alive && lane == 0) {
+      double uA[2], uB[2], pB[3], pw[3];
+      cam_unproject(tp.cam, root0, root1, uA);
+      cam_unproject(tp.cam, sub0, sub1, uB);
+      const Pose tinv = pose_inverse(Ttgt);
+      reproject_point(pose_mul(Tsrc, tinv), uA, uB, pB);
+      pose_xform(tinv, pB, pw);
+      double cen[3], rgt[3], dwn[3];
+      unit_ray(tp.cam, root0, root1, cen); unit_ray(tp.cam, root0 + nLevelScale, root1, rgt); unit_ray(tp.cam, root0, root1 + nLevelScale, dwn);
+      double pc[3];
+      pose_xform(Tsrc, pw, pc);                                        // RefreshPixelVectors, normal (0, 0, -1)
+      const double hgt = fabs(-pc[2]), rc = fabs(-cen[2]), rr = fabs(-rgt[2]), rd = fabs(-dwn[2]);
+      double dr[3], dd[3];
+      for (int i = 0; i < 3; i++) { const double cop = cen[i] * hgt / rc; dr[i] = rgt[i] * hgt / rr - cop; dd[i] = dwn[i] * hgt / rd - cop; }
+      EpiResult& r = res[wave];
+      rot_inv(Tsrc, dr, r.right); rot_inv(Tsrc, dd, r.down);
+      for (int i = 0; i < 3; i++) r.pos[i] = pw[i];
+      r.root[0] = root0; r.root[1] = root1; r.sub[0] = sub0; r.sub[1] = sub1; r.irx = ca; r.iry = cb;
+      r.ok = 1;
+    }
+    __syncthreads();
+    // ---- ordered commit: mMap.vpPoints.push_back + the two measurements, :692-701 ----
+    if (threadIdx.x == 0) {
+      for (int wv = 0; wv < GROW_WAVES; wv++) {
+        if (!res[wv].ok) continue;
+        const int pid = st->n_points;
+        if (pid >= P) break;                                             // map capacity: stop growing
+        const EpiResult& r = res[wv];
+        MapPointDev mp;
+        for (int i = 0; i < 3; i++) { mp.pos[i] = r.pos[i]; mp.right[i] = r.right[i]; mp.down[i] = r.down[i]; }
+        mp.src_kf = ksrc; mp.src_level = nLevel; mp.irx = r.irx; mp.iry = r.iry; mp.bad = 0; mp.n_in = 0; mp.n_out = 0; mp.n_meas_kfs = 2;
+        m.pts[(size_t)s * P + pid] = mp;
+        TrackData td;
+        for (int i = 0; i < 3; i++) td.cam[i] = 0;
+        for (int i = 0; i < 2; i++) { td.image[i] = 0; td.vfound[i] = 0; }
+        for (int i = 0; i < 4; i++) { td.derivs[i] = 0; td.warp_inv[i] = 0; td.last_warp[i] = 0; }
+        td.sqrt_inv_noise = 0; td.tsum = 0; td.tsumsq = 0;
+        td.last_warp[0] = 9999.9; td.last_warp[3] = 9999.9;               // jni/PatchFinder.cc:23
+        m.td[(size_t)s * P + pid] = td;
+        m.pt_level[(size_t)s * P + pid] = -1; m.pt_flags[(size_t)s * P + pid] = 0;
+        MeasDev mm;
+        mm.valid = 1; mm.level = (signed char)nLevel; mm.subpix = 1; mm.pad = 0;
+        for (int k = 0; k <= ksrc; k++) {                                 // the new column of the measurement table
+          MeasDev z; z.root[0] = 0; z.root[1] = 0; z.valid = 0; z.level = 0; z.subpix = 0; z.source = 0; z.pad = 0;
+          m.kf_meas[((size_t)s * K + k) * P + pid] = z;
+        }
+        mm.source = 2 /* SRC_ROOT */; mm.root[0] = r.root[0]; mm.root[1] = r.root[1];
+        m.kf_meas[((size_t)s * K + ksrc) * P + pid] = mm;
+        mm.source = 4 /* SRC_EPIPOLAR */; mm.root[0] = r.sub[0]; mm.root[1] = r.sub[1];
+        m.kf_meas[((size_t)s * K + ktgt) * P + pid] = mm;
+        m.cur_meas[(size_t)s * P + pid].valid = 0;
+        st->n_points = pid + 1;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+int grow_alloc(vslam_system* sys) {
+  if (!sys->p.grow_map) return VSLAM_OK;
+  const size_t S = sys->S, K = sys->p.max_keyframes;
+  for (int l = 0; l < NLEV; l++) {
+    void* ptr = nullptr;
+    HIPCHK(hipMalloc(&ptr, S * K * (size_t)sys->tp.kcap[l] * sizeof(uint32_t) + 64));
+    sys->allocs.push_back(ptr);
+    sys->map.kf_corners[l] = (uint32_t*)ptr;
+  }
+  void* ptr = nullptr;
+  HIPCHK(hipMalloc(&ptr, S * K * NLEV * sizeof(int) + 64));
+  HIPCHK(hipMemsetAsync(ptr, 0, S * K * NLEV * sizeof(int) + 64, sys->stream));
+  sys->allocs.push_back(ptr);
+  sys->map.kf_ncorners = (int*)ptr;
+  return VSLAM_OK;
+}
+
+int grow_on_keyframe(vslam_system* sys) {
+  if (!sys->p.grow_map) return VSLAM_OK;
+  const LevelGeom* g = sys->geom;
+  hipLaunchKernelGGL(k_copy_kf_corners, dim3(NLEV, sys->S), dim3(256), 0, sys->stream, sys->map, sys->tp, sys->fr.corners[0], sys->fr.corners[1],
+                     sys->fr.corners[2], sys->fr.corners[3], sys->fr.ncorners, g[0].cap, g[1].cap, g[2].cap, g[3].cap);
+  int r = fe_keyframe_rest_gated(sys);                                   // pK->MakeKeyFrame_Rest(), jni/MapMaker.cc:488
+  if (r) return r;
+  GrowArgs a;
+  for (int l = 0; l < NLEV; l++) {
+    a.cand[l] = sys->cand[l]; a.cap[l] = g[l].cap; a.w[l] = g[l].w; a.h[l] = g[l].h; a.kf_pitch[l] = g[l].pitch;
+    a.kf_stride[l] = (size_t)g[l].pitch * g[l].h;
+  }
+  a.ncand = sys->ncand;
+  const int order[NLEV] = {3, 0, 1, 2};                                   // AddSomeMapPoints(3); (0); (1); (2), :498-501
+  for (int i = 0; i < NLEV; i++) {
+    r = fe_thin_new_keyframe(sys, order[i]);
+    if (r) return r;
+    if (sys->tp.P == 8) hipLaunchKernelGGL(k_epipolar<8>, dim3(sys->S), dim3(GROW_THREADS), 0, sys->stream, sys->map, sys->tp, a, order[i]);
+    else hipLaunchKernelGGL(k_epipolar<11>, dim3(sys->S), dim3(GROW_THREADS), 0, sys->stream, sys->map, sys->tp, a, order[i]);
+  }
+  HIPCHK(hipGetLastError());
+  return VSLAM_OK;
+}

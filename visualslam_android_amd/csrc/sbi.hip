@@ -39,15 +39,6 @@ DEVFN Se2 se2_inverse(const Se2& a) {                              // :506-511
 }
 DEVFN int clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
 
-// ATANCamera::UnProject, jni/ATANCamera.cc:149-164
-DEVFN void cam_unproject_dev(const CamModel& c, double ix, double iy, double out[2]) {
-  const double dx = (ix - c.center[0]) * (1.0 / c.focal[0]), dy = (iy - c.center[1]) * (1.0 / c.focal[1]);
-  const double dist_r = sqrt(dx * dx + dy * dy);
-  const double r = c.w == 0.0 ? dist_r : tan(dist_r * c.w) * (1.0 / c.two_tan);
-  const double f = dist_r > 0.01 ? r / dist_r : 1.0;
-  out[0] = dx * f; out[1] = dy * f;
-}
-
 __global__ __launch_bounds__(SBI_THREADS) void k_sbi(SbiArgs a) {
   __shared__ float t0[SBI_MAX_PIX];      // zero-mean small image, later the warped template
   __shared__ float t1[SBI_MAX_PIX];      // row pass, later this frame's template
@@ -190,7 +181,7 @@ __global__ __launch_bounds__(SBI_THREADS) void k_sbi(SbiArgs a) {
     turned[k][0] = cx + (CtoC.t[0] + (CtoC.R[0] * offs[k][0] + CtoC.R[1] * offs[k][1]));
     turned[k][1] = cy + (CtoC.t[1] + (CtoC.R[2] * offs[k][0] + CtoC.R[3] * offs[k][1]));
     double up[2];
-    cam_unproject_dev(a.cam, cx + offs[k][0], cy + offs[k][1], up);
+    cam_unproject(a.cam, cx + offs[k][0], cy + offs[k][1], up);
     orig[k][0] = up[0]; orig[k][1] = up[1]; orig[k][2] = 1.0;
   }
   Pose so3; for (int i = 0; i < 9; i++) so3.R[i] = (i % 4 == 0) ? 1.0 : 0.0; so3.t[0] = so3.t[1] = so3.t[2] = 0.0;

@@ -46,6 +46,7 @@ extern "C" int vslam_default_params(vslam_params* p, int width, int height, int 
   p->quirks = 0;
   p->device = 0;
   p->ba_delay_frames = 0;
+  p->grow_map = 0;
   return VSLAM_OK;
 }
 
@@ -138,6 +139,7 @@ extern "C" int vslam_create(const vslam_params* p, vslam_system** out) {
   {
     int r = trk_alloc(sys);
     if (!r) r = ba_alloc(sys);
+    if (!r) r = grow_alloc(sys);
     if (!r && hipStreamSynchronize(sys->stream) != hipSuccess) r = VSLAM_E_HIP;
     if (!r) r = map_init_states(sys);
     if (r) { vslam_destroy(sys); return r; }

@@ -942,6 +942,16 @@ void trk_fill_params(const vslam_params& p, TrackParams& t) {
   t.ba_max_iterations = p.ba_max_iterations; t.ba_convergence_limit = p.ba_convergence_limit;
   t.ba_min_sigma2 = p.ba_min_tukey_sigma * p.ba_min_tukey_sigma; t.ba_window = p.ba_window; t.ba_min_keyframes = p.ba_min_keyframes;
   t.quirks = p.quirks; t.max_points = p.max_points; t.max_keyframes = p.max_keyframes; t.ba_delay = p.ba_delay_frames;
+  t.grow_map = p.grow_map;
+  {                                                                  // ATANCamera::OnePixelDist, jni/ATANCamera.cc:86-91
+    double a[2], b[2];
+    cam_unproject(t.cam, t.cam.size[0] / 2, t.cam.size[1] / 2, a);
+    cam_unproject(t.cam, t.cam.size[0] / 2 + 1, t.cam.size[1] / 2 + 1, b);
+    const double d0 = a[0] - b[0], d1 = a[1] - b[1];
+    t.one_pixel_dist = sqrt(d0 * d0 + d1 * d1) / sqrt(2.0);
+  }
+  const int kcap_max[NLEV] = {16384, 8192, 2048, 512};               // stored corner list of a keyframe (grow_map): see DESIGN.md
+  for (int l = 0; l < NLEV; l++) t.kcap[l] = p.max_corners[l] < kcap_max[l] ? p.max_corners[l] : kcap_max[l];
 
 }
 

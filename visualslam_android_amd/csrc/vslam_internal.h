@@ -111,6 +111,9 @@ struct TrackParams {        // device copy of the tunables the kernels read
   int quirks;
   int max_points, max_keyframes;
   int ba_delay;             // vslam_params.ba_delay_frames
+  int grow_map;             // vslam_params.grow_map
+  double one_pixel_dist;    // ATANCamera::OnePixelDist, jni/ATANCamera.cc:86-91
+  int kcap[NLEV];           // capacity of a keyframe's stored corner list per level (grow_map)
 };
 
 struct MapDev {             // device pointers of the map + tracker of all streams
@@ -123,6 +126,8 @@ struct MapDev {             // device pointers of the map + tracker of all strea
   int* kf_fixed;            // [S][max_keyframes]
   double* kf_depth;         // [S][max_keyframes][2]
   uint8_t* kf_img[NLEV];    // [S][max_keyframes][h*pitch]
+  uint32_t* kf_corners[NLEV];   // [S][max_keyframes][kcap_l]  Level::vCorners of the keyframes (grow_map only: epipolar search)
+  int* kf_ncorners;         // [S][max_keyframes][NLEV]
   TrackerState* st;         // [S]
   int* pvs_list;            // [S][NLEV][max_points]
   int2* search_list;        // [S][max_points]  (point index, sub-pixel iterations)
@@ -180,6 +185,11 @@ static inline void prof_mark(vslam_system* sys, int k) {
 int fe_make_keyframe_lite(vslam_system* sys, const uint8_t* gray, size_t row_stride, size_t stream_stride,
                           int on_device);
 int fe_fast_nonmax(vslam_system* sys);
+int fe_keyframe_corners(vslam_system* sys, int s, int kf);   // FAST corners of a stored keyframe into MapDev::kf_corners (map upload)
+int fe_keyframe_rest_gated(vslam_system* sys);               // non-max + candidates of the current frame for the streams with kf_pending
+int fe_thin_new_keyframe(vslam_system* sys, int level);      // ThinCandidates(new keyframe, level) for the streams with kf_pending
+int grow_alloc(vslam_system* sys);
+int grow_on_keyframe(vslam_system* sys);                      // AddSomeMapPoints(3, 0, 1, 2) for the streams with kf_pending
 int fe_sbi(vslam_system* sys, const FrameDev& last);   // k_sbi on the front-end stream: this frame's SBI + rotation prior against `last`
 void cam_fill(CamModel& c, const double cam5[5], double width, double height, int quirks);
 int fe_make_keyframe_rest(vslam_system* sys, double min_score);
