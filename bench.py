@@ -107,6 +107,8 @@ def main():
                     help="vslam_params.ba_delay_frames: 0 = synchronous map-maker; D > 0 = Bundle::Compute on its own HIP stream, applied D frames later")
     ap.add_argument("--use-sbi", type=int, default=int(os.environ.get("VSLAM_BENCH_USE_SBI", 0)),
                     help="vslam_params.use_sbi: 1 = SmallBlurryImage rotation prior in the motion model (the reference's gvnUseSBI)")
+    ap.add_argument("--grow-map", type=int, default=int(os.environ.get("VSLAM_BENCH_GROW_MAP", 0)),
+                    help="vslam_params.grow_map: 1 = every new keyframe also adds map points by epipolar search (AddSomeMapPoints)")
     ap.add_argument("--no-events", action="store_true", help="skip the per-stage HIP events in the timed region")
     args = ap.parse_args()
     rank, world, local_rank = dist_env()
@@ -147,7 +149,7 @@ def main():
     NS = max(1, min(args.systems, S))
     assert S % NS == 0, "--streams must be a multiple of --systems"
     Sk = S // NS
-    vpk = capi.default_params(W, H, Sk, patch_size=args.patch, device=local_rank, ba_delay_frames=args.ba_delay, use_sbi=args.use_sbi)
+    vpk = capi.default_params(W, H, Sk, patch_size=args.patch, device=local_rank, ba_delay_frames=args.ba_delay, use_sbi=args.use_sbi, grow_map=args.grow_map)
     systems = [capi.System(vpk) for _ in range(NS)]
 
     def sys_of(s):
@@ -287,7 +289,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: %dx%d 4-level FAST-10 + %dx%d PatchFinder ZMSSD search, TrackMap pose update, "
                                    "AddKeyFrame + BundleAdjustRecent on keyframe frames" % (W, H, args.patch, args.patch),
-                       "streams_per_gpu": S, "systems_per_gpu": NS, "ba_delay_frames": args.ba_delay, "use_sbi": args.use_sbi, "patch_size": args.patch, "corners_l0_per_frame": ncorn,
+                       "streams_per_gpu": S, "systems_per_gpu": NS, "ba_delay_frames": args.ba_delay, "use_sbi": args.use_sbi, "grow_map": args.grow_map, "patch_size": args.patch, "corners_l0_per_frame": ncorn,
                        "patches_attempted_per_frame": round(att, 1), "patches_found_per_frame": round(fnd, 1),
                        "zmssd_evals_per_frame": round(zm, 1), "keyframes_added_per_stream": kf_adds,
                        "ba_trials_per_stream": ba_trials, "streams_tracking_good": good, "setup_seconds": round(setup_s, 1)},

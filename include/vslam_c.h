@@ -122,6 +122,9 @@ int vslam_make_keyframe_rest(vslam_system* sys, double min_shi_tomasi_score);
 int vslam_thin_candidates(vslam_system* sys, int keyframe);
 /* Candidate::irLevelPos (packed x | y<<16) and dSTScore of one level, raster order; *n = count (may exceed cap). */
 int vslam_read_candidates(vslam_system* sys, int stream, int level, uint32_t* pos, double* score, int cap, int* n);
+/* grow_map = 1: Level::vCorners (packed x | y << 16, raster order) of a stored keyframe -- the epipolar search's target list.
+ * At most 16384 / 8192 / 4096 / 2048 corners per level are kept (a longer list is cut in raster order); *n = stored count. */
+int vslam_get_keyframe_corners(vslam_system* sys, int stream, int keyframe, int level, uint32_t* corners, int cap, int* n);
 /* use_sbi = 1: the SmallBlurryImage of the current frame (jni/SmallBlurryImage.cc:20-55: (w/16) x (h/16) u8 image and its
  * zero-mean blurred fp32 template) and rot8 = { mv6SBIRot[6] (jni/Tracker.cc:885-893), final ESM score, 0 }. */
 int vslam_read_sbi(vslam_system* sys, int stream, uint8_t* small_img, float* tmpl, double rot8[8]);

@@ -250,6 +250,11 @@ class OracleSystem:
         self.L.orc_sys_get_state(self.h, C.byref(s))
         return s
 
+    def grow_log(self, cap=65536):
+        out = np.zeros((cap, 3), np.int32)
+        n = self.L.orc_sys_get_grow_log(self.h, _p(out), cap)
+        return out[:n]
+
     def point_tracks(self):
         n = self.state().n_points
         found, searched, level, subpix = (np.zeros(n, np.int32) for _ in range(4))

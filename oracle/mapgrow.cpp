@@ -119,6 +119,8 @@ static V3 unit_ray(const Camera& cam, double ix, double iy) {
 bool System::AddPointEpipolar(int ksrc, int ktgt, int nLevel, int nCandidate) {
   // :525-703
   KeyFrame& kSrc = *kfs[ksrc]; KeyFrame& kTarget = *kfs[ktgt];
+  grow_log.push_back(nLevel); grow_log.push_back((int)kSrc.cand[nLevel][nCandidate]); grow_log.push_back(0);
+  int& why = grow_log.back();
   const int nLevelScale = level_scale(nLevel);
   const uint32_t cpos = kSrc.cand[nLevel][nCandidate];
   const double irLevelPos[2] = {(double)(cpos & 0xFFFF), (double)(cpos >> 16)};
@@ -132,8 +134,8 @@ bool System::AddPointEpipolar(int ksrc, int ktgt, int nLevel, int nCandidate) {
   const V3 v3CamCenter_TC = xform(kTarget.pose, v3(srcInv.t[0], srcInv.t[1], srcInv.t[2]));
   V3 v3RayStart_TC, v3RayEnd_TC;
   for (int i = 0; i < 3; i++) { v3RayStart_TC[i] = v3CamCenter_TC[i] + dStartDepth * v3LineDirn_TC[i]; v3RayEnd_TC[i] = v3CamCenter_TC[i] + dEndDepth * v3LineDirn_TC[i]; }
-  if (v3RayEnd_TC[2] <= v3RayStart_TC[2]) return false;
-  if (v3RayEnd_TC[2] <= 0.0) return false;
+  if (v3RayEnd_TC[2] <= v3RayStart_TC[2]) { why = 1; return false; }
+  if (v3RayEnd_TC[2] <= 0.0) { why = 1; return false; }
   if (v3RayStart_TC[2] <= 0.0) {
     const double f = 0.001 - v3RayStart_TC[2] / v3LineDirn_TC[2];
     for (int i = 0; i < 3; i++) v3RayStart_TC[i] += v3LineDirn_TC[i] * f;
@@ -141,11 +143,11 @@ bool System::AddPointEpipolar(int ksrc, int ktgt, int nLevel, int nCandidate) {
   const double v2A[2] = {v3RayStart_TC[0] / v3RayStart_TC[2], v3RayStart_TC[1] / v3RayStart_TC[2]};
   const double v2B[2] = {v3RayEnd_TC[0] / v3RayEnd_TC[2], v3RayEnd_TC[1] / v3RayEnd_TC[2]};
   double along[2] = {v2A[0] - v2B[0], v2A[1] - v2B[1]};
-  if (along[0] * along[0] + along[1] * along[1] < 0.00000001) return false;
+  if (along[0] * along[0] + along[1] * along[1] < 0.00000001) { why = 2; return false; }
   { const double n = sqrt(along[0] * along[0] + along[1] * along[1]); along[0] /= n; along[1] /= n; }
   const double normal[2] = {along[1], -along[0]};
   const double dNormDist = v2A[0] * normal[0] + v2A[1] * normal[1];
-  if (fabs(dNormDist) > camera.largest_radius) return false;
+  if (fabs(dNormDist) > camera.largest_radius) { why = 3; return false; }
   double dMinLen = std::min(along[0] * v2A[0] + along[1] * v2A[1], along[0] * v2B[0] + along[1] * v2B[1]) - 0.05;
   double dMaxLen = std::max(along[0] * v2A[0] + along[1] * v2A[1], along[0] * v2B[0] + along[1] * v2B[1]) + 0.05;
   if (dMinLen < -2.0) dMinLen = -2.0;
@@ -157,7 +159,7 @@ bool System::AddPointEpipolar(int ksrc, int ktgt, int nLevel, int nCandidate) {
   f.P = p.patch_size; f.max_ssd = 500 * p.patch_size * p.patch_size;   // jni/PatchFinder.cc:19-20
   f.level = nLevel;                                                    // MakeTemplateCoarseNoWarp :130-142
   const int a = (int)irLevelPos[0], b = (int)irLevelPos[1], bord = f.P / 2 + 1;
-  if (!(a >= bord && b >= bord && a < kSrc.w[nLevel] - bord && b < kSrc.h[nLevel] - bord)) return false;   // TemplateBad
+  if (!(a >= bord && b >= bord && a < kSrc.w[nLevel] - bord && b < kSrc.h[nLevel] - bord)) { why = 4; return false; }   // TemplateBad
   f.tmpl.resize((size_t)f.P * f.P);
   for (int y = 0; y < f.P; y++) for (int x = 0; x < f.P; x++) f.tmpl[(size_t)y * f.P + x] = kSrc.im[nLevel][(size_t)(b - f.P / 2 + y) * kSrc.w[nLevel] + (a - f.P / 2 + x)];
   f.tsum = 0; f.tsumsq = 0;
@@ -180,13 +182,13 @@ bool System::AddPointEpipolar(int ksrc, int ktgt, int nLevel, int nCandidate) {
     const int nZMSSD = finder_zmssd(f, kTarget.im[nLevel].data(), kTarget.w[nLevel], kTarget.h[nLevel], kTarget.w[nLevel], cx, cy);
     if (nZMSSD < nBestZMSSD) { nBest = (int)i; nBestZMSSD = nZMSSD; }
   }
-  if (nBest == -1) return false;
+  if (nBest == -1) { why = 5; return false; }
 
   f.coarse[0] = 0; f.coarse[1] = 0;
   finder_make_subpix(f);
   f.subpix[0] = level_zero_pos((double)(vIR[nBest] & 0xFFFF), nLevel);   // SetSubPixPos :661
   f.subpix[1] = level_zero_pos((double)(vIR[nBest] >> 16), nLevel);
-  if (!finder_iterate_subpix_to_convergence(f, kTarget, 10)) return false;
+  if (!finder_iterate_subpix_to_convergence(f, kTarget, 10)) { why = 6; return false; }
 
   double uA[2], uB[2];
   camera.unproject(v2RootPos[0], v2RootPos[1], uA);
@@ -230,4 +232,11 @@ extern "C" void orc_reproject_point(const double AfromB12[12], const double v2A[
   for (int i = 0; i < 3; i++) T.t[i] = AfromB12[9 + i];
   const orc::V3 r = orc::reproject_point(T, v2A, v2B);
   for (int i = 0; i < 3; i++) out3[i] = r[i];
+}
+
+extern "C" int orc_sys_get_grow_log(void* sys, int* out3, int cap) {
+  orc::System* S = (orc::System*)sys;
+  const int n = (int)S->grow_log.size() / 3;
+  for (int i = 0; i < n && i < cap; i++) for (int k = 0; k < 3; k++) out3[3 * i + k] = S->grow_log[3 * i + k];
+  return n;
 }

@@ -123,6 +123,8 @@ int orc_sys_get_points(void* sys, double* pos3, int* bad, int* n_in, int* n_out,
 void orc_sys_get_keyframe_pose(void* sys, int kf, double pose12[12]);
 int orc_sys_get_keyframe_meas(void* sys, int kf, int* pt, int* level, double* root, int* source, int cap);
 int orc_sys_get_template(void* sys, int pt, uint8_t* tmpl, int* sum, int* sumsq, int* bad);
+/* every AddPointEpipolar call so far: (level, packed candidate position, stage at which it gave up; 0 = point added) */
+int orc_sys_get_grow_log(void* sys, int* out3, int cap);
 int orc_sys_bundle_adjust_recent(void* sys);   /* MapMaker::BundleAdjustRecent, jni/MapMaker.cc:801-851 */
 int orc_sys_bundle_adjust_all(void* sys);      /* MapMaker::BundleAdjustAll,    jni/MapMaker.cc:776-798 */
 

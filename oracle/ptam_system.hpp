@@ -150,6 +150,7 @@ struct System {
   void ThinCandidates(KeyFrame& k, int level); int ClosestKeyFrame(int kidx);
   bool AddPointEpipolar(int ksrc, int ktgt, int level, int candidate); int AddSomeMapPoints(int level);
   int n_points_added = 0;
+  std::vector<int> grow_log;   // per AddPointEpipolar call: level, packed candidate position, stage at which it gave up (0 = point added)
   int BundleAdjust(const std::vector<int>& adj, const std::vector<int>& fixed, const std::vector<int>& points, bool recent);
   // a finished Bundle whose results are still to be written to the map (asynchronous map-maker model, see mapmaker.cpp)
   struct PendingBA { Bundle b; std::vector<int> id_view, id_point; bool recent = true; int accepted = 0; int countdown = -1; };

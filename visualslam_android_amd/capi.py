@@ -64,6 +64,7 @@ SYMBOLS = {
     "vslam_read_corners": (_i, [_sys, _i, _i, _vp, _i, _ip]),
     "vslam_read_row_lut": (_i, [_sys, _i, _i, _vp]),
     "vslam_read_max_corners": (_i, [_sys, _i, _i, _vp, _vp, _i, _ip]),
+    "vslam_get_keyframe_corners": (_i, [_sys, _i, _i, _i, _vp, _i, _ip]),
     "vslam_read_sbi": (_i, [_sys, _i, _vp, _vp, _vp]),
     "vslam_make_keyframe_rest": (_i, [_sys, C.c_double]),
     "vslam_thin_candidates": (_i, [_sys, _i]),
@@ -331,6 +332,11 @@ class System:
         pos = np.zeros((n, 3)); bad, nin, nout = (np.zeros(n, np.int32) for _ in range(3))
         _check(self.lib.vslam_get_points(self.h, stream, pos.ctypes.data, bad.ctypes.data, nin.ctypes.data, nout.ctypes.data, n))
         return {"pos": pos, "bad": bad, "n_in": nin, "n_out": nout}
+
+    def keyframe_corners(self, stream, kf, level, cap=16384):
+        out = np.zeros(cap, np.uint32); n = C.c_int(0)
+        _check(self.lib.vslam_get_keyframe_corners(self.h, stream, kf, level, out.ctypes.data, cap, C.byref(n)))
+        return out[:min(n.value, cap)].copy()
 
     def read_sbi(self, stream):
         hs, ws = self.params.height // 16, self.params.width // 16

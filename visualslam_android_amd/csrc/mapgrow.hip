@@ -16,6 +16,8 @@
 
 struct GrowArgs {
   const uint32_t* cand[NLEV]; const int* ncand; int cap[NLEV];     // current frame's candidate lists [S][cap], counts [S][NLEV]
+  double* cand_score[NLEV];   // a candidate AddPointEpipolar rejects gets its score replaced by -(stage at which it gave up): 1 ray, 2 line,
+                              // 3 radius, 4 template border, 5 no corner on the line, 6 sub-pixel, 7 map full (vslam_read_candidates)
   int w[NLEV], h[NLEV], kf_pitch[NLEV]; size_t kf_stride[NLEV];
 };
 
@@ -130,6 +132,7 @@ __global__ __launch_bounds__(GROW_THREADS) void k_epipolar(MapDev m, TrackParams
   for (int c0 = 0; c0 < ncand; c0 += GROW_WAVES) {
     const int ci = c0 + wave;
     bool alive = ci < ncand;
+    int why = 0;
     if (lane == 0) res[wave].ok = 0;
     double irx = 0, iry = 0, root0 = 0, root1 = 0, along0 = 0, along1 = 0, normal0 = 0, normal1 = 0, dNormDist = 0, dMinLen = 0, dMaxLen = 0;
     int ca = 0, cb = 0;
@@ -148,19 +151,19 @@ __global__ __launch_bounds__(GROW_THREADS) void k_epipolar(MapDev m, TrackParams
       pose_xform(Ttgt, srcInv.t, centre);
       double rs[3], re[3];
       for (int i = 0; i < 3; i++) { rs[i] = centre[i] + dStartDepth * dirn[i]; re[i] = centre[i] + dEndDepth * dirn[i]; }
-      if (re[2] <= rs[2]) alive = false;
-      if (re[2] <= 0.0) alive = false;
+      if (re[2] <= rs[2]) { alive = false; why = 1; }
+      if (re[2] <= 0.0) { alive = false; why = 1; }
       if (alive) {
         if (rs[2] <= 0.0) { const double f = 0.001 - rs[2] / dirn[2]; for (int i = 0; i < 3; i++) rs[i] += dirn[i] * f; }
         const double v2A[2] = {rs[0] / rs[2], rs[1] / rs[2]}, v2B[2] = {re[0] / re[2], re[1] / re[2]};
         along0 = v2A[0] - v2B[0]; along1 = v2A[1] - v2B[1];
-        if (along0 * along0 + along1 * along1 < 0.00000001) alive = false;
+        if (along0 * along0 + along1 * along1 < 0.00000001) { alive = false; why = 2; }
         else {
           const double n = sqrt(along0 * along0 + along1 * along1);
           along0 /= n; along1 /= n;
           normal0 = along1; normal1 = -along0;
           dNormDist = v2A[0] * normal0 + v2A[1] * normal1;
-          if (fabs(dNormDist) > tp.cam.largest_radius) alive = false;
+          if (fabs(dNormDist) > tp.cam.largest_radius) { alive = false; why = 3; }
           const double la = along0 * v2A[0] + along1 * v2A[1], lb = along0 * v2B[0] + along1 * v2B[1];
           dMinLen = (la < lb ? la : lb) - 0.05; dMaxLen = (la > lb ? la : lb) + 0.05;
           if (dMinLen < -2.0) dMinLen = -2.0;
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(GROW_THREADS) void k_epipolar(MapDev m, TrackParams
       // ---- MakeTemplateCoarseNoWarp (jni/PatchFinder.cc:130-142) + MakeTemplateSums ----
       ca = (int)irx; cb = (int)iry;
       const int bord = HALF + 1;
-      if (!(ca >= bord && cb >= bord && ca < wl - bord && cb < hl - bord)) alive = false;
+      if (!(ca >= bord && cb >= bord && ca < wl - bord && cb < hl - bord)) { if (alive) why = 4; alive = false; }
     }
     int tsum = 0, tsumsq = 0;
     if (alive) {
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(GROW_THREADS) void k_epipolar(MapDev m, TrackParams
           if (ssd < nBestZMSSD) { nBest = base + k; nBestZMSSD = ssd; }
         }
       }
-      if (nBest == -1) alive = false;
+      if (nBest == -1) { alive = false; why = 5; }
     }
     // ---- MakeSubPixTemplate + SetSubPixPos + IterateSubPixToConvergence(kTarget, 10), :658-664 ----
     double sub0 = 0, sub1 = 0;
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(GROW_THREADS) void k_epipolar(MapDev m, TrackParams
         sub0 -= u0 * nLevelScale; sub1 -= u1 * nLevelScale; meanDiff -= u2;
         if (u0 * u0 + u1 * u1 < 0.03 * 0.03) { converged = true; break; }
       }
-      if (!converged) alive = false;
+      if (!converged) { alive = false; why = 6; }
     }
     // ---- triangulation and the new point's patch vectors, :666-702 (lane 0) ----
     if (alive && lane == 0) {
@@ -296,13 +299,14 @@ __global__ __launch_bounds__(GROW_THREADS) void k_epipolar(MapDev m, TrackParams
       r.root[0] = root0; r.root[1] = root1; r.sub[0] = sub0; r.sub[1] = sub1; r.irx = ca; r.iry = cb;
       r.ok = 1;
     }
+    if (lane == 0 && ci < ncand && why) a.cand_score[nLevel][(size_t)s * a.cap[nLevel] + ci] = -(double)why;
     __syncthreads();
     // ---- ordered commit: mMap.vpPoints.push_back + the two measurements, :692-701 ----
     if (threadIdx.x == 0) {
       for (int wv = 0; wv < GROW_WAVES; wv++) {
         if (!res[wv].ok) continue;
         const int pid = st->n_points;
-        if (pid >= P) break;                                             // map capacity: stop growing
+        if (pid >= P) { if (c0 + wv < ncand) a.cand_score[nLevel][(size_t)s * a.cap[nLevel] + c0 + wv] = -7.0; continue; }   // map capacity: stop growing
         const EpiResult& r = res[wv];
         MapPointDev mp;
         for (int i = 0; i < 3; i++) { mp.pos[i] = r.pos[i]; mp.right[i] = r.right[i]; mp.down[i] = r.down[i]; }
@@ -360,7 +364,7 @@ int grow_on_keyframe(vslam_system* sys) {
   if (r) return r;
   GrowArgs a;
   for (int l = 0; l < NLEV; l++) {
-    a.cand[l] = sys->cand[l]; a.cap[l] = g[l].cap; a.w[l] = g[l].w; a.h[l] = g[l].h; a.kf_pitch[l] = g[l].pitch;
+    a.cand[l] = sys->cand[l]; a.cand_score[l] = sys->cand_score[l]; a.cap[l] = g[l].cap; a.w[l] = g[l].w; a.h[l] = g[l].h; a.kf_pitch[l] = g[l].pitch;
     a.kf_stride[l] = (size_t)g[l].pitch * g[l].h;
   }
   a.ncand = sys->ncand;
@@ -372,5 +376,18 @@ int grow_on_keyframe(vslam_system* sys) {
     else hipLaunchKernelGGL(k_epipolar<11>, dim3(sys->S), dim3(GROW_THREADS), 0, sys->stream, sys->map, sys->tp, a, order[i]);
   }
   HIPCHK(hipGetLastError());
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_get_keyframe_corners(vslam_system* sys, int stream, int keyframe, int level, uint32_t* corners, int cap, int* n) {
+  if (!sys || stream < 0 || stream >= sys->S || keyframe < 0 || keyframe >= sys->p.max_keyframes || level < 0 || level >= NLEV) { vslam_set_error("get_keyframe_corners: bad argument"); return VSLAM_E_INVALID; }
+  if (!sys->p.grow_map) { vslam_set_error("get_keyframe_corners: keyframe corner lists are only kept with grow_map"); return VSLAM_E_STATE; }
+  HIPCHK(hipStreamSynchronize(sys->stream));
+  const size_t slot = (size_t)stream * sys->p.max_keyframes + keyframe;
+  int cnt = 0;
+  HIPCHK(hipMemcpy(&cnt, sys->map.kf_ncorners + slot * NLEV + level, sizeof(int), hipMemcpyDeviceToHost));
+  if (n) *n = cnt;
+  const int m = cnt < cap ? cnt : cap;
+  if (corners && m > 0) HIPCHK(hipMemcpy(corners, sys->map.kf_corners[level] + slot * sys->tp.kcap[level], (size_t)m * 4, hipMemcpyDeviceToHost));
   return VSLAM_OK;
 }

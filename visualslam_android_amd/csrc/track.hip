@@ -950,7 +950,7 @@ void trk_fill_params(const vslam_params& p, TrackParams& t) {
     const double d0 = a[0] - b[0], d1 = a[1] - b[1];
     t.one_pixel_dist = sqrt(d0 * d0 + d1 * d1) / sqrt(2.0);
   }
-  const int kcap_max[NLEV] = {16384, 8192, 2048, 512};               // stored corner list of a keyframe (grow_map): see DESIGN.md
+  const int kcap_max[NLEV] = {16384, 8192, 4096, 2048};               // stored corner list of a keyframe (grow_map): see DESIGN.md
   for (int l = 0; l < NLEV; l++) t.kcap[l] = p.max_corners[l] < kcap_max[l] ? p.max_corners[l] : kcap_max[l];
 
 }
