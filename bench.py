@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--use-sbi", type=int, default=int(os.environ.get("VSLAM_BENCH_USE_SBI", 0)),
                     help="vslam_params.use_sbi: 1 = SmallBlurryImage rotation prior in the motion model (the reference's gvnUseSBI)")
     ap.add_argument("--grow-map", type=int, default=int(os.environ.get("VSLAM_BENCH_GROW_MAP", 0)),
-                    help="vslam_params.grow_map: 1 = every new keyframe also adds map points by epipolar search (AddSomeMapPoints)")
+                    help="vslam_params.grow_map bit flags: 1 = AddSomeMapPoints (epipolar search), 2 = ReFindInSingleKeyFrame, 3 = both (the reference)")
     ap.add_argument("--no-events", action="store_true", help="skip the per-stage HIP events in the timed region")
     args = ap.parse_args()
     rank, world, local_rank = dist_env()

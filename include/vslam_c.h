@@ -76,9 +76,12 @@ typedef struct vslam_params {
                                       map-maker); D > 0: it runs on its own HIP stream beside the next frames and its results
                                       are applied at the start of the D-th following frame (the reference's map-maker is a
                                       second thread whose results also arrive "a few frames later", jni/MapMaker.cc:80-123) */
-  int grow_map;                    /* 1: every new keyframe also runs MakeKeyFrame_Rest's candidates, ThinCandidates and
-                                      AddSomeMapPoints (epipolar search + triangulation, jni/MapMaker.cc:498-501, 525-703), so the
-                                      map gains points; 0 (default): the map only gains keyframes and measurements */
+  int grow_map;                    /* bit flags, the rest of MapMaker::AddKeyFrameFromTopOfQueue (jni/MapMaker.cc:481-506) on every new keyframe:
+                                      1: MakeKeyFrame_Rest's candidates, ThinCandidates and AddSomeMapPoints (epipolar search +
+                                         triangulation, :498-501, 525-703), so the map gains points;
+                                      2: ReFindInSingleKeyFrame (:497, 967-1056), so the keyframe also gains measurements of points the
+                                         tracker did not measure in it;
+                                      3: both, the reference's behaviour; 0 (default): only the tracker's measurements are stored */
 } vslam_params;
 
 const char* vslam_last_error(void);

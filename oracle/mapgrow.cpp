@@ -5,8 +5,8 @@
 //   MapMaker::ReprojectPoint                      jni/MapMaker.cc:174-200
 //   MapPoint::RefreshPixelVectors                 jni/MapPoint.cc:4-29
 //   PatchFinder::MakeTemplateCoarseNoWarp         jni/PatchFinder.cc:130-142
-// Not built (documented in DESIGN.md): ReFindInSingleKeyFrame / ReFindNewlyMade / ReFindFromFailureQueue -- a new point
-// starts with its two stereo measurements and gains more when the tracker measures it in later keyframes.
+//   MapMaker::ReFind_Common / ReFindInSingleKeyFrame  jni/MapMaker.cc:967-1056  (grow_map bit 1)
+// Not built (documented in DESIGN.md): ReFindNewlyMade / ReFindFromFailureQueue (run()'s lower-priority jobs).
 // Third-party arithmetic restated (parity unpinned): Eigen::JacobiSVD of the 4x4 triangulation matrix -> smallest
 // eigenvector of A^T A by cyclic Jacobi rotations (the sign of the vector cancels in the projective division).
 #include "ptam_system.hpp"
@@ -211,6 +211,47 @@ bool System::AddPointEpipolar(int ksrc, int ktgt, int nLevel, int nCandidate) {
   kTarget.meas[pid] = m;
   pNew->meas_kfs.insert(ksrc); pNew->meas_kfs.insert(ktgt);
   return true;
+}
+
+// MapMaker::ReFind_Common, jni/MapMaker.cc:967-1036.  The reference's function-static PatchFinder is `refinder`.
+bool System::ReFind_Common(int kidx, int pi) {
+  KeyFrame& k = *kfs[kidx];
+  MapPoint& pt = *pts[pi];
+  if (pt.meas_kfs.count(kidx) || pt.never_retry.count(kidx)) return false;                       // :971-973
+  const V3 v3Cam = xform(k.pose, pt.pos);
+  if (v3Cam[2] < 0.001) { pt.never_retry.insert(kidx); return false; }                            // :979-982
+  const double ip0 = v3Cam[0] / v3Cam[2], ip1 = v3Cam[1] / v3Cam[2];
+  if (ip0 * ip0 + ip1 * ip1 > camera.largest_radius * camera.largest_radius) { pt.never_retry.insert(kidx); return false; }
+  const Camera::Proj pr = camera.project(ip0, ip1);
+  if (pr.invalid) { pt.never_retry.insert(kidx); return false; }
+  if (pr.im[0] < 0 || pr.im[1] < 0 || pr.im[0] > k.w[0] || pr.im[1] > k.h[0]) { pt.never_retry.insert(kidx); return false; }
+  double d[4];
+  camera.derivs(pr, d);
+  Finder& f = refinder;
+  f.P = p.patch_size; f.max_ssd = p.patch_size * p.patch_size * 500;
+  f.have_last = refind_last_point == pi;                                                          // &p == mpLastTemplateMapPoint
+  finder_calc_level_and_warp(f, pt, k.pose, d);                                                   // MakeTemplateCoarse, jni/PatchFinder.cc:72-76:
+  finder_make_template(f, pt, *kfs[pt.src_kf]);              // a regenerated template's own verdict replaces the bad-scale flag (:112-117)
+  refind_last_point = pi;
+  if (f.bad) { pt.never_retry.insert(kidx); return false; }                                       // :1004-1007
+  if (!finder_find_coarse(f, pr.im, k, 4)) { pt.never_retry.insert(kidx); return false; }         // :1009-1013
+  Measurement m;
+  m.level = f.level; m.source = SRC_REFIND;
+  if (f.level > 0) {
+    finder_make_subpix(f);
+    finder_iterate_subpix_to_convergence(f, k, 8);                                               // result not looked at, :1022
+    m.root[0] = f.subpix[0]; m.root[1] = f.subpix[1]; m.subpix = true;
+  } else { m.root[0] = f.coarse[0]; m.root[1] = f.coarse[1]; m.subpix = false; }
+  k.meas[pi] = m;
+  pt.meas_kfs.insert(kidx);
+  return true;
+}
+
+// MapMaker::ReFindInSingleKeyFrame, jni/MapMaker.cc:1040-1056.  Bad points stay in the arrays here (HandleBadPoints) and are skipped.
+int System::ReFindInSingleKeyFrame(int kidx) {
+  int n = 0;
+  for (int i = 0; i < (int)pts.size(); i++) if (!pts[i]->bad && ReFind_Common(kidx, i)) n++;
+  return n;
 }
 
 int System::AddSomeMapPoints(int nLevel) {

@@ -3,7 +3,7 @@
 //  BundleAdjustAll :776-798, BundleAdjustRecent :801-851, BundleAdjust :854-960).
 // The reference orders its std::set<KeyFrame*> / std::map<MapPoint*,...> by heap address; the build defines the
 // order as insertion index.  The map-maker runs synchronously (the reference's thread is disabled,
-// jni/MapMaker.cc:56).  Map growth (ReFind*, AddSomeMapPoints) is a "next" row and not run here.
+// jni/MapMaker.cc:56).  Map growth (ReFindInSingleKeyFrame, AddSomeMapPoints) is in mapgrow.cpp, behind Params::grow_map.
 #include "ptam_system.hpp"
 
 namespace orc {
@@ -31,8 +31,8 @@ void System::AddKeyFrame() {
   kfs.push_back(pK);
   const int kidx = (int)kfs.size() - 1;
   for (auto& it : pK->meas) { pts[it.first]->meas_kfs.insert(kidx); it.second.source = SRC_TRACKER; }   // :491-494
-  // ReFindInSingleKeyFrame (:497): not built.  AddSomeMapPoints (:498-501) when the map is allowed to grow:
-  if (p.grow_map) {
+  if (p.grow_map & 2) n_refound = ReFindInSingleKeyFrame(kidx);                                            // :497
+  if (p.grow_map & 1) {                                                                                   // AddSomeMapPoints, :498-501
     make_keyframe_rest_candidates(*pK, 70.0);                                                              // rest of MakeKeyFrame_Rest, :488
     n_points_added = AddSomeMapPoints(3) + AddSomeMapPoints(0) + AddSomeMapPoints(1) + AddSomeMapPoints(2);
   }

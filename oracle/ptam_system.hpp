@@ -74,7 +74,7 @@ struct Params {
   double cam[5]; int quirks;
   int ba_delay_frames = 0;   // 0: results applied at once; D > 0: applied at the start of the D-th following frame
   int use_sbi = 0;           // gvnUseSBI, jni/Tracker.cc:88 (reference: 1)
-  int grow_map = 0;          // AddKeyFrameFromTopOfQueue's AddSomeMapPoints (jni/MapMaker.cc:498-501); 0: the map only gains measurements
+  int grow_map = 0;          // bit 0: AddSomeMapPoints (jni/MapMaker.cc:498-501), bit 1: ReFindInSingleKeyFrame (:497); 0: only the tracker's measurements
 };
 
 // SmallBlurryImage (jni/SmallBlurryImage.h): mimSmall, mimTemplate (zero-mean, blurred), mimImageJacs (x, y interleaved)
@@ -149,7 +149,9 @@ struct System {
   // map growth (mapgrow.cpp)
   void ThinCandidates(KeyFrame& k, int level); int ClosestKeyFrame(int kidx);
   bool AddPointEpipolar(int ksrc, int ktgt, int level, int candidate); int AddSomeMapPoints(int level);
-  int n_points_added = 0;
+  bool ReFind_Common(int kidx, int pi); int ReFindInSingleKeyFrame(int kidx);
+  Finder refinder; int refind_last_point = -1;     // ReFind_Common's static PatchFinder and its mpLastTemplateMapPoint
+  int n_points_added = 0, n_refound = 0;
   std::vector<int> grow_log;   // per AddPointEpipolar call: level, packed candidate position, stage at which it gave up (0 = point added)
   int BundleAdjust(const std::vector<int>& adj, const std::vector<int>& fixed, const std::vector<int>& points, bool recent);
   // a finished Bundle whose results are still to be written to the map (asynchronous map-maker model, see mapmaker.cpp)

@@ -17,7 +17,8 @@ class Drift:
     """Template pixels are trunc(bilinear sample) (jni/vision/ImageHandler.cpp:12-19): on a flat neighbourhood the
     exact value is an integer and a 1-ulp difference between the device libm and glibc (atan/tan/sin/cos in the camera
     model and SE3 exp) flips it by one grey level.  Observed rate: about 1 template in 10^4.  Such a flip changes one
-    ZMSSD / sub-pixel result slightly; from then on the two runs are compared with the floating-point bars only."""
+    ZMSSD / sub-pixel result slightly (rarely: which of two neighbouring corners wins); from then on the two runs are
+    compared with the floating-point bars only."""
     def __init__(self):
         self.seen = False
 
@@ -31,12 +32,17 @@ def compare_frame(o, g, s, tag, drift=None, tight=None):
     nf = max(1, int(f.sum()))
     mism = int((to["found"] != tg["found"]).sum()) + (int((np.abs(to["vfound"][f] - tg["vfound"][f]).max(1) > 1e-9).sum()) if f.any() else 0)
     assert mism <= max(2, 0.003 * nf), (tag, mism)
-    if mism:
-        drift.seen = True
     d = pose_err(so.pose, sg.pose)
-    assert d < POSE_TOL, (tag, d)
     assert (so.quality, so.did_coarse, so.kf_added, so.n_keyframes) == (sg.quality, sg.did_coarse, sg.kf_added, sg.n_keyframes), tag
     assert list(so.attempted) == list(sg.attempted), tag
+    if mism:
+        # the frame in which a flipped template pixel makes another corner win for one or two patches (observed: a whole-pixel
+        # move of 1 measurement in 905 at 320x240 -> 1.4e-4 in the pose): the two pose solvers no longer see the same
+        # measurements, so this frame is held to 10x the bar and the run is compared with the drift bars from here on
+        drift.seen = True
+        assert d < 10 * POSE_TOL, (tag, d)
+        return
+    assert d < POSE_TOL, (tag, d)
     if drift.seen:
         assert d < 1e-5 and np.abs(np.array(so.found[:]) - np.array(sg.found[:])).max() <= 3, (tag, d)
         assert f.sum() == 0 or np.abs(to["vfound"][f] - tg["vfound"][f]).max() < 0.1, tag
@@ -282,35 +288,50 @@ def test_small_blurry_image_rotation_prior():
     g.close()
 
 
-@pytest.mark.parametrize("patch", [8, 11])
-def test_map_growth_matches_oracle(patch):
-    """grow_map = 1: every new keyframe runs MakeKeyFrame_Rest's candidates, ThinCandidates and AddSomeMapPoints
-    (epipolar search + triangulation, jni/MapMaker.cc:393-437, 525-703).  The number of points added, their positions,
-    patch vectors and stereo measurements, and the tracking that then uses them, against the oracle configured alike."""
+@pytest.mark.parametrize("patch,grow", [(8, 1), (11, 1), (8, 2), (8, 3), (11, 3)])
+def test_map_growth_matches_oracle(patch, grow):
+    """grow_map bit 0: every new keyframe runs MakeKeyFrame_Rest's candidates, ThinCandidates and AddSomeMapPoints
+    (epipolar search + triangulation, jni/MapMaker.cc:393-437, 525-703); bit 1: ReFindInSingleKeyFrame (:497, 967-1056);
+    3 is the reference's AddKeyFrameFromTopOfQueue.  The number of points added, their positions, the new keyframe's
+    measurement row (tracker, re-found, root and epipolar entries), and the tracking that then uses them, against the oracle."""
     w, h = 320, 240
     f, m, frames = make_scene(w, h, seed=77, n_frames=46, per_level=(120, 50, 20, 8))
     n0 = len(m["points"])
-    vp = capi.default_params(w, h, 2, patch_size=patch, grow_map=1)
+    vp = capi.default_params(w, h, 2, patch_size=patch, grow_map=grow)
     g = capi.System(vp)
     for s in range(2):
         g.load_map(s, m); g.set_pose(s, f.pose(-1))
-    o = make_oracle(capi.default_params(w, h, 1, patch_size=patch, grow_map=1), m, f.pose(-1))
+    o = make_oracle(capi.default_params(w, h, 1, patch_size=patch, grow_map=grow), m, f.pose(-1))
     drift = Drift()
     grew = 0
+    refound = 0
     for t in range(46):
         g.track_frame(np.stack([frames[t]] * 2)); o.track_frame(frames[t])
         so, sg = o.state(), g.state(1)
         assert so.n_points == sg.n_points == g.state(0).n_points, (t, so.n_points, sg.n_points)
         if so.kf_added:
             grew += 1
-            po, pg = o.points(), g.points(1)
-            n1 = so.n_points
-            assert n1 > n0 or grew > 1
-            assert np.abs(po["pos"][n0:n1] - pg["pos"][n0:n1]).max() < 1e-6, t      # triangulated through a 4x4 Jacobi eigen-solve
             k_new = so.n_keyframes - 1
             mo, mg = o.keyframe_meas(k_new), g.keyframe_meas(1, k_new)
             assert np.array_equal(mo["pt"], mg["pt"]) and np.array_equal(mo["source"], mg["source"]) and np.array_equal(mo["level"], mg["level"]), t
-            assert np.abs(mo["root"] - mg["root"]).max() < 1e-7, t
+            dr = np.abs(mo["root"] - mg["root"]).max(1)
+            off = dr > 1e-7
+            if off.any():
+                # ReFind_Common warps every template afresh and keeps the sub-pixel result whether or not it converged: a
+                # one-grey-level template flip (see Drift) moves a level-3 result by ~0.01 level pixels = ~0.1 px at level zero
+                assert off.sum() <= 3 and dr.max() < 0.2 and (mo["level"][off] > 0).all(), (t, dr.max())
+                assert drift.seen or (mo["source"][off] == 1).all(), t
+                drift.seen = True
+            refound += int((mo["source"] == 1).sum())
+            po, pg = o.points(), g.points(1)
+            n1 = so.n_points
+            if grow & 1:
+                assert n1 > n0 or grew > 1
+                assert np.abs(po["pos"][n0:n1] - pg["pos"][n0:n1]).max() < (1e-3 if drift.seen else 1e-6), t      # triangulated through a 4x4 Jacobi eigen-solve
+            else:
+                assert n1 == n0
         compare_frame(o, g, 1, "grow frame %d" % t, drift, tight=1e-6)
-    assert grew >= 3 and o.state().n_points > n0 + 30
+    assert grew >= 3
+    assert (o.state().n_points > n0 + 30) == bool(grow & 1)
+    assert (refound > 50) == bool(grow & 2)
     g.close()

@@ -72,3 +72,26 @@ def test_map_growth_adds_points_on_the_scene_plane():
     assert P["n_in"][n0:].sum() > 3 * len(new) > P["n_out"][n0:].sum()   # the tracker uses them as inliers
     kf_new = o.keyframe_meas(o.state().n_keyframes - 1)
     assert (kf_new["source"] == 2).sum() > 0                   # SRC_ROOT measurements of the points this keyframe created
+
+
+def test_refind_in_single_keyframe_adds_measurements():
+    """grow_map bit 1 (ReFindInSingleKeyFrame / ReFind_Common, jni/MapMaker.cc:967-1056): the new keyframe gains SRC_REFIND
+    measurements of points the tracker did not measure this frame (its 1000-point budget, PVS sampling), close to where the
+    keyframe's pose projects them, and never a second measurement of a point the tracker already measured."""
+    w, h = 320, 240
+    f, m, frames = make_scene(w, h, seed=77, n_frames=46, per_level=(120, 50, 20, 8))
+    o = make_oracle(capi.default_params(w, h, 1, grow_map=2), m, f.pose(-1))
+    o_plain = make_oracle(capi.default_params(w, h, 1), m, f.pose(-1))
+    refound = 0
+    for i in range(46):
+        o.track_frame(frames[i]); o_plain.track_frame(frames[i])
+        st = o.state()
+        assert st.quality == 2
+        if st.kf_added:
+            km = o.keyframe_meas(st.n_keyframes - 1)
+            assert len(np.unique(km["pt"])) == len(km["pt"])
+            refound += int((km["source"] == 1).sum())
+            assert set(km["source"].tolist()) <= {0, 1}
+    assert refound > 0
+    assert o.state().n_points == o_plain.state().n_points == len(m["points"])
+    assert pose_err(o.state().pose, f.pose(45)) < 6e-3

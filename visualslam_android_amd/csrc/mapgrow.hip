@@ -13,6 +13,7 @@
 
 #define GROW_THREADS 256
 #define GROW_WAVES (GROW_THREADS / 64)
+#define REFIND_BLOCKS 32
 
 struct GrowArgs {
   const uint32_t* cand[NLEV]; const int* ncand; int cap[NLEV];     // current frame's candidate lists [S][cap], counts [S][NLEV]
@@ -25,6 +26,75 @@ struct EpiResult { int ok; double pos[3], right[3], down[3], root[2], sub[2]; in
 
 DEVFN int wsum_i(int v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d); return v; }
 DEVFN double wsum_d(double v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d); return v; }
+
+// PatchFinder::ZMSSDAtPoint (jni/PatchFinder.cc:352-380) by one wavefront; the template lies in LDS
+template <int PS>
+DEVFN int wave_zmssd(const uint8_t* tmpl, const uint8_t* img, int ip, int wl, int hl, int cx, int cy, int tsum, int tsumsq, int max_ssd, int lane) {
+  constexpr int NPIX = PS * PS, HALF = PS / 2;
+  if (!(cx >= HALF && cy >= HALF && cx < wl - HALF && cy < hl - HALF)) return max_ssd + 1;
+  int sA = 0, sQ = 0, sX = 0;
+  for (int q = lane; q < NPIX; q += 64) {
+    const int y = q / PS, x = q - y * PS;
+    const int n = img[(size_t)(cy - HALF + y) * ip + (cx - HALF + x)], t = tmpl[q];
+    sA += n; sQ += n * n; sX += n * t;
+  }
+  sA = wsum_i(sA); sQ = wsum_i(sQ); sX = wsum_i(sX);
+  const int SA = tsum, SB = sA;
+  return ((2 * SA * SB - SA * SA - SB * SB) / NPIX + sQ + tsumsq - 2 * sX);
+}
+
+// MakeSubPixTemplate (jni/PatchFinder.cc:242-271) + IterateSubPixToConvergence (:273-350) by one wavefront, starting from
+// the level-zero position in sub0/sub1; these are left wherever the iteration stopped (ReFind_Common reads them regardless)
+template <int PS>
+DEVFN bool wave_subpix(const uint8_t* tmpl, const uint8_t* img, int ip, int wl, int hl, int nLevel, int max_its, int lane, double& sub0, double& sub1) {
+  constexpr int HALF = PS / 2, Q = PS - 2, NQL = (Q * Q + 63) / 64;
+  const int nLevelScale = 1 << nLevel;
+  double gx[NQL], gy[NQL];
+  double h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0;
+  for (int q = 0; q < NQL; q++) {
+    const int k = q * 64 + lane;
+    gx[q] = 0; gy[q] = 0;
+    if (k < Q * Q) {
+      const int x = k / Q + 1, y = k % Q + 1;
+      gx[q] = 0.5 * (tmpl[y * PS + x + 1] - tmpl[y * PS + x - 1]);
+      gy[q] = 0.5 * (tmpl[(y + 1) * PS + x] - tmpl[(y - 1) * PS + x]);
+      h00 += gx[q] * gx[q]; h01 += gx[q] * gy[q]; h02 += gx[q]; h11 += gy[q] * gy[q]; h12 += gy[q]; h22 += 1.0;
+    }
+  }
+  h00 = wsum_d(h00); h01 = wsum_d(h01); h02 = wsum_d(h02); h11 = wsum_d(h11); h12 = wsum_d(h12); h22 = wsum_d(h22);
+  const double H[9] = {h00, h01, h02, h01, h11, h12, h02, h12, h22};
+  double Hinv[9];
+  inv3(H, Hinv);
+  double meanDiff = 0.0;
+  for (int it = 0; it < max_its; it++) {
+    const double cx = level_n_pos(sub0, nLevel), cy = level_n_pos(sub1, nLevel);
+    const int xb = (int)(cx > 0.0 ? cx + 0.5 : cx - 0.5), yb = (int)(cy > 0.0 ? cy + 0.5 : cy - 0.5);
+    const int b = HALF + 1;
+    if (!(xb >= b && yb >= b && xb < wl - b && yb < hl - b)) return false;
+    const double bx = cx - HALF, by = cy - HALF;
+    const double dX = bx - floor(bx), dY = by - floor(by);
+    const float fTL = (float)((1.0 - dX) * (1.0 - dY)), fTR = (float)((dX) * (1.0 - dY));
+    const float fBL = (float)((1.0 - dX) * (dY)), fBR = (float)((dX) * (dY));
+    double a0 = 0, a1 = 0, a2 = 0;
+    for (int q = 0; q < NQL; q++) {
+      const int k = q * 64 + lane;
+      if (k < Q * Q) {
+        const int x = k / Q + 1, y = k % Q + 1;
+        const uint8_t* tl = img + (size_t)((int)by + y) * ip + (int)bx + x;
+        const float fPixel = fTL * tl[0] + fTR * tl[1] + fBL * tl[ip] + fBR * tl[ip + 1];
+        const double dDiff = (fPixel - (float)tmpl[y * PS + x]) + meanDiff;
+        a0 += dDiff * gx[q]; a1 += dDiff * gy[q]; a2 += dDiff;
+      }
+    }
+    a0 = wsum_d(a0); a1 = wsum_d(a1); a2 = wsum_d(a2);
+    const double u0 = Hinv[0] * a0 + Hinv[1] * a1 + Hinv[2] * a2;
+    const double u1 = Hinv[3] * a0 + Hinv[4] * a1 + Hinv[5] * a2;
+    const double u2 = Hinv[6] * a0 + Hinv[7] * a1 + Hinv[8] * a2;
+    sub0 -= u0 * nLevelScale; sub1 -= u1 * nLevelScale; meanDiff -= u2;
+    if (u0 * u0 + u1 * u1 < 0.03 * 0.03) return true;
+  }
+  return false;
+}
 
 // smallest-eigenvalue eigenvector of a symmetric 4x4 matrix: cyclic Jacobi, 16 sweeps (same sequence as the oracle)
 DEVFN void smallest_eigvec4(const double Sin[16], double out[4]) {
@@ -209,18 +279,7 @@ __global__ __launch_bounds__(GROW_THREADS) void k_epipolar(MapDev m, TrackParams
           bm &= bm - 1;
           const uint32_t c = __shfl(cv, k);
           const int cx = c & 0xFFFF, cy = c >> 16;
-          int ssd = tp.max_ssd + 1;
-          if (cx >= HALF && cy >= HALF && cx < wl - HALF && cy < hl - HALF) {   // ZMSSDAtPoint :352-380
-            int sA = 0, sQ = 0, sX = 0;
-            for (int q = lane; q < NPIX; q += 64) {
-              const int y = q / PS, x = q - y * PS;
-              const int n = img_tgt[(size_t)(cy - HALF + y) * ip + (cx - HALF + x)], t = tmpl[q];
-              sA += n; sQ += n * n; sX += n * t;
-            }
-            sA = wsum_i(sA); sQ = wsum_i(sQ); sX = wsum_i(sX);
-            const int SA = tsum, SB = sA;
-            ssd = ((2 * SA * SB - SA * SA - SB * SB) / NPIX + sQ + tsumsq - 2 * sX);
-          }
+          const int ssd = wave_zmssd<PS>(tmpl, img_tgt, ip, wl, hl, cx, cy, tsum, tsumsq, tp.max_ssd, lane);   // ZMSSDAtPoint :352-380
           if (ssd < nBestZMSSD) { nBest = base + k; nBestZMSSD = ssd; }
         }
       }
@@ -231,51 +290,7 @@ __global__ __launch_bounds__(GROW_THREADS) void k_epipolar(MapDev m, TrackParams
     if (alive) {
       const uint32_t bc = tcorners[nBest];
       sub0 = level_zero_pos((double)(bc & 0xFFFF), nLevel); sub1 = level_zero_pos((double)(bc >> 16), nLevel);
-      double gx[NQL], gy[NQL];
-      double h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0;
-      for (int q = 0; q < NQL; q++) {
-        const int k = q * 64 + lane;
-        gx[q] = 0; gy[q] = 0;
-        if (k < Q * Q) {
-          const int x = k / Q + 1, y = k % Q + 1;
-          gx[q] = 0.5 * (tmpl[y * PS + x + 1] - tmpl[y * PS + x - 1]);
-          gy[q] = 0.5 * (tmpl[(y + 1) * PS + x] - tmpl[(y - 1) * PS + x]);
-          h00 += gx[q] * gx[q]; h01 += gx[q] * gy[q]; h02 += gx[q]; h11 += gy[q] * gy[q]; h12 += gy[q]; h22 += 1.0;
-        }
-      }
-      h00 = wsum_d(h00); h01 = wsum_d(h01); h02 = wsum_d(h02); h11 = wsum_d(h11); h12 = wsum_d(h12); h22 = wsum_d(h22);
-      const double H[9] = {h00, h01, h02, h01, h11, h12, h02, h12, h22};
-      double Hinv[9];
-      inv3(H, Hinv);
-      double meanDiff = 0.0;
-      bool converged = false;
-      for (int it = 0; it < 10; it++) {
-        const double cx = level_n_pos(sub0, nLevel), cy = level_n_pos(sub1, nLevel);
-        const int xb = (int)(cx > 0.0 ? cx + 0.5 : cx - 0.5), yb = (int)(cy > 0.0 ? cy + 0.5 : cy - 0.5);
-        const int b = HALF + 1;
-        if (!(xb >= b && yb >= b && xb < wl - b && yb < hl - b)) break;
-        const double bx = cx - HALF, by = cy - HALF;
-        const double dX = bx - floor(bx), dY = by - floor(by);
-        const float fTL = (float)((1.0 - dX) * (1.0 - dY)), fTR = (float)((dX) * (1.0 - dY));
-        const float fBL = (float)((1.0 - dX) * (dY)), fBR = (float)((dX) * (dY));
-        double a0 = 0, a1 = 0, a2 = 0;
-        for (int q = 0; q < NQL; q++) {
-          const int k = q * 64 + lane;
-          if (k < Q * Q) {
-            const int x = k / Q + 1, y = k % Q + 1;
-            const uint8_t* tl = img_tgt + (size_t)((int)by + y) * ip + (int)bx + x;
-            const float fPixel = fTL * tl[0] + fTR * tl[1] + fBL * tl[ip] + fBR * tl[ip + 1];
-            const double dDiff = (fPixel - (float)tmpl[y * PS + x]) + meanDiff;
-            a0 += dDiff * gx[q]; a1 += dDiff * gy[q]; a2 += dDiff;
-          }
-        }
-        a0 = wsum_d(a0); a1 = wsum_d(a1); a2 = wsum_d(a2);
-        const double u0 = Hinv[0] * a0 + Hinv[1] * a1 + Hinv[2] * a2;
-        const double u1 = Hinv[3] * a0 + Hinv[4] * a1 + Hinv[5] * a2;
-        const double u2 = Hinv[6] * a0 + Hinv[7] * a1 + Hinv[8] * a2;
-        sub0 -= u0 * nLevelScale; sub1 -= u1 * nLevelScale; meanDiff -= u2;
-        if (u0 * u0 + u1 * u1 < 0.03 * 0.03) { converged = true; break; }
-      }
+      const bool converged = wave_subpix<PS>(tmpl, img_tgt, ip, wl, hl, nLevel, 10, lane, sub0, sub1);
       if (!converged) { alive = false; why = 6; }
     }
     // ---- triangulation and the new point's patch vectors, :666-702 (lane 0) ----
@@ -338,6 +353,142 @@ __global__ __launch_bounds__(GROW_THREADS) void k_epipolar(MapDev m, TrackParams
   }
 }
 
+// MapMaker::ReFindInSingleKeyFrame(new keyframe) / ReFind_Common, jni/MapMaker.cc:967-1056 (vslam_params.grow_map bit 1).
+// One wavefront per map point, the points of a stream strided over the grid; a point writes only its own cell of the new
+// keyframe's measurement row, so no ordering is needed.  ReFind_Common's function-static PatchFinder never sees the same
+// point twice in a row here, so its template cache never hits and every template is warped afresh (MakeTemplateCoarse,
+// jni/PatchFinder.cc:72-125: a regenerated template's own in-bounds verdict replaces the bad-scale flag of :62-65).
+// sNeverRetryKFs is not kept: its only readers are ReFindNewlyMade / ReFindFromFailureQueue, which are not built.
+template <int PS>
+__global__ __launch_bounds__(GROW_THREADS) void k_refind(MapDev m, TrackParams tp, GrowArgs a) {
+  constexpr int HALF = PS / 2;
+  const int s = blockIdx.y;
+  TrackerState* st = &m.st[s];
+  if (!st->kf_pending) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int K = tp.max_keyframes, P = tp.max_points;
+  const int ksrc = st->n_kf;
+  __shared__ uint8_t sh_tmpl[GROW_WAVES][128];
+  uint8_t* tmpl = sh_tmpl[wave];
+  const Pose Tk = m.kf_pose[(size_t)s * K + ksrc];
+  const int npts = st->n_points;
+  for (int pid = blockIdx.x * GROW_WAVES + wave; pid < npts; pid += gridDim.x * GROW_WAVES) {
+    MapPointDev& p = m.pts[(size_t)s * P + pid];
+    MeasDev& cell = m.kf_meas[((size_t)s * K + ksrc) * P + pid];
+    if (p.bad || cell.valid) continue;                               // :971 (and the trash list, jni/Map.cc:16-27)
+    double c[3];
+    pose_xform(Tk, p.pos, c);
+    if (c[2] < 0.001) continue;                                      // :979
+    const double ip0 = c[0] / c[2], ip1 = c[1] / c[2];
+    if (ip0 * ip0 + ip1 * ip1 > tp.cam.largest_radius * tp.cam.largest_radius) continue;   // :985
+    const CamProj pr = cam_project(tp.cam, ip0, ip1);
+    if (pr.invalid) continue;                                        // :991
+    if (pr.im[0] < 0 || pr.im[1] < 0 || pr.im[0] > a.w[0] || pr.im[1] > a.h[0]) continue;   // :996
+    double d[4];
+    cam_derivs(tp.cam, pr, d);
+    // CalcSearchLevelAndWarpMatrix, jni/PatchFinder.cc:31-68
+    const double ooz = 1.0 / c[2];
+    double mr[3], md[3];
+    pose_rot(Tk, p.right, mr);
+    pose_rot(Tk, p.down, md);
+    const double r0 = mr[0] - c[0] * mr[2] * ooz, r1 = mr[1] - c[1] * mr[2] * ooz;
+    const double d0 = md[0] - c[0] * md[2] * ooz, d1 = md[1] - c[1] * md[2] * ooz;
+    const double wi[4] = {(d[0] * r0 + d[1] * r1) * ooz, (d[0] * d0 + d[1] * d1) * ooz, (d[2] * r0 + d[3] * r1) * ooz, (d[2] * d0 + d[3] * d1) * ooz};
+    double det = wi[0] * wi[3] - wi[1] * wi[2];
+    int level = 0;
+    while (det > 3 && level < NLEV - 1) { level++; det *= 0.25; }
+    const int scale = 1 << level;
+    // MakeTemplateCoarseCont, :79-125: transform_image with the accumulated stepping of jni/vision/ImageHandler.cpp:21-113
+    double inv[4];
+    inv2(wi, inv);
+    const double m2[4] = {inv[0] * scale, inv[1] * scale, inv[2] * scale, inv[3] * scale};
+    int nOutside = 0, sum = 0, sumsq = 0;
+    {
+      const int sl = p.src_level;
+      const uint8_t* src = m.kf_img[sl] + ((size_t)s * K + p.src_kf) * a.kf_stride[sl];
+      const int sp = a.kf_pitch[sl], iw = a.w[sl], ih = a.h[sl];
+      const double across[2] = {m2[0], m2[2]}, down[2] = {m2[1], m2[3]};
+      double px = (double)p.irx - (m2[0] * HALF + m2[1] * HALF), py = (double)p.iry - (m2[2] * HALF + m2[3] * HALF);
+      const double cr[2] = {down[0] - PS * across[0], down[1] - PS * across[1]};
+      if (lane < PS) {
+#pragma unroll 1
+        for (int i = 0; i < lane; i++) {
+#pragma unroll
+          for (int j = 0; j < PS; j++) { px += across[0]; py += across[1]; }
+          px += cr[0]; py += cr[1];
+        }
+        const float x_bound = (float)(iw - 1), y_bound = (float)(ih - 1);
+        for (int j = 0; j < PS; j++) {
+          double x = px, y = py;
+          px += across[0]; py += across[1];
+          int v = 0;
+          if (0 <= x && 0 <= y && x < x_bound && y < y_bound) {
+            const int lx = (int)x, ly = (int)y;
+            x -= lx; y -= ly;
+            const uint8_t* q0 = src + (size_t)ly * sp + lx;
+            v = (uint8_t)((1 - y) * ((1 - x) * q0[0] + x * q0[1]) + y * ((1 - x) * q0[sp] + x * q0[sp + 1]));
+          } else nOutside++;
+          tmpl[lane * PS + j] = (uint8_t)v;
+          sum += v; sumsq += v * v;
+        }
+      }
+    }
+    nOutside = wsum_i(nOutside);
+    const int tsum = wsum_i(sum), tsumsq = wsum_i(sumsq);
+    __builtin_amdgcn_wave_barrier();
+    if (nOutside) continue;                                          // TemplateBad, :1004
+    // FindPatchCoarse(v2Image, k, 4), jni/PatchFinder.cc:170-235; the keyframe's corner list is in raster order, the row
+    // look-up table becomes a lower-bound search on the packed (y << 16 | x) positions
+    const int wl = a.w[level], hl = a.h[level], ip = a.kf_pitch[level];
+    const uint8_t* img = m.kf_img[level] + ((size_t)s * K + ksrc) * a.kf_stride[level];
+    const uint32_t* corners = m.kf_corners[level] + ((size_t)s * K + ksrc) * tp.kcap[level];
+    const int nc = m.kf_ncorners[((size_t)s * K + ksrc) * NLEV + level];
+    const double irx = pr.im[0] / scale, iry = pr.im[1] / scale;
+    const unsigned nRange = (4u + scale - 1) / scale;
+    int nTop = (int)(iry - nRange);
+    const int nBottomPlusOne = (int)(iry + nRange + 1);
+    const int nLeft = (int)(irx - nRange), nRight = (int)(irx + nRange);
+    if (nTop < 0) nTop = 0;
+    if (nTop >= hl || nBottomPlusOne <= 0) continue;
+    int lo = 0, hi = nc;
+    { const uint32_t key = (uint32_t)nTop << 16; while (lo < hi) { const int mid = (lo + hi) >> 1; if (corners[mid] < key) lo = mid + 1; else hi = mid; } }
+    const int i0 = lo;
+    int i1 = nc;
+    if (nBottomPlusOne < hl) { lo = i0; hi = nc; const uint32_t key = (uint32_t)nBottomPlusOne << 16; while (lo < hi) { const int mid = (lo + hi) >> 1; if (corners[mid] < key) lo = mid + 1; else hi = mid; } i1 = lo; }
+    int bestx = -1, besty = -1, nBest = tp.max_ssd + 1;
+    for (int base = i0; base < i1; base += 64) {
+      bool ok = false;
+      uint32_t cv = 0;
+      if (base + lane < i1) {
+        cv = corners[base + lane];
+        const int cx = cv & 0xFFFF, cy = cv >> 16;
+        const double dx = irx - cx, dy = iry - cy;
+        ok = !(cx < nLeft || cx > nRight) && !(dx * dx + dy * dy > (double)(nRange * nRange));
+      }
+      unsigned long long bm = __ballot(ok);
+      while (bm) {
+        const int k = __ffsll((long long)bm) - 1;
+        bm &= bm - 1;
+        const uint32_t cc = __shfl(cv, k);
+        const int cx = cc & 0xFFFF, cy = cc >> 16;
+        const int ssd = wave_zmssd<PS>(tmpl, img, ip, wl, hl, cx, cy, tsum, tsumsq, tp.max_ssd, lane);
+        if (ssd < nBest) { bestx = cx; besty = cy; nBest = ssd; }
+      }
+    }
+    if (!(nBest < tp.max_ssd)) continue;                             // :1010
+    double sub0 = level_zero_pos((double)bestx, level), sub1 = level_zero_pos((double)besty, level);
+    if (level > 0) wave_subpix<PS>(tmpl, img, ip, wl, hl, level, 8, lane, sub0, sub1);   // :1020-1024, convergence not looked at
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {                                                 // :1016-1034
+      MeasDev mm;
+      mm.valid = 1; mm.level = (signed char)level; mm.subpix = level > 0; mm.source = 1 /* SRC_REFIND */; mm.pad = 0;
+      mm.root[0] = sub0; mm.root[1] = sub1;
+      cell = mm;
+      p.n_meas_kfs += 1;
+    }
+  }
+}
+
 int grow_alloc(vslam_system* sys) {
   if (!sys->p.grow_map) return VSLAM_OK;
   const size_t S = sys->S, K = sys->p.max_keyframes;
@@ -360,14 +511,19 @@ int grow_on_keyframe(vslam_system* sys) {
   const LevelGeom* g = sys->geom;
   hipLaunchKernelGGL(k_copy_kf_corners, dim3(NLEV, sys->S), dim3(256), 0, sys->stream, sys->map, sys->tp, sys->fr.corners[0], sys->fr.corners[1],
                      sys->fr.corners[2], sys->fr.corners[3], sys->fr.ncorners, g[0].cap, g[1].cap, g[2].cap, g[3].cap);
-  int r = fe_keyframe_rest_gated(sys);                                   // pK->MakeKeyFrame_Rest(), jni/MapMaker.cc:488
-  if (r) return r;
   GrowArgs a;
   for (int l = 0; l < NLEV; l++) {
     a.cand[l] = sys->cand[l]; a.cand_score[l] = sys->cand_score[l]; a.cap[l] = g[l].cap; a.w[l] = g[l].w; a.h[l] = g[l].h; a.kf_pitch[l] = g[l].pitch;
     a.kf_stride[l] = (size_t)g[l].pitch * g[l].h;
   }
   a.ncand = sys->ncand;
+  if (sys->p.grow_map & 2) {                                             // ReFindInSingleKeyFrame(*pK), jni/MapMaker.cc:497
+    if (sys->tp.P == 8) hipLaunchKernelGGL(k_refind<8>, dim3(REFIND_BLOCKS, sys->S), dim3(GROW_THREADS), 0, sys->stream, sys->map, sys->tp, a);
+    else hipLaunchKernelGGL(k_refind<11>, dim3(REFIND_BLOCKS, sys->S), dim3(GROW_THREADS), 0, sys->stream, sys->map, sys->tp, a);
+  }
+  if (!(sys->p.grow_map & 1)) { HIPCHK(hipGetLastError()); return VSLAM_OK; }
+  int r = fe_keyframe_rest_gated(sys);                                   // pK->MakeKeyFrame_Rest(), jni/MapMaker.cc:488
+  if (r) return r;
   const int order[NLEV] = {3, 0, 1, 2};                                   // AddSomeMapPoints(3); (0); (1); (2), :498-501
   for (int i = 0; i < NLEV; i++) {
     r = fe_thin_new_keyframe(sys, order[i]);
