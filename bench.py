@@ -109,6 +109,8 @@ def main():
                     help="vslam_params.use_sbi: 1 = SmallBlurryImage rotation prior in the motion model (the reference's gvnUseSBI)")
     ap.add_argument("--grow-map", type=int, default=int(os.environ.get("VSLAM_BENCH_GROW_MAP", 0)),
                     help="vslam_params.grow_map bit flags: 1 = AddSomeMapPoints (epipolar search), 2 = ReFindInSingleKeyFrame, 3 = both (the reference)")
+    ap.add_argument("--diag-kf-dist-mult", type=float, default=None,
+                    help="DIAGNOSTIC ONLY (not the metric): overrides vslam_params.max_kf_dist_wiggle_mult, e.g. 1e9 = no keyframes, no BA")
     ap.add_argument("--no-events", action="store_true", help="skip the per-stage HIP events in the timed region")
     args = ap.parse_args()
     rank, world, local_rank = dist_env()
@@ -150,6 +152,8 @@ def main():
     assert S % NS == 0, "--streams must be a multiple of --systems"
     Sk = S // NS
     vpk = capi.default_params(W, H, Sk, patch_size=args.patch, device=local_rank, ba_delay_frames=args.ba_delay, use_sbi=args.use_sbi, grow_map=args.grow_map)
+    if args.diag_kf_dist_mult is not None:
+        vpk.max_kf_dist_wiggle_mult = args.diag_kf_dist_mult
     systems = [capi.System(vpk) for _ in range(NS)]
 
     def sys_of(s):
@@ -289,7 +293,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: %dx%d 4-level FAST-10 + %dx%d PatchFinder ZMSSD search, TrackMap pose update, "
                                    "AddKeyFrame + BundleAdjustRecent on keyframe frames" % (W, H, args.patch, args.patch),
-                       "streams_per_gpu": S, "systems_per_gpu": NS, "ba_delay_frames": args.ba_delay, "use_sbi": args.use_sbi, "grow_map": args.grow_map, "patch_size": args.patch, "corners_l0_per_frame": ncorn,
+                       "streams_per_gpu": S, "systems_per_gpu": NS, "ba_delay_frames": args.ba_delay, "use_sbi": args.use_sbi, "grow_map": args.grow_map, "diagnostic_kf_dist_mult": args.diag_kf_dist_mult, "patch_size": args.patch, "corners_l0_per_frame": ncorn,
                        "patches_attempted_per_frame": round(att, 1), "patches_found_per_frame": round(fnd, 1),
                        "zmssd_evals_per_frame": round(zm, 1), "keyframes_added_per_stream": kf_adds,
                        "ba_trials_per_stream": ba_trials, "streams_tracking_good": good, "setup_seconds": round(setup_s, 1)},

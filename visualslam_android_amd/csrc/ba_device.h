@@ -54,6 +54,53 @@ struct BaView {          // pointers already offset to one problem
   int* free_cams;        // [max_cams] indices of the adjustable cameras
 };
 
+// The view as the phase functions use it: every pointer is a global-address-space pointer held in scalar registers.
+// The phases are separate (noinline) functions; through a plain `const BaView&` they would see generic pointers that
+// live in the caller's private memory: every access becomes a flat load of the pointer followed by a flat load of the
+// datum, and every store may alias the view itself, so nothing can be hoisted.  Each phase therefore converts the view
+// once at its top (ba_g): 64-bit values through readfirstlane (the view is uniform per workgroup), typed address_space(1).
+#define AS1 __attribute__((address_space(1)))
+struct BaViewG {
+  int max_cams, max_pts, max_meas;
+  BaResult AS1* res;
+  Pose AS1* cam_pose; Pose AS1* cam_new; int AS1* cam_fixed; int AS1* cam_row; double AS1* cam_U; double AS1* cam_ea;
+  double AS1* pt_pos; double AS1* pt_new; double AS1* pt_V; double AS1* pt_eb; double AS1* pt_Vinv; int AS1* pt_nmeas; int AS1* pt_nout;
+  int AS1* ms_p; int AS1* ms_c; int AS1* ms_state; double AS1* ms_found; double AS1* ms_sin; double AS1* ms_cam; double AS1* ms_eps; double AS1* ms_err2;
+  double AS1* ms_derivs;
+  double AS1* ms_tcam; double AS1* ms_tfac; double AS1* ms_teps;
+  int AS1* lut;
+  double AS1* S; double AS1* E; double AS1* cam_up; double AS1* map_up;
+  double AS1* scratch;
+  int AS1* outl;
+  int AS1* free_cams;
+};
+template <class T> DEVFN T AS1* ba_uniform_ptr(T* p) {
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return (T AS1*)(((unsigned long long)hi << 32) | lo);
+}
+DEVFN BaViewG ba_g(const BaView& v) {
+  BaViewG g;
+  g.max_cams = __builtin_amdgcn_readfirstlane(v.max_cams); g.max_pts = __builtin_amdgcn_readfirstlane(v.max_pts); g.max_meas = __builtin_amdgcn_readfirstlane(v.max_meas);
+#define BA_G(f) g.f = ba_uniform_ptr(v.f)
+  BA_G(res); BA_G(cam_pose); BA_G(cam_new); BA_G(cam_fixed); BA_G(cam_row); BA_G(cam_U); BA_G(cam_ea);
+  BA_G(pt_pos); BA_G(pt_new); BA_G(pt_V); BA_G(pt_eb); BA_G(pt_Vinv); BA_G(pt_nmeas); BA_G(pt_nout);
+  BA_G(ms_p); BA_G(ms_c); BA_G(ms_state); BA_G(ms_found); BA_G(ms_sin); BA_G(ms_cam); BA_G(ms_eps); BA_G(ms_err2); BA_G(ms_derivs);
+  BA_G(ms_tcam); BA_G(ms_tfac); BA_G(ms_teps); BA_G(lut); BA_G(S); BA_G(E); BA_G(cam_up); BA_G(map_up); BA_G(scratch); BA_G(outl); BA_G(free_cams);
+#undef BA_G
+  return g;
+}
+DEVFN Pose ba_load_pose(const Pose AS1* p) {
+  Pose T;
+  _Pragma("unroll") for (int k = 0; k < 9; k++) T.R[k] = p->R[k];
+  _Pragma("unroll") for (int k = 0; k < 3; k++) T.t[k] = p->t[k];
+  return T;
+}
+DEVFN void ba_store_pose(Pose AS1* p, const Pose& T) {
+  _Pragma("unroll") for (int k = 0; k < 9; k++) p->R[k] = T.R[k];
+  _Pragma("unroll") for (int k = 0; k < 3; k++) p->t[k] = T.t[k];
+}
+
 // Diagnostic build only (-DVSLAM_BA_PROF): clock64() stamps of block 0 / lane 0 per phase of ba_compute, accumulated in
 // g_ba_prof[phase]; read with vslam_debug_ba_prof().  Never compiled into the product library.
 #ifdef VSLAM_BA_PROF
@@ -96,7 +143,7 @@ DEVFN int ba_block_sum_i(int v, int* red) {
 
 // ProjectAndFindSquaredError, jni/Bundle.cc:181-199, on operands already in registers (camera pose T, point X, found
 // position f, sqrt-inv-noise sn).  Stores v3Cam, state, derivatives, epsilon, error^2 of measurement i.
-DEVFN int ba_project_meas(const BaView& v, const BaConfig& cfg, int i, const Pose& T, const double X[3], double f0, double f1, double sn, double& e2) {
+DEVFN int ba_project_meas(const BaViewG& v, const BaConfig& cfg, int i, const Pose& T, const double X[3], double f0, double f1, double sn, double& e2) {
   double c[3];
   pose_xform(T, X, c);
   MS(ms_cam, 0, i) = c[0]; MS(ms_cam, 1, i) = c[1]; MS(ms_cam, 2, i) = c[2];
@@ -119,7 +166,7 @@ DEVFN int ba_project_meas(const BaView& v, const BaConfig& cfg, int i, const Pos
 // first loads the operands of BA_ILP (or 2) independent measurements unconditionally -- index clamped, no branch
 // between the loads -- and only then computes, so the round trips overlap.  Accumulation order is unchanged.
 struct MeasState { double cm[3], d[4]; int st; };
-DEVFN void ba_load_state(const BaView& v, int i, MeasState& m) {      // i < 0: loads measurement 0, state forced to erased
+DEVFN void ba_load_state(const BaViewG& v, int i, MeasState& m) {      // i < 0: loads measurement 0, state forced to erased
   const int ic = i < 0 ? 0 : i;
   m.st = v.ms_state[ic];
   m.cm[0] = MS(ms_cam, 0, ic); m.cm[1] = MS(ms_cam, 1, ic); m.cm[2] = MS(ms_cam, 2, ic);
@@ -136,7 +183,8 @@ DEVFN void ba_jac_A(const double cm[3], const double d[4], double A[12]) {
     A[k] = d[0] * f0 + d[1] * f1; A[6 + k] = d[2] * f0 + d[3] * f1;
   }
 }
-DEVFN void ba_jac_B(const double* R, const double cm[3], const double d[4], double B[6]) {
+template <class RP>
+DEVFN void ba_jac_B(RP R, const double cm[3], const double d[4], double B[6]) {
   const double ooz = 1.0 / cm[2];
 #pragma unroll
   for (int k = 0; k < 3; k++) {
@@ -146,7 +194,8 @@ DEVFN void ba_jac_B(const double* R, const double cm[3], const double d[4], doub
   }
 }
 // W = A^T B (6x3, :302) of measurement i in adjustable camera with rotation R
-DEVFN void ba_jac_W(const MeasState& m, const double* R, double W[18]) {
+template <class RP>
+DEVFN void ba_jac_W(const MeasState& m, RP R, double W[18]) {
   double A[12], B[6];
   ba_jac_A(m.cm, m.d, A);
   ba_jac_B(R, m.cm, m.d, B);
@@ -243,7 +292,9 @@ DEVFN bool ba_block_solve_lds(const double* S, double* E, int n, double* A, int*
 // pass 1 of Do_LM_Step (jni/Bundle.cc:209-215): project every measurement still in the list; returns this thread's
 // count of valid ones.  Kept out of line (like FindNewError below): the fp64 atan / division sequences of the camera model
 // get their own register allocation instead of inheriting the pressure of the Schur-complement tasks.
-__device__ __attribute__((noinline)) int ba_pass1_project(const BaView& v, const BaConfig& cfg, int nm) {
+__device__ __attribute__((noinline)) int ba_pass1_project(const BaView& v_, const BaConfig& cfg_, int nm) {
+  const BaViewG v = ba_g(v_);
+  const BaConfig cfg = cfg_;
   int nvalid = 0;
   for (int i0 = threadIdx.x; i0 < nm; i0 += BA_ILP_PROJ * BA_THREADS) {
     int st[BA_ILP_PROJ], mc[BA_ILP_PROJ], mp[BA_ILP_PROJ]; double f0[BA_ILP_PROJ], f1[BA_ILP_PROJ], sn[BA_ILP_PROJ];
@@ -254,7 +305,7 @@ __device__ __attribute__((noinline)) int ba_pass1_project(const BaView& v, const
     }
     Pose T[BA_ILP_PROJ]; double X[BA_ILP_PROJ][3];
     _Pragma("unroll") for (int u = 0; u < BA_ILP_PROJ; u++) {
-      T[u] = v.cam_pose[mc[u]];
+      T[u] = ba_load_pose(v.cam_pose + mc[u]);
       _Pragma("unroll") for (int k = 0; k < 3; k++) X[u][k] = v.pt_pos[3 * mp[u] + k];
     }
     _Pragma("unroll") for (int u = 0; u < BA_ILP_PROJ; u++) {
@@ -271,7 +322,9 @@ __device__ __attribute__((noinline)) int ba_pass1_project(const BaView& v, const
 // pass 1 right after an accepted step: the committed cameras / points are the trial state FindNewError has just
 // projected, so v3Cam, the radial factor (the atan) and the residual are taken from its stores instead of being
 // recomputed -- the same values, bit for bit; only the camera derivatives are still to do.
-__device__ __attribute__((noinline)) int ba_pass1_cached(const BaView& v, const BaConfig& cfg, int nm) {
+__device__ __attribute__((noinline)) int ba_pass1_cached(const BaView& v_, const BaConfig& cfg_, int nm) {
+  const BaViewG v = ba_g(v_);
+  const BaConfig cfg = cfg_;
   int nvalid = 0;
   for (int i0 = threadIdx.x; i0 < nm; i0 += BA_ILP * BA_THREADS) {
     int st[BA_ILP]; double c[BA_ILP][3], fac[BA_ILP], e0[BA_ILP], e1[BA_ILP];
@@ -310,7 +363,9 @@ __device__ __attribute__((noinline)) int ba_pass1_cached(const BaView& v, const 
 }
 
 // FindNewError (jni/Bundle.cc:537-561): this thread's share of the objective at the trial state.
-__device__ __attribute__((noinline)) double ba_find_new_error(const BaView& v, const BaConfig& cfg, int nm, double sigma2) {
+__device__ __attribute__((noinline)) double ba_find_new_error(const BaView& v_, const BaConfig& cfg_, int nm, double sigma2) {
+  const BaViewG v = ba_g(v_);
+  const BaConfig cfg = cfg_;
   double ne = 0.0;
   for (int i0 = threadIdx.x; i0 < nm; i0 += BA_ILP_PROJ * BA_THREADS) {
     int st[BA_ILP_PROJ], mc[BA_ILP_PROJ], mp[BA_ILP_PROJ]; double f0[BA_ILP_PROJ], f1[BA_ILP_PROJ], sn[BA_ILP_PROJ];
@@ -321,7 +376,7 @@ __device__ __attribute__((noinline)) double ba_find_new_error(const BaView& v, c
     }
     Pose T[BA_ILP_PROJ]; double X[BA_ILP_PROJ][3];
     _Pragma("unroll") for (int u = 0; u < BA_ILP_PROJ; u++) {
-      T[u] = v.cam_new[mc[u]];
+      T[u] = ba_load_pose(v.cam_new + mc[u]);
       _Pragma("unroll") for (int k = 0; k < 3; k++) X[u][k] = v.pt_new[3 * mp[u] + k];
     }
     _Pragma("unroll") for (int u = 0; u < BA_ILP_PROJ; u++) {
@@ -342,7 +397,8 @@ __device__ __attribute__((noinline)) double ba_find_new_error(const BaView& v, c
 
 // V, epsilon_b (jni/Bundle.cc:49-56, :312-316).  Each phase below is its own function so that it gets its own register
 // allocation (see ba_pass1_project).
-__device__ __attribute__((noinline)) void ba_accum_V(const BaView& v, int nc, int np) {
+__device__ __attribute__((noinline)) void ba_accum_V(const BaView& v_, int nc, int np) {
+  const BaViewG v = ba_g(v_);
   // V, epsilon_b per point: one lane per point, cameras in id order
   for (int p = threadIdx.x; p < np; p += BA_THREADS) {
     double V[6] = {0, 0, 0, 0, 0, 0}, eb[3] = {0, 0, 0};
@@ -369,7 +425,8 @@ __device__ __attribute__((noinline)) void ba_accum_V(const BaView& v, int nc, in
   }
 }
 
-__device__ __attribute__((noinline)) void ba_accum_U(const BaView& v, int nfree, int np) {
+__device__ __attribute__((noinline)) void ba_accum_U(const BaView& v_, int nfree, int np) {
+  const BaViewG v = ba_g(v_);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // U, epsilon_a per adjustable camera: one wavefront per camera (segmented wave reduction)
   for (int f = wave; f < nfree; f += BA_WAVES) {
@@ -395,7 +452,7 @@ __device__ __attribute__((noinline)) void ba_accum_U(const BaView& v, int nfree,
     }
     _Pragma("unroll") for (int k = 0; k < 27; k++) acc[k] = ba_wave_sum(acc[k]);
     if (lane == 0) {
-      double* U = v.cam_U + 36 * j;
+      double AS1* U = v.cam_U + 36 * j;
       int q = 0;
       _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) U[r * 6 + c] = acc[q++];
       _Pragma("unroll") for (int r = 0; r < 6; r++) v.cam_ea[6 * j + r] = acc[21 + r];
@@ -404,7 +461,8 @@ __device__ __attribute__((noinline)) void ba_accum_U(const BaView& v, int nfree,
 }
 
 // S diagonal block + E of one adjustable camera (jni/Bundle.cc:362-396); called by one wavefront.
-__device__ __attribute__((noinline)) void ba_task_diag(const BaView& v, int task, int np, int nS, double lambda) {
+__device__ __attribute__((noinline)) void ba_task_diag(const BaView& v_, int task, int np, int nS, double lambda) {
+  const BaViewG v = ba_g(v_);
   const int lane = threadIdx.x & 63;
   const int j = v.free_cams[task], row = v.cam_row[j];
   double acc[27];
@@ -432,7 +490,7 @@ __device__ __attribute__((noinline)) void ba_task_diag(const BaView& v, int task
   }
   _Pragma("unroll") for (int k = 0; k < 27; k++) acc[k] = ba_wave_sum(acc[k]);
   if (lane == 0) {
-    const double* U = v.cam_U + 36 * j;
+    const double AS1* U = v.cam_U + 36 * j;
     int q = 0;
     _Pragma("unroll") for (int r = 0; r < 6; r++)
       for (int c = 0; c <= r; c++) {
@@ -446,7 +504,8 @@ __device__ __attribute__((noinline)) void ba_task_diag(const BaView& v, int task
 }
 
 // S off-diagonal block of one pair of adjustable cameras (:400-426); called by one wavefront.
-__device__ __attribute__((noinline)) void ba_task_pair(const BaView& v, int task, int np, int nS) {
+__device__ __attribute__((noinline)) void ba_task_pair(const BaView& v_, int task, int np, int nS) {
+  const BaViewG v = ba_g(v_);
   const int lane = threadIdx.x & 63;
   int t = task, fj = 1;
   while (t >= fj) { t -= fj; fj++; }                         // pair (fj > fk): free-camera ordinals
@@ -490,7 +549,8 @@ __device__ __attribute__((noinline)) void ba_task_pair(const BaView& v, int task
 }
 
 // map updates (jni/Bundle.cc:440-462, :484): trial point positions; returns this thread's share of |update|^2.
-__device__ __attribute__((noinline)) double ba_map_update(const BaView& v, int nfree, int np) {
+__device__ __attribute__((noinline)) double ba_map_update(const BaView& v_, int nfree, int np) {
+  const BaViewG v = ba_g(v_);
   double ssq = 0.0;
   for (int p = threadIdx.x; p < np; p += BA_THREADS) {
     double sum[3] = {0, 0, 0};
@@ -502,7 +562,7 @@ __device__ __attribute__((noinline)) double ba_map_update(const BaView& v, int n
         if (ms[u].st != MS_OK) continue;
         double W[18];
         ba_jac_W(ms[u], v.cam_pose[jj[u]].R, W);
-        const double* cu = v.cam_up + v.cam_row[jj[u]];
+        const double AS1* cu = v.cam_up + v.cam_row[jj[u]];
         _Pragma("unroll") for (int c = 0; c < 3; c++) { double s = 0; for (int r = 0; r < 6; r++) s += W[r * 3 + c] * cu[r]; sum[c] += s; }
       }
     }
@@ -519,7 +579,8 @@ __device__ __attribute__((noinline)) double ba_map_update(const BaView& v, int n
 }
 
 // Bundle::Compute.  Called by all BA_THREADS threads of one workgroup.
-DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
+DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
+  const BaViewG v = ba_g(v_);
   __shared__ double red[BA_WAVES];
   __shared__ int ired[BA_WAVES];
   __shared__ int hist[768];
@@ -527,7 +588,7 @@ DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
   __shared__ double sh_lambda, sh_factor, sh_sigma2, sh_cur_err, sh_new_err;
   __shared__ double lds_A[BA_LDS_N * (BA_LDS_N + 1)];
   __shared__ int sh_converged, sh_hitmax, sh_counter, sh_accepted, sh_error, sh_nout, sh_cache_valid;
-  BaResult* R = v.res;
+  BaResult AS1* R = v.res;
   const int nc = R->n_cams, np = R->n_pts, nm = R->n_meas;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) {
@@ -549,12 +610,12 @@ DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
   while (!sh_converged && !sh_hitmax && !sh_error) {             // :153 (no abort signal: the map-maker runs synchronously)
     // ================= Do_LM_Step =================
     // pass 1 (:209-215): project every measurement still in the list
-    int nvalid = sh_cache_valid ? ba_pass1_cached(v, cfg, nm) : ba_pass1_project(v, cfg, nm);
+    int nvalid = sh_cache_valid ? ba_pass1_cached(v_, cfg, nm) : ba_pass1_project(v_, cfg, nm);
     nvalid = ba_block_sum_i(nvalid, ired);
     BA_STAMP(1);
     if (nvalid == 0) { if (threadIdx.x == 0) sh_error = 1; __syncthreads(); break; }
     {                                                              // :220-227 Tukey sigma, clamped
-      const double med = block_radix_select(v.scratch, nm, nvalid / 2, hist, sel);
+      const double med = block_radix_select((const double*)v.scratch, nm, nvalid / 2, hist, sel);
       double s2 = tukey_sigma_squared(med, (unsigned long)nvalid);
       if (s2 < cfg.min_sigma2) s2 = cfg.min_sigma2;
       if (threadIdx.x == 0) sh_sigma2 = s2;
@@ -588,9 +649,9 @@ DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
     if (threadIdx.x == 0) sh_cur_err = cur;
     __syncthreads();
     BA_STAMP(3);
-    ba_accum_V(v, nc, np);
+    ba_accum_V(v_, nc, np);
     BA_STAMP(4);
-    ba_accum_U(v, nfree, np);
+    ba_accum_U(v_, nfree, np);
     __syncthreads();
     BA_STAMP(5);
     // ---- inner loop over lambda (:326-501) ----
@@ -614,27 +675,32 @@ DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
       // S: diagonal blocks + E (:362-396) and off-diagonal blocks (:400-426); one wavefront per block
       const int ntask = nfree + nfree * (nfree - 1) / 2;
       for (int task = wave; task < ntask; task += BA_WAVES) {
-        if (task < nfree) ba_task_diag(v, task, np, nS, lambda);
-        else ba_task_pair(v, task - nfree, np, nS);
+        if (task < nfree) ba_task_diag(v_, task, np, nS, lambda);
+        else ba_task_pair(v_, task - nfree, np, nS);
       }
       __syncthreads();
       BA_STAMP(7);
-      if (nS > 0 && !(nS <= BA_LDS_N ? ba_block_solve_lds(v.S, v.E, nS, lds_A, ired) : ba_block_solve(v.S, v.E, nS, ired))) { if (threadIdx.x == 0) sh_error = 1; __syncthreads(); break; }
+      if (nS > 0 && !(nS <= BA_LDS_N ? ba_block_solve_lds((const double*)v.S, (double*)v.E, nS, lds_A, ired) : ba_block_solve((double*)v.S, (double*)v.E, nS, ired))) { if (threadIdx.x == 0) sh_error = 1; __syncthreads(); break; }
       for (int t = threadIdx.x; t < nS; t += BA_THREADS) v.cam_up[t] = v.E[t];
       __syncthreads();
       BA_STAMP(8);
       // map updates (:440-462)
-      double ssq = ba_map_update(v, nfree, np);
+      double ssq = ba_map_update(v_, nfree, np);
       for (int t = threadIdx.x; t < nS; t += BA_THREADS) ssq += v.cam_up[t] * v.cam_up[t];
       ssq = ba_block_sum(ssq, red);                                    // :467-470
       for (int j = threadIdx.x; j < nc; j += BA_THREADS) {             // :476-482
-        if (v.cam_fixed[j]) v.cam_new[j] = v.cam_pose[j];
-        else v.cam_new[j] = pose_mul(se3_exp(v.cam_up + v.cam_row[j]), v.cam_pose[j]);
+        const Pose Tj = ba_load_pose(v.cam_pose + j);
+        if (v.cam_fixed[j]) ba_store_pose(v.cam_new + j, Tj);
+        else {
+          double mu[6];
+          _Pragma("unroll") for (int k = 0; k < 6; k++) mu[k] = v.cam_up[v.cam_row[j] + k];
+          ba_store_pose(v.cam_new + j, pose_mul(se3_exp(mu), Tj));
+        }
       }
       __syncthreads();
       BA_STAMP(9);
       // FindNewError (:537-561)
-      double ne = ba_find_new_error(v, cfg, nm, sigma2);
+      double ne = ba_find_new_error(v_, cfg, nm, sigma2);
       ne = ba_block_sum(ne, red);
       BA_STAMP(10);
       if (threadIdx.x == 0) {
@@ -648,7 +714,7 @@ DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
     }
     if (sh_error) break;
     if (sh_new_err < sh_cur_err) {                                     // :503-514
-      for (int j = threadIdx.x; j < nc; j += BA_THREADS) v.cam_pose[j] = v.cam_new[j];
+      for (int j = threadIdx.x; j < nc; j += BA_THREADS) ba_store_pose(v.cam_pose + j, ba_load_pose(v.cam_new + j));
       for (int t = threadIdx.x; t < 3 * np; t += BA_THREADS) v.pt_pos[t] = v.pt_new[t];
       if (threadIdx.x == 0) { sh_factor = 2.0; sh_lambda *= 0.3; sh_accepted++; sh_cache_valid = 1; }   // ModifyLambda_GoodStep :609-612
     } else if (threadIdx.x == 0) sh_cache_valid = 0;
@@ -671,7 +737,7 @@ DEVFN void ba_compute(const BaView& v, const BaConfig& cfg) {
           v.outl[2 * off] = v.ms_p[i]; v.outl[2 * off + 1] = v.ms_c[i];
           v.ms_state[i] = MS_ERASED;
           v.lut[(size_t)v.ms_c[i] * v.max_pts + v.ms_p[i]] = -1;
-          atomicAdd(&v.pt_nout[v.ms_p[i]], 1);
+          atomicAdd((int*)&v.pt_nout[v.ms_p[i]], 1);
         }
         for (int w = 0; w < BA_WAVES; w++) base += ired[w];
       }

@@ -172,7 +172,7 @@ DEVFN int closest_keyframe(const Pose* kfp, int n_old, const Pose& self) {
 
 template <int PS>
 __global__ __launch_bounds__(GROW_THREADS) void k_epipolar(MapDev m, TrackParams tp, GrowArgs a, int nLevel) {
-  constexpr int NPIX = PS * PS, HALF = PS / 2, Q = PS - 2, NQL = (Q * Q + 63) / 64;
+  constexpr int NPIX = PS * PS, HALF = PS / 2;
   const int s = blockIdx.x;
   TrackerState* st = &m.st[s];
   if (!st->kf_pending) return;
