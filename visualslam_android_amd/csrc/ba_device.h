@@ -60,6 +60,7 @@ struct BaView {          // pointers already offset to one problem
 // datum, and every store may alias the view itself, so nothing can be hoisted.  Each phase therefore converts the view
 // once at its top (ba_g): 64-bit values through readfirstlane (the view is uniform per workgroup), typed address_space(1).
 #define AS1 __attribute__((address_space(1)))
+#define AS3 __attribute__((address_space(3)))
 struct BaViewG {
   int max_cams, max_pts, max_meas;
   BaResult AS1* res;
@@ -548,6 +549,112 @@ __device__ __attribute__((noinline)) void ba_task_pair(const BaView& v_, int tas
     }
 }
 
+// The whole reduced camera system of one LM trial, S = U* - sum_p Y_p W_p^T and E = ea - sum_p Y_p eb_p (jni/Bundle.cc:362-434),
+// for problems with at most BA_MFMA_FREE adjustable cameras (BundleAdjustRecent: 5) as ONE fp64 matrix product on the
+// matrix cores: per point p the 6 n_free x 3 stack Y_p (= W_j V*^-1 of every adjustable camera that measures p, zero rows
+// otherwise, plus one row V*^-1 eb_p) times the 3 x 6 n_free stack W_p^T.  The wave-per-block form above re-derives W_j and Y_j for
+// every camera pair (10 x 650 + 5 x 400 fp64 instructions per point); here each (point, camera) is derived once (one lane
+// each, BA_MFMA_PPC points per wavefront and trip), staged k-major in LDS and multiplied by v_mfma_f64_16x16x4_f64
+// (operand layout: tools/probes/mfma_f64_layout.hip; a = A[l%16][l/16], b = B[l/16][l%16], d[v] = D[l/16+4v][l%16]).
+// Wave partials are added in wave order, the lower triangle is mirrored as the reference mirrors it (:431-434).
+#define BA_MFMA_FREE 5
+#define BA_MFMA_PPC 12                                  // points per wavefront and trip: 12 x 5 cameras = 60 lanes, K = 36
+#define BA_MFMA_K (3 * BA_MFMA_PPC)
+#define BA_MFMA_STAGE (4 * BA_MFMA_K * 16)              // doubles per wavefront: Y rows 0-15 / 16-31, W columns 0-15 / 16-31, each [K][16]
+typedef double ba_v4d __attribute__((ext_vector_type(4)));
+__device__ __attribute__((noinline)) void ba_schur_mfma(const BaView& v_, int nfree, int np, int nS, double lambda, double* lds_) {
+  const BaViewG v = ba_g(v_);
+  double AS3* lds = (double AS3*)lds_;                    // the staging buffer is LDS: ds_read / ds_write, not flat
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double AS3* Y0 = lds + wave * BA_MFMA_STAGE; double AS3* Y1 = Y0 + BA_MFMA_K * 16; double AS3* W0 = Y1 + BA_MFMA_K * 16; double AS3* W1 = W0 + BA_MFMA_K * 16;
+  for (int t = lane; t < BA_MFMA_STAGE; t += 64) Y0[t] = 0.0;      // rows / columns no lane ever writes stay zero
+  const bool active = lane < BA_MFMA_PPC * nfree;
+  const int pl = active ? lane / nfree : 0, f = active ? lane - pl * nfree : 0;
+  const int j = v.free_cams[f];
+  double Rj[9];
+  _Pragma("unroll") for (int k = 0; k < 9; k++) Rj[k] = v.cam_pose[j].R[k];
+  ba_v4d d00 = {0, 0, 0, 0}, d10 = {0, 0, 0, 0}, d11 = {0, 0, 0, 0};
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  // two-deep software pipeline over the trips: the measurement index of trip t+2 and the operands of trip t+1 are in
+  // flight while trip t is derived, staged and multiplied (lut -> state is a dependent pair of global round trips)
+  constexpr int STRIDE = BA_WAVES * BA_MFMA_PPC;
+  const int pfirst = wave * BA_MFMA_PPC;
+  auto lut_of = [&](int p0) -> int { const int p = p0 + pl; return (active && p < np) ? v.lut[(size_t)j * v.max_pts + p] : -1; };
+  int i_nxt = lut_of(pfirst + STRIDE);
+  MeasState ms_n; double Vi_n[9], eb_n[3];
+  {
+    const int pc = pfirst + pl < np ? pfirst + pl : np - 1;
+    ba_load_state(v, lut_of(pfirst), ms_n);
+    _Pragma("unroll") for (int k = 0; k < 9; k++) Vi_n[k] = PT(pt_Vinv, k, pc);
+    _Pragma("unroll") for (int k = 0; k < 3; k++) eb_n[k] = PT(pt_eb, k, pc);
+  }
+  for (int p0 = pfirst; p0 < np; p0 += STRIDE) {
+    const int p = p0 + pl;
+    const MeasState ms = ms_n;
+    double Vi[9], eb[3];
+    _Pragma("unroll") for (int k = 0; k < 9; k++) Vi[k] = Vi_n[k];
+    _Pragma("unroll") for (int k = 0; k < 3; k++) eb[k] = eb_n[k];
+    {
+      const int i_cur = i_nxt;
+      i_nxt = lut_of(p0 + 2 * STRIDE);
+      const int pn = p0 + STRIDE + pl, pc = pn < np ? pn : np - 1;
+      ba_load_state(v, i_cur, ms_n);
+      _Pragma("unroll") for (int k = 0; k < 9; k++) Vi_n[k] = PT(pt_Vinv, k, pc);
+      _Pragma("unroll") for (int k = 0; k < 3; k++) eb_n[k] = PT(pt_eb, k, pc);
+    }
+    double W[18], Y[18];
+    if (ms.st == MS_OK) {
+      ba_jac_W(ms, Rj, W);
+      _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c < 3; c++) Y[r * 3 + c] = W[r * 3] * Vi[c] + W[r * 3 + 1] * Vi[3 + c] + W[r * 3 + 2] * Vi[6 + c];
+    } else {
+      _Pragma("unroll") for (int q = 0; q < 18; q++) { W[q] = 0.0; Y[q] = 0.0; }
+    }
+    if (active) {
+      _Pragma("unroll") for (int r = 0; r < 6; r++) {
+        const int row = 6 * f + r;
+        double AS3* yd = (row < 16 ? Y0 + row : Y1 + (row - 16)) + 3 * pl * 16;
+        double AS3* wd = (row < 16 ? W0 + row : W1 + (row - 16)) + 3 * pl * 16;
+        _Pragma("unroll") for (int c = 0; c < 3; c++) { yd[c * 16] = Y[r * 3 + c]; wd[c * 16] = W[r * 3 + c]; }
+      }
+      if (f == 0) {                                               // row 30 of the left operand: V*^-1 eb_p, so that D[30][.] = sum_p W (V*^-1 eb) (:388-396)
+        _Pragma("unroll") for (int c = 0; c < 3; c++) Y1[(3 * pl + c) * 16 + 14] = p < np ? Vi[c * 3] * eb[0] + Vi[c * 3 + 1] * eb[1] + Vi[c * 3 + 2] * eb[2] : 0.0;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0) only: the prefetched global loads stay in flight
+    __builtin_amdgcn_wave_barrier();
+    _Pragma("unroll") for (int ks = 0; ks < BA_MFMA_K / 4; ks++) {
+      const int o = (ks * 4 + (lane >> 4)) * 16 + (lane & 15);
+      const double a0 = Y0[o], a1 = Y1[o], b0 = W0[o], b1 = W1[o];
+      d00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, d00, 0, 0, 0);   // the tile of rows 0-15 x columns 16-31 lies above the diagonal: not needed
+      d10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, d10, 0, 0, 0);
+      d11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, d11, 0, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0) only: the prefetched global loads stay in flight
+    __builtin_amdgcn_wave_barrier();
+  }
+  // the wave's 32 x 32 partial product, row-major, into its own staging area
+  __syncthreads();
+  _Pragma("unroll") for (int q = 0; q < 4; q++) {
+    const int r = (lane >> 4) + 4 * q, c = lane & 15;
+    Y0[r * 32 + c] = d00[q]; Y0[(16 + r) * 32 + c] = d10[q]; Y0[(16 + r) * 32 + 16 + c] = d11[q];
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 32 * 32; t += BA_THREADS) {
+    const int r = t >> 5, c = t & 31;
+    if (!(r < nS || r == 30) || c >= nS || (r < nS && c > r)) continue;
+    double sum = 0.0;
+    for (int w = 0; w < BA_WAVES; w++) sum += lds[w * BA_MFMA_STAGE + t];
+    if (r == 30) { const int fk = c / 6, kk = v.free_cams[fk]; v.E[c] = v.cam_ea[6 * kk + (c - 6 * fk)] - sum; continue; }   // rows of S follow the adjustable cameras in order (cam_row == 6 * ordinal)
+    const int fj = r / 6, jj = v.free_cams[fj];
+    double u = 0.0;
+    if (c / 6 == fj) { u = v.cam_U[36 * jj + (r - 6 * fj) * 6 + (c - 6 * fj)]; if (r == c) u *= (1.0 + lambda); }
+    const double val = u - sum;
+    v.S[(size_t)r * nS + c] = val; v.S[(size_t)c * nS + r] = val;
+  }
+  __syncthreads();
+}
+
 // map updates (jni/Bundle.cc:440-462, :484): trial point positions; returns this thread's share of |update|^2.
 __device__ __attribute__((noinline)) double ba_map_update(const BaView& v_, int nfree, int np) {
   const BaViewG v = ba_g(v_);
@@ -586,7 +693,8 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
   __shared__ int hist[768];
   __shared__ unsigned long long sel[1];
   __shared__ double sh_lambda, sh_factor, sh_sigma2, sh_cur_err, sh_new_err;
-  __shared__ double lds_A[BA_LDS_N * (BA_LDS_N + 1)];
+  __shared__ double lds_buf[BA_WAVES * BA_MFMA_STAGE > BA_LDS_N * (BA_LDS_N + 1) ? BA_WAVES * BA_MFMA_STAGE : BA_LDS_N * (BA_LDS_N + 1)];
+  double* lds_A = lds_buf;
   __shared__ int sh_converged, sh_hitmax, sh_counter, sh_accepted, sh_error, sh_nout, sh_cache_valid;
   BaResult AS1* R = v.res;
   const int nc = R->n_cams, np = R->n_pts, nm = R->n_meas;
@@ -673,10 +781,13 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
       __syncthreads();
       BA_STAMP(6);
       // S: diagonal blocks + E (:362-396) and off-diagonal blocks (:400-426); one wavefront per block
-      const int ntask = nfree + nfree * (nfree - 1) / 2;
-      for (int task = wave; task < ntask; task += BA_WAVES) {
-        if (task < nfree) ba_task_diag(v_, task, np, nS, lambda);
-        else ba_task_pair(v_, task - nfree, np, nS);
+      if (nfree <= BA_MFMA_FREE) ba_schur_mfma(v_, nfree, np, nS, lambda, lds_buf);
+      else {
+        const int ntask = nfree + nfree * (nfree - 1) / 2;
+        for (int task = wave; task < ntask; task += BA_WAVES) {
+          if (task < nfree) ba_task_diag(v_, task, np, nS, lambda);
+          else ba_task_pair(v_, task - nfree, np, nS);
+        }
       }
       __syncthreads();
       BA_STAMP(7);
