@@ -8,8 +8,12 @@ from helpers import make_scene, make_oracle, pose_err
 from visualslam_android_amd import capi
 grow = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 patch = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-w, h = 320, 240
-f, m, frames = make_scene(w, h, seed=77, n_frames=46, per_level=(120, 50, 20, 8))
+if len(sys.argv) > 3 and sys.argv[3] == "vga":
+    w, h = 640, 480
+    f, m, frames = make_scene(w, h, seed=1234, n_frames=46)
+else:
+    w, h = 320, 240
+    f, m, frames = make_scene(w, h, seed=77, n_frames=46, per_level=(120, 50, 20, 8))
 vp = capi.default_params(w, h, 1, patch_size=patch, grow_map=grow)
 g = capi.System(vp); g.load_map(0, m); g.set_pose(0, f.pose(-1))
 o = make_oracle(capi.default_params(w, h, 1, patch_size=patch, grow_map=grow), m, f.pose(-1))
