@@ -37,7 +37,7 @@ __host__ __device__ inline BaView ba_view(const BaPool& b, int n) {
   return v;
 }
 
-__global__ __launch_bounds__(BA_THREADS) void k_ba_compute(BaPool pool, BaConfig cfg) {
+__global__ __launch_bounds__(BA_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ba_compute(BaPool pool, BaConfig cfg) {
   const BaView v = ba_view(pool, blockIdx.x);
   if (!v.res->active || v.res->computed) return;
   ba_compute(v, cfg);

@@ -16,7 +16,7 @@
 #pragma once
 #include "dev_math.h"
 
-#define BA_THREADS 512
+#define BA_THREADS 256  // 4 waves; with amdgpu_waves_per_eu(2,2) on the kernel two problems share a CU (measured: 512 x 1 -4 %, 128 x 4 -4 %)
 #define BA_LDS_N 60      // reduced camera systems up to 60 x 60 (10 adjustable cameras) are solved in LDS
 #define BA_WAVES (BA_THREADS / 64)
 #define BA_ILP_PROJ 1   // the two projection passes are bound by fp64 transcendental maths, not by latency: more in flight only spills
