@@ -110,6 +110,11 @@ class MapMaker {
   void BundleAdjustAll() { vslam_detail::check(vslam_bundle_adjust_all(mMap.sys)); }                   // :776-798
   // :393-422, all four levels of the current candidate lists against keyframe nKeyFrame's measurements (< 0: the tracker's)
   void ThinCandidates(int nKeyFrame = -1) { vslam_detail::check(vslam_thin_candidates(mMap.sys, nKeyFrame)); }
+  // :1254-1286 "SaveMap": map.dump and keyframes/<i>.info below `dir` (the reference writes to the working directory)
+  void GUICommandHandler(const std::string& sCommand, const std::string& dir = ".") {
+    if (sCommand == "SaveMap") vslam_detail::check(vslam_save_map(mMap.sys, 0, dir.c_str()));
+    else throw std::runtime_error("MapMaker::GUICommandHandler: unhandled command " + sCommand);
+  }
  protected:
   Map& mMap;
   ATANCamera mCamera;

@@ -198,6 +198,12 @@ int vslam_get_point_tracks(vslam_system* sys, int stream, int* found, int* searc
                            double* vfound, double* image, int cap);
 int vslam_get_points(vslam_system* sys, int stream, double* pos3, int* bad, int* n_inlier, int* n_outlier, int cap);
 int vslam_get_keyframe_pose(vslam_system* sys, int stream, int keyframe, double pose12[12]);
+/* The reference's only on-disk format, MapMaker::GUICommandHandler("SaveMap") (jni/MapMaker.cc:1254-1286): writes
+ * <dir>/map.dump -- per map point (bad ones are in the reference's trash list and not written) v3WorldPos the way Eigen
+ * streams a Vector3d (one coefficient per line, right-aligned to a common width, 6 significant digits) followed by two
+ * blanks and nSourceLevel -- and <dir>/keyframes/<i>.info -- se3CfromW the way jni/RT.h:303-312 streams it (three lines
+ * "r0 r1 r2 t") plus the blank line of the trailing endl.  The directories must exist.  Returns the number of points written. */
+int vslam_save_map(vslam_system* sys, int stream, const char* dir);
 int vslam_get_keyframe_measurements(vslam_system* sys, int stream, int keyframe, int* point, int* level,
                                     double* root_pos, int* source, int cap);
 int vslam_get_template(vslam_system* sys, int stream, int point, uint8_t* tmpl /* P*P */, int* sum, int* sumsq,

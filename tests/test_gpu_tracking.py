@@ -2,6 +2,7 @@
 
 Bars (BASELINE.json north_star): corner indices and found-patch sets bit-exact; pose SE3 within 1e-4 (observed ~1e-13:
 both sides compute in fp64 without FMA contraction; only the order of the reductions differs)."""
+import os
 import numpy as np
 import pytest
 
@@ -334,4 +335,31 @@ def test_map_growth_matches_oracle(patch, grow):
     assert grew >= 3
     assert (o.state().n_points > n0 + 30) == bool(grow & 1)
     assert (refound > 50) == bool(grow & 2)
+    g.close()
+
+
+def test_save_map_writes_the_reference_dump_format(tmp_path):
+    """vslam_save_map = MapMaker's "SaveMap" (jni/MapMaker.cc:1254-1286): Eigen's column print of v3WorldPos + two blanks +
+    nSourceLevel per good point, se3CfromW rows per keyframe; 6 significant digits, so the round trip is held to that."""
+    w, h = 320, 240
+    f, m, frames = make_scene(w, h, seed=5, n_frames=2, per_level=(60, 25, 10, 4))
+    g = capi.System(capi.default_params(w, h, 1))
+    g.load_map(0, m); g.set_pose(0, f.pose(-1))
+    g.track_frame(frames[0][None])
+    d = str(tmp_path)
+    n = g.save_map(0, d)
+    P = g.points(0)
+    good = P["bad"] == 0
+    assert n == int(good.sum()) > 0
+    pos, lvl, poses = capi.read_map_dump(d)
+    assert pos.shape == (n, 3) and np.allclose(pos, P["pos"][good], rtol=1e-5, atol=1e-9)
+    assert np.array_equal(lvl, np.array([p["level"] for p in m["points"]], np.int32)[good])
+    st = g.state(0)
+    assert poses.shape == (st.n_keyframes, 12)
+    for k in range(st.n_keyframes):
+        assert np.allclose(poses[k], g.keyframe_pose(0, k), rtol=1e-5, atol=1e-9)
+    lines = open(os.path.join(d, "map.dump")).read().split("\n")
+    assert len(lines) == 3 * n + 1 and lines[-1] == ""
+    assert len({len(x) for x in lines[0:2]} | {len(lines[2].rsplit("  ", 1)[0])}) == 1          # Eigen's common column width
+    assert open(os.path.join(d, "keyframes", "0.info")).read().endswith("\n\n")             # `<< endl` after the matrix
     g.close()

@@ -88,6 +88,7 @@ SYMBOLS = {
     "vslam_get_point_tracks": (_i, [_sys, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "vslam_get_points": (_i, [_sys, _i, _vp, _vp, _vp, _vp, _i]),
     "vslam_get_keyframe_pose": (_i, [_sys, _i, _i, _vp]),
+    "vslam_save_map": (_i, [_sys, _i, C.c_char_p]),
     "vslam_get_bundle_stats": (_i, [_sys, _i, _vp]),
     "vslam_get_keyframe_measurements": (_i, [_sys, _i, _i, _vp, _vp, _vp, _vp, _i]),
     "vslam_get_template": (_i, [_sys, _i, _i, _vp, _ip, _ip, _ip]),
@@ -144,6 +145,20 @@ def _check(rc):
     if rc < 0:
         raise VslamError("vslam error %d: %s" % (rc, load_library().vslam_last_error().decode()))
     return rc
+
+
+def read_map_dump(directory):
+    """Reads what `System.save_map` / the reference's "SaveMap" wrote: (positions [n, 3], source levels [n], keyframe poses
+    [k, 12] as rotation rows then translation).  The text holds 6 significant digits."""
+    tok = open(os.path.join(directory, "map.dump")).read().split()
+    a = np.array(tok, dtype=np.float64).reshape(-1, 4) if tok else np.zeros((0, 4))
+    poses = []
+    k = 0
+    while os.path.exists(os.path.join(directory, "keyframes", "%d.info" % k)):
+        m = np.array(open(os.path.join(directory, "keyframes", "%d.info" % k)).read().split(), dtype=np.float64).reshape(3, 4)
+        poses.append(np.concatenate([m[:, :3].reshape(-1), m[:, 3]]))
+        k += 1
+    return a[:, :3], a[:, 3].astype(np.int32), np.array(poses).reshape(-1, 12)
 
 
 def default_params(width, height, n_streams=1, **overrides):
@@ -367,6 +382,11 @@ class System:
         p = np.zeros(12)
         _check(self.lib.vslam_get_keyframe_pose(self.h, stream, kf, p.ctypes.data))
         return p
+
+    def save_map(self, stream, directory):
+        """MapMaker's "SaveMap" dump (jni/MapMaker.cc:1254-1286): <directory>/map.dump and <directory>/keyframes/<i>.info."""
+        os.makedirs(os.path.join(directory, "keyframes"), exist_ok=True)
+        return _check(self.lib.vslam_save_map(self.h, stream, os.fsencode(directory)))
 
     def keyframe_meas(self, stream, kf, cap=8192):
         pt, level, source = (np.zeros(cap, np.int32) for _ in range(3))

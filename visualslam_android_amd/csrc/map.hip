@@ -356,6 +356,42 @@ extern "C" int vslam_get_keyframe_pose(vslam_system* sys, int s, int k, double p
   return VSLAM_OK;
 }
 
+// MapMaker::GUICommandHandler("SaveMap"), jni/MapMaker.cc:1254-1286.  std::ostream's default floating-point format is
+// %g with precision 6; Eigen's default IOFormat right-aligns the coefficients of a matrix to the widest one.
+extern "C" int vslam_save_map(vslam_system* sys, int s, const char* dir) {
+  CHK_STREAM(sys, s);
+  if (!dir) return VSLAM_E_INVALID;
+  TrackerState st;
+  int r = get_state(sys, s, &st); if (r) return r;
+  const int n = st.n_points, nk = st.n_kf;
+  std::vector<MapPointDev> p(n > 0 ? n : 1);
+  if (n > 0) HIPCHK(hipMemcpy(p.data(), sys->map.pts + (size_t)s * sys->p.max_points, sizeof(MapPointDev) * n, hipMemcpyDeviceToHost));
+  std::vector<Pose> kp(nk > 0 ? nk : 1);
+  if (nk > 0) HIPCHK(hipMemcpy(kp.data(), sys->map.kf_pose + (size_t)s * sys->p.max_keyframes, sizeof(Pose) * nk, hipMemcpyDeviceToHost));
+  char path[4096];
+  snprintf(path, sizeof(path), "%s/map.dump", dir);
+  FILE* f = fopen(path, "w");
+  if (!f) { vslam_set_error("save_map: cannot open map.dump in the given directory"); return VSLAM_E_INVALID; }
+  int written = 0;
+  for (int i = 0; i < n; i++) {
+    if (p[i].bad) continue;
+    char c[3][64]; size_t wmax = 0;
+    for (int q = 0; q < 3; q++) { snprintf(c[q], sizeof(c[q]), "%g", p[i].pos[q]); if (strlen(c[q]) > wmax) wmax = strlen(c[q]); }
+    fprintf(f, "%*s\n%*s\n%*s  %d\n", (int)wmax, c[0], (int)wmax, c[1], (int)wmax, c[2], p[i].src_level);
+    written++;
+  }
+  fclose(f);
+  for (int k = 0; k < nk; k++) {
+    snprintf(path, sizeof(path), "%s/keyframes/%d.info", dir, k);
+    FILE* g = fopen(path, "w");
+    if (!g) { vslam_set_error("save_map: cannot open keyframes/<i>.info in the given directory"); return VSLAM_E_INVALID; }
+    for (int i = 0; i < 3; i++) fprintf(g, "%g %g %g %g\n", kp[k].R[i * 3], kp[k].R[i * 3 + 1], kp[k].R[i * 3 + 2], kp[k].t[i]);
+    fprintf(g, "\n");
+    fclose(g);
+  }
+  return written;
+}
+
 extern "C" int vslam_get_keyframe_measurements(vslam_system* sys, int s, int k, int* point, int* level, double* root_pos, int* source, int cap) {
   CHK_STREAM(sys, s);
   TrackerState st;
