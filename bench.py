@@ -127,7 +127,7 @@ def main():
     from visualslam_android_amd import capi, feeder
     S, W, H, K, Wm = args.streams, args.width, args.height, args.steps, args.warmup
     T = Wm + K
-    nthreads = min(16, os.cpu_count() or 8)
+    nthreads = max(2, min(16, (os.cpu_count() or 8) // max(1, world)))   # set-up threads per rank: the ranks of a node share its cores
 
     # ---- synthetic scenes: one seeded feeder, trajectory and ground-truth map per stream -----------------------------
     t_setup = time.time()
