@@ -561,6 +561,7 @@ __device__ __attribute__((noinline)) void ba_task_pair(const BaView& v_, int tas
 #define BA_MFMA_PPC 12                                  // points per wavefront and trip: 12 x 5 cameras = 60 lanes, K = 36
 #define BA_MFMA_K (3 * BA_MFMA_PPC)
 #define BA_MFMA_STAGE (4 * BA_MFMA_K * 16)              // doubles per wavefront: Y rows 0-15 / 16-31, W columns 0-15 / 16-31, each [K][16]
+static_assert(BA_MFMA_STAGE >= 32 * 32 && BA_MFMA_K % 4 == 0, "a wavefront's staging area also holds its 32 x 32 partial product");
 typedef double ba_v4d __attribute__((ext_vector_type(4)));
 __device__ __attribute__((noinline)) void ba_schur_mfma(const BaView& v_, int nfree, int np, int nS, double lambda, double* lds_) {
   const BaViewG v = ba_g(v_);
