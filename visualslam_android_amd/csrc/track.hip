@@ -723,15 +723,31 @@ __global__ __launch_bounds__(POSE_THREADS) __attribute__((amdgpu_waves_per_eu(2,
 #endif
   const PoseWs ws = {m.pose_ws + (size_t)s * POSE_WS_COMPS * P, m.pose_wsi + (size_t)s * 2 * P, P};
   int nfound_thread = 0;
-  for (int e = threadIdx.x; e < n; e += POSE_THREADS) {             // gather
-    const int idx = ilist[e];
-    const TrackData& t = td[idx];
-    ws.i[e] = m.pt_flags[(size_t)s * P + idx]; ws.i[P + e] = idx;
-    for (int i = 0; i < 3; i++) ws.d[(0 + i) * P + e] = t.cam[i];
-    for (int i = 0; i < 2; i++) { ws.d[(3 + i) * P + e] = t.image[i]; ws.d[(9 + i) * P + e] = t.vfound[i]; }
-    for (int i = 0; i < 4; i++) ws.d[(5 + i) * P + e] = t.derivs[i];
-    ws.d[11 * P + e] = t.sqrt_inv_noise;
-    if (ws.i[e] & TDF_FOUND) nfound_thread++;
+  // gather, POSE_GB entries per thread at a time: the entry indices, then every operand of the batch are loaded before
+  // anything is stored, so the dependent pair of round trips (list -> tracker data) is paid once per batch, not per entry
+  constexpr int POSE_GB = 4;
+  for (int e0 = threadIdx.x; e0 < n; e0 += POSE_GB * POSE_THREADS) {
+    int idx[POSE_GB], fl[POSE_GB]; double v[POSE_GB][12];
+#pragma unroll
+    for (int u = 0; u < POSE_GB; u++) { const int e = e0 + u * POSE_THREADS; idx[u] = ilist[e < n ? e : n - 1]; }
+#pragma unroll
+    for (int u = 0; u < POSE_GB; u++) {
+      const TrackData& t = td[idx[u]];
+      fl[u] = m.pt_flags[(size_t)s * P + idx[u]];
+      for (int i = 0; i < 3; i++) v[u][i] = t.cam[i];
+      for (int i = 0; i < 2; i++) { v[u][3 + i] = t.image[i]; v[u][9 + i] = t.vfound[i]; }
+      for (int i = 0; i < 4; i++) v[u][5 + i] = t.derivs[i];
+      v[u][11] = t.sqrt_inv_noise;
+    }
+#pragma unroll
+    for (int u = 0; u < POSE_GB; u++) {
+      const int e = e0 + u * POSE_THREADS;
+      if (e >= n) continue;
+      ws.i[e] = fl[u]; ws.i[P + e] = idx[u];
+#pragma unroll
+      for (int c = 0; c < 12; c++) ws.d[c * P + e] = v[u][c];
+      if (fl[u] & TDF_FOUND) nfound_thread++;
+    }
   }
   nfound_thread = wave_sum_i(nfound_thread);
   if ((threadIdx.x & 63) == 0) icnt[threadIdx.x >> 6] = nfound_thread;
@@ -789,34 +805,51 @@ __global__ __launch_bounds__(POSE_THREADS) __attribute__((amdgpu_waves_per_eu(2,
     POSE_STAMP(7);
   }
   POSE_STAMP(8);
-  for (int e = threadIdx.x; e < n; e += POSE_THREADS) {             // scatter what the iterations changed
-    TrackData& t = td[ws.i[P + e]];
-    m.pt_flags[(size_t)s * P + ws.i[P + e]] = ws.i[e];
-    for (int i = 0; i < 3; i++) t.cam[i] = ws.d[(0 + i) * P + e];
-    for (int i = 0; i < 2; i++) t.image[i] = ws.d[(3 + i) * P + e];
-    for (int i = 0; i < 4; i++) t.derivs[i] = ws.d[(5 + i) * P + e];
+  // scatter what the iterations changed, batched like the gather; the fine stage exports the measurements of the found
+  // patches (:594-607) and sums the scene depth (:610-625) from the same registers
+  MeasDev* cm = m.cur_meas + (size_t)s * P;
+  if (stage != 0) {
+    for (int i = threadIdx.x; i < st->n_points; i += POSE_THREADS) cm[i].valid = 0;
+    __syncthreads();
+  }
+  double dSum = 0, dSumSq = 0; int nNum = 0;
+  for (int e0 = threadIdx.x; e0 < n; e0 += POSE_GB * POSE_THREADS) {
+    int idx[POSE_GB], fl[POSE_GB], lv[POSE_GB]; double v[POSE_GB][11];
+#pragma unroll
+    for (int u = 0; u < POSE_GB; u++) {
+      const int e = e0 + u * POSE_THREADS, ec = e < n ? e : n - 1;
+      idx[u] = ws.i[P + ec]; fl[u] = ws.i[ec];
+#pragma unroll
+      for (int c = 0; c < 11; c++) v[u][c] = ws.d[c * P + ec];
+    }
+    if (stage != 0) {
+#pragma unroll
+      for (int u = 0; u < POSE_GB; u++) lv[u] = m.pt_level[(size_t)s * P + idx[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < POSE_GB; u++) {
+      const int e = e0 + u * POSE_THREADS;
+      if (e >= n) continue;
+      TrackData& t = td[idx[u]];
+      m.pt_flags[(size_t)s * P + idx[u]] = fl[u];
+      for (int i = 0; i < 3; i++) t.cam[i] = v[u][i];
+      for (int i = 0; i < 2; i++) t.image[i] = v[u][3 + i];
+      for (int i = 0; i < 4; i++) t.derivs[i] = v[u][5 + i];
+      if (stage != 0 && (fl[u] & TDF_FOUND)) {
+        MeasDev mm;
+        mm.root[0] = v[u][9]; mm.root[1] = v[u][10];
+        mm.valid = 1; mm.level = (signed char)lv[u]; mm.subpix = (fl[u] & TDF_SUBPIX) ? 1 : 0; mm.source = 0 /* SRC_TRACKER */; mm.pad = 0;
+        cm[idx[u]] = mm;
+        const double z = v[u][2];
+        dSum += z; dSumSq += z * z; nNum++;
+      }
+    }
   }
   if (stage == 0) {
     if (threadIdx.x == 0) { st->pose_cur = pose; st->did_coarse = 1; }
     return;
   }
-  // ---- measurement export (:594-607) and scene depth (:610-625) ----
-  MeasDev* cm = m.cur_meas + (size_t)s * P;
-  for (int i = threadIdx.x; i < st->n_points; i += POSE_THREADS) cm[i].valid = 0;
-  __syncthreads();
-  double dSum = 0, dSumSq = 0; int nNum = 0;
-  for (int e = threadIdx.x; e < n; e += POSE_THREADS) {
-    const int idx = ilist[e];
-    const TrackData& t = td[idx];
-    const int tflags = m.pt_flags[(size_t)s * P + idx];
-    if (!(tflags & TDF_FOUND)) continue;
-    MeasDev mm;
-    mm.root[0] = t.vfound[0]; mm.root[1] = t.vfound[1];
-    mm.valid = 1; mm.level = (signed char)m.pt_level[(size_t)s * P + idx]; mm.subpix = (tflags & TDF_SUBPIX) ? 1 : 0; mm.source = 0 /* SRC_TRACKER */; mm.pad = 0;
-    cm[idx] = mm;
-    const double z = t.cam[2];
-    dSum += z; dSumSq += z * z; nNum++;
-  }
+  // ---- scene depth (:610-625) ----
   dSum = wave_sum_d(dSum); dSumSq = wave_sum_d(dSumSq); nNum = wave_sum_i(nNum);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) { red[wave * 28] = dSum; red[wave * 28 + 1] = dSumSq; icnt[wave] = nNum; }
