@@ -22,6 +22,8 @@
 #define BA_ILP_PROJ 1   // the two projection passes are bound by fp64 transcendental maths, not by latency: more in flight only spills
 #define BA_ILP_S 1      // Schur-complement tasks: 36 accumulators + two 6x3 blocks per lane leave no registers for a second point
 #define BA_ILP 4        // independent measurements per thread and loop trip: the loops are memory-latency bound at 2 waves/SIMD
+#define BA_ILP_W 8      // pass 2 (weights): 9 operands per measurement, nothing else live
+#define BA_ILP_P 6      // per-point loops over cameras (V, map update): 11 cameras in 2 trips, 5 adjustable ones in 1
 
 #define MS_OK 0
 #define MS_BAD 1      // bBad: z <= 0 or zero Tukey weight in this step
@@ -403,15 +405,15 @@ __device__ __attribute__((noinline)) void ba_accum_V(const BaView& v_, int nc, i
   // V, epsilon_b per point: one lane per point, cameras in id order
   for (int p = threadIdx.x; p < np; p += BA_THREADS) {
     double V[6] = {0, 0, 0, 0, 0, 0}, eb[3] = {0, 0, 0};
-    for (int c0 = 0; c0 < nc; c0 += BA_ILP) {
-      int ii[BA_ILP]; MeasState ms[BA_ILP]; double e[BA_ILP][2];
-      _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) ii[u] = c0 + u < nc ? v.lut[(size_t)(c0 + u) * v.max_pts + p] : -1;
-      _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) {
+    for (int c0 = 0; c0 < nc; c0 += BA_ILP_P) {
+      int ii[BA_ILP_P]; MeasState ms[BA_ILP_P]; double e[BA_ILP_P][2];
+      _Pragma("unroll") for (int u = 0; u < BA_ILP_P; u++) ii[u] = c0 + u < nc ? v.lut[(size_t)(c0 + u) * v.max_pts + p] : -1;
+      _Pragma("unroll") for (int u = 0; u < BA_ILP_P; u++) {
         ba_load_state(v, ii[u], ms[u]);
         const int ic = ii[u] < 0 ? 0 : ii[u];
         e[u][0] = MS(ms_eps, 0, ic); e[u][1] = MS(ms_eps, 1, ic);
       }
-      _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) {
+      _Pragma("unroll") for (int u = 0; u < BA_ILP_P; u++) {
         if (ms[u].st != MS_OK) continue;
         double B[6];
         ba_jac_B(v.cam_pose[c0 + u].R, ms[u].cm, ms[u].d, B);
@@ -662,11 +664,11 @@ __device__ __attribute__((noinline)) double ba_map_update(const BaView& v_, int 
   double ssq = 0.0;
   for (int p = threadIdx.x; p < np; p += BA_THREADS) {
     double sum[3] = {0, 0, 0};
-    for (int f0 = 0; f0 < nfree; f0 += BA_ILP) {
-      int jj[BA_ILP]; MeasState ms[BA_ILP];
-      _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) jj[u] = v.free_cams[f0 + u < nfree ? f0 + u : nfree - 1];
-      _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) ba_load_state(v, f0 + u < nfree ? v.lut[(size_t)jj[u] * v.max_pts + p] : -1, ms[u]);
-      _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) {
+    for (int f0 = 0; f0 < nfree; f0 += BA_ILP_P) {
+      int jj[BA_ILP_P]; MeasState ms[BA_ILP_P];
+      _Pragma("unroll") for (int u = 0; u < BA_ILP_P; u++) jj[u] = v.free_cams[f0 + u < nfree ? f0 + u : nfree - 1];
+      _Pragma("unroll") for (int u = 0; u < BA_ILP_P; u++) ba_load_state(v, f0 + u < nfree ? v.lut[(size_t)jj[u] * v.max_pts + p] : -1, ms[u]);
+      _Pragma("unroll") for (int u = 0; u < BA_ILP_P; u++) {
         if (ms[u].st != MS_OK) continue;
         double W[18];
         ba_jac_W(ms[u], v.cam_pose[jj[u]].R, W);
@@ -724,7 +726,7 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
     BA_STAMP(1);
     if (nvalid == 0) { if (threadIdx.x == 0) sh_error = 1; __syncthreads(); break; }
     {                                                              // :220-227 Tukey sigma, clamped
-      const double med = block_radix_select((const double*)v.scratch, nm, nvalid / 2, hist, sel);
+      const double med = block_radix_select(v.scratch, nm, nvalid / 2, hist, sel);
       double s2 = tukey_sigma_squared(med, (unsigned long)nvalid);
       if (s2 < cfg.min_sigma2) s2 = cfg.min_sigma2;
       if (threadIdx.x == 0) sh_sigma2 = s2;
@@ -734,16 +736,16 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
     BA_STAMP(2);
     // pass 2 (:241-321): weights and objective; A, B, W are re-derived by their consumers
     double cur = 0.0;
-    for (int i0 = threadIdx.x; i0 < nm; i0 += BA_ILP * BA_THREADS) {   // BA_ILP measurements in flight per thread
-      int stt[BA_ILP]; double e2[BA_ILP], ep0[BA_ILP], ep1[BA_ILP], sn[BA_ILP], dd[BA_ILP][4];
-      _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) {
+    for (int i0 = threadIdx.x; i0 < nm; i0 += BA_ILP_W * BA_THREADS) {   // BA_ILP_W measurements in flight per thread
+      int stt[BA_ILP_W]; double e2[BA_ILP_W], ep0[BA_ILP_W], ep1[BA_ILP_W], sn[BA_ILP_W], dd[BA_ILP_W][4];
+      _Pragma("unroll") for (int u = 0; u < BA_ILP_W; u++) {
         const int i = i0 + u * BA_THREADS, ic = i < nm ? i : nm - 1;   // unconditional loads: no branch between them
         stt[u] = v.ms_state[ic];
         e2[u] = v.ms_err2[ic]; ep0[u] = MS(ms_eps, 0, ic); ep1[u] = MS(ms_eps, 1, ic); sn[u] = v.ms_sin[ic];
         _Pragma("unroll") for (int k = 0; k < 4; k++) dd[u][k] = MS(ms_derivs, k, ic);
         if (i >= nm) stt[u] = MS_ERASED;
       }
-      _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) {
+      _Pragma("unroll") for (int u = 0; u < BA_ILP_W; u++) {
         const int i = i0 + u * BA_THREADS;
         if (stt[u] == MS_ERASED) continue;
         if (stt[u] == MS_BAD) { cur += 1.0; continue; }
@@ -832,28 +834,35 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
     } else if (threadIdx.x == 0) sh_cache_valid = 0;
     __syncthreads();
     BA_STAMP(11);
-    // erase the outliers in list order (:517-528): ordered compaction of the (p, c) pairs
+    // erase the outliers in list order (:517-528): ordered compaction of the (p, c) pairs, BA_ERASE_B chunks of the list
+    // per barrier pair (all their states are loaded first; one LDS table of per-chunk, per-wavefront counts)
     {
+      constexpr int BA_ERASE_B = 8;
+      __shared__ int ecnt[BA_ERASE_B * BA_WAVES];
       int base = sh_nout;
-      for (int i0 = 0; i0 < nm; i0 += BA_THREADS) {
-        const int i = i0 + threadIdx.x;
-        const bool bad = i < nm && v.ms_state[i] == MS_BAD;
-        const unsigned long long bm = __ballot(bad);
-        __syncthreads();
-        if (lane == 0) ired[wave] = __popcll(bm);
-        __syncthreads();
-        int off = base;
-        for (int w = 0; w < wave; w++) off += ired[w];
-        if (bad) {
-          off += __popcll(bm & ((1ull << lane) - 1ull));
-          v.outl[2 * off] = v.ms_p[i]; v.outl[2 * off + 1] = v.ms_c[i];
-          v.ms_state[i] = MS_ERASED;
-          v.lut[(size_t)v.ms_c[i] * v.max_pts + v.ms_p[i]] = -1;
-          atomicAdd((int*)&v.pt_nout[v.ms_p[i]], 1);
+      for (int i0 = 0; i0 < nm; i0 += BA_ERASE_B * BA_THREADS) {
+        bool bad[BA_ERASE_B]; unsigned long long bm[BA_ERASE_B];
+        _Pragma("unroll") for (int u = 0; u < BA_ERASE_B; u++) {
+          const int i = i0 + u * BA_THREADS + threadIdx.x;
+          bad[u] = v.ms_state[i < nm ? i : nm - 1] == MS_BAD && i < nm;
         }
-        for (int w = 0; w < BA_WAVES; w++) base += ired[w];
+        _Pragma("unroll") for (int u = 0; u < BA_ERASE_B; u++) { bm[u] = __ballot(bad[u]); if (lane == 0) ecnt[u * BA_WAVES + wave] = __popcll(bm[u]); }
+        __syncthreads();
+        _Pragma("unroll") for (int u = 0; u < BA_ERASE_B; u++) {
+          int off = base;
+          for (int w = 0; w < BA_WAVES; w++) { const int c = ecnt[u * BA_WAVES + w]; if (w < wave) off += c; base += c; }
+          if (bad[u]) {
+            const int i = i0 + u * BA_THREADS + threadIdx.x;
+            off += __popcll(bm[u] & ((1ull << lane) - 1ull));
+            const int pp = v.ms_p[i], cc = v.ms_c[i];
+            v.outl[2 * off] = pp; v.outl[2 * off + 1] = cc;
+            v.ms_state[i] = MS_ERASED;
+            v.lut[(size_t)cc * v.max_pts + pp] = -1;
+            atomicAdd((int*)&v.pt_nout[pp], 1);
+          }
+        }
+        __syncthreads();
       }
-      __syncthreads();
       if (threadIdx.x == 0) sh_nout = base;
       __syncthreads();
     }
