@@ -322,54 +322,57 @@ __device__ __attribute__((noinline)) int ba_pass1_project(const BaView& v_, cons
   return nvalid;
 }
 
-// pass 1 right after an accepted step: the committed cameras / points are the trial state FindNewError has just
-// projected, so v3Cam, the radial factor (the atan) and the residual are taken from its stores instead of being
-// recomputed -- the same values, bit for bit; only the camera derivatives are still to do.
-__device__ __attribute__((noinline)) int ba_pass1_cached(const BaView& v_, const BaConfig& cfg_, int nm) {
+// Passes 1 and 2 right after an accepted step, in one sweep: the committed cameras / points are the trial state
+// FindNewError has just projected, so v3Cam, the radial factor (the atan), the residual and its square are taken from
+// its stores instead of being recomputed -- the same values, bit for bit -- and the median of the squared errors (sigma) is
+// already known, because FindNewError also left them in `scratch`.  What is left is the camera derivatives and the Tukey
+// weights; the unweighted epsilon / derivatives / error^2 of the two-pass form are never written or read back
+// (136 instead of 264 B per measurement).  Returns this thread's share of the objective (pass 2's `cur`).
+__device__ __attribute__((noinline)) double ba_pass12_cached(const BaView& v_, const BaConfig& cfg_, int nm, double sigma2) {
   const BaViewG v = ba_g(v_);
   const BaConfig cfg = cfg_;
-  int nvalid = 0;
+  double cur = 0.0;
   for (int i0 = threadIdx.x; i0 < nm; i0 += BA_ILP * BA_THREADS) {
-    int st[BA_ILP]; double c[BA_ILP][3], fac[BA_ILP], e0[BA_ILP], e1[BA_ILP];
+    int st[BA_ILP]; double c[BA_ILP][3], fac[BA_ILP], e0[BA_ILP], e1[BA_ILP], sn[BA_ILP];
     _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) {
       const int i = i0 + u * BA_THREADS, ic = i < nm ? i : nm - 1;
       st[u] = v.ms_state[ic];
       c[u][0] = MS(ms_tcam, 0, ic); c[u][1] = MS(ms_tcam, 1, ic); c[u][2] = MS(ms_tcam, 2, ic);
-      fac[u] = v.ms_tfac[ic]; e0[u] = MS(ms_teps, 0, ic); e1[u] = MS(ms_teps, 1, ic);
+      fac[u] = v.ms_tfac[ic]; e0[u] = MS(ms_teps, 0, ic); e1[u] = MS(ms_teps, 1, ic); sn[u] = v.ms_sin[ic];
     }
     _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) {
       const int i = i0 + u * BA_THREADS;
-      if (i >= nm) continue;
-      double e2 = __builtin_huge_val();
-      if (st[u] != MS_ERASED) {
-        MS(ms_cam, 0, i) = c[u][0]; MS(ms_cam, 1, i) = c[u][1]; MS(ms_cam, 2, i) = c[u][2];
-        if (c[u][2] <= 0) v.ms_state[i] = MS_BAD;
-        else {
-          v.ms_state[i] = MS_OK;
-          CamProj pr;                                               // cam_project minus its atan
-          pr.cam[0] = c[u][0] / c[u][2]; pr.cam[1] = c[u][1] / c[u][2];
-          pr.r = sqrt(pr.cam[0] * pr.cam[0] + pr.cam[1] * pr.cam[1]);
-          pr.factor = fac[u]; pr.invalid = 0; pr.im[0] = 0; pr.im[1] = 0;
-          double dd[4];
-          cam_derivs(cfg.cam, pr, dd);
-          MS(ms_derivs, 0, i) = dd[0]; MS(ms_derivs, 1, i) = dd[1]; MS(ms_derivs, 2, i) = dd[2]; MS(ms_derivs, 3, i) = dd[3];
-          MS(ms_eps, 0, i) = e0[u]; MS(ms_eps, 1, i) = e1[u];
-          e2 = e0[u] * e0[u] + e1[u] * e1[u];
-          v.ms_err2[i] = e2;
-          nvalid++;
-        }
-      }
-      v.scratch[i] = e2;
+      if (i >= nm || st[u] == MS_ERASED) continue;
+      MS(ms_cam, 0, i) = c[u][0]; MS(ms_cam, 1, i) = c[u][1]; MS(ms_cam, 2, i) = c[u][2];
+      if (c[u][2] <= 0) { v.ms_state[i] = MS_BAD; cur += 1.0; continue; }          // pass 1: bBad; pass 2 (:243-246)
+      CamProj pr;                                                     // cam_project minus its atan
+      pr.cam[0] = c[u][0] / c[u][2]; pr.cam[1] = c[u][1] / c[u][2];
+      pr.r = sqrt(pr.cam[0] * pr.cam[0] + pr.cam[1] * pr.cam[1]);
+      pr.factor = fac[u]; pr.invalid = 0; pr.im[0] = 0; pr.im[1] = 0;
+      double dd[4];
+      cam_derivs(cfg.cam, pr, dd);
+      const double e2 = e0[u] * e0[u] + e1[u] * e1[u];
+      const double dWeight = tukey_sqrt_weight(e2, sigma2);
+      MS(ms_eps, 0, i) = e0[u] * dWeight; MS(ms_eps, 1, i) = e1[u] * dWeight;
+      if (dWeight == 0) { v.ms_state[i] = MS_BAD; cur += 1.0; continue; }
+      v.ms_state[i] = MS_OK;
+      cur += tukey_objective(e2, sigma2);
+      _Pragma("unroll") for (int k = 0; k < 4; k++) MS(ms_derivs, k, i) = sn[u] * (dWeight * dd[k]);
     }
   }
-  return nvalid;
+  return cur;
 }
 
 // FindNewError (jni/Bundle.cc:537-561): this thread's share of the objective at the trial state.
-__device__ __attribute__((noinline)) double ba_find_new_error(const BaView& v_, const BaConfig& cfg_, int nm, double sigma2) {
+// It also prepares the next Do_LM_Step in case this trial is accepted: the squared error of every measurement that stays
+// in the list (state OK now, in front of the trial camera) goes to `scratch` for the median, +inf for the others, and
+// their number is returned.
+struct BaNewError { double ne; int nvalid; };
+__device__ __attribute__((noinline)) BaNewError ba_find_new_error(const BaView& v_, const BaConfig& cfg_, int nm, double sigma2) {
   const BaViewG v = ba_g(v_);
   const BaConfig cfg = cfg_;
   double ne = 0.0;
+  int nv = 0;
   for (int i0 = threadIdx.x; i0 < nm; i0 += BA_ILP_PROJ * BA_THREADS) {
     int st[BA_ILP_PROJ], mc[BA_ILP_PROJ], mp[BA_ILP_PROJ]; double f0[BA_ILP_PROJ], f1[BA_ILP_PROJ], sn[BA_ILP_PROJ];
     _Pragma("unroll") for (int u = 0; u < BA_ILP_PROJ; u++) {
@@ -388,14 +391,19 @@ __device__ __attribute__((noinline)) double ba_find_new_error(const BaView& v_, 
       double c[3];
       pose_xform(T[u], X[u], c);
       MS(ms_tcam, 0, i) = c[0]; MS(ms_tcam, 1, i) = c[1]; MS(ms_tcam, 2, i) = c[2];
-      if (c[2] <= 0) { ne += 1.0; continue; }
+      if (c[2] <= 0) { ne += 1.0; v.scratch[i] = __builtin_huge_val(); continue; }
       const CamProj pr = cam_project(cfg.cam, c[0] / c[2], c[1] / c[2]);
       const double e0 = (f0[u] - pr.im[0]) * sn[u], e1 = (f1[u] - pr.im[1]) * sn[u];
       v.ms_tfac[i] = pr.factor; MS(ms_teps, 0, i) = e0; MS(ms_teps, 1, i) = e1;
-      ne += tukey_objective(e0 * e0 + e1 * e1, sigma2);
+      const double e2 = e0 * e0 + e1 * e1;
+      ne += tukey_objective(e2, sigma2);
+      const bool stays = st[u] == MS_OK;                              // MS_BAD ones are erased at the end of this step
+      v.scratch[i] = stays ? e2 : __builtin_huge_val();
+      nv += stays ? 1 : 0;
     }
   }
-  return ne;
+  BaNewError r; r.ne = ne; r.nvalid = nv;
+  return r;
 }
 
 // V, epsilon_b (jni/Bundle.cc:49-56, :312-316).  Each phase below is its own function so that it gets its own register
@@ -698,7 +706,7 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
   __shared__ double sh_lambda, sh_factor, sh_sigma2, sh_cur_err, sh_new_err;
   __shared__ double lds_buf[BA_WAVES * BA_MFMA_STAGE > BA_LDS_N * (BA_LDS_N + 1) ? BA_WAVES * BA_MFMA_STAGE : BA_LDS_N * (BA_LDS_N + 1)];
   double* lds_A = lds_buf;
-  __shared__ int sh_converged, sh_hitmax, sh_counter, sh_accepted, sh_error, sh_nout, sh_cache_valid;
+  __shared__ int sh_converged, sh_hitmax, sh_counter, sh_accepted, sh_error, sh_nout, sh_cache_valid, sh_next_nvalid;
   BaResult AS1* R = v.res;
   const int nc = R->n_cams, np = R->n_pts, nm = R->n_meas;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -721,8 +729,10 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
   while (!sh_converged && !sh_hitmax && !sh_error) {             // :153 (no abort signal: the map-maker runs synchronously)
     // ================= Do_LM_Step =================
     // pass 1 (:209-215): project every measurement still in the list
-    int nvalid = sh_cache_valid ? ba_pass1_cached(v_, cfg, nm) : ba_pass1_project(v_, cfg, nm);
-    nvalid = ba_block_sum_i(nvalid, ired);
+    const bool cached = sh_cache_valid != 0;                       // the previous step was accepted: FindNewError has projected this state
+    int nvalid;
+    if (cached) nvalid = sh_next_nvalid;
+    else nvalid = ba_block_sum_i(ba_pass1_project(v_, cfg, nm), ired);
     BA_STAMP(1);
     if (nvalid == 0) { if (threadIdx.x == 0) sh_error = 1; __syncthreads(); break; }
     {                                                              // :220-227 Tukey sigma, clamped
@@ -736,7 +746,8 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
     BA_STAMP(2);
     // pass 2 (:241-321): weights and objective; A, B, W are re-derived by their consumers
     double cur = 0.0;
-    for (int i0 = threadIdx.x; i0 < nm; i0 += BA_ILP_W * BA_THREADS) {   // BA_ILP_W measurements in flight per thread
+    if (cached) cur = ba_pass12_cached(v_, cfg, nm, sigma2);
+    else for (int i0 = threadIdx.x; i0 < nm; i0 += BA_ILP_W * BA_THREADS) {   // BA_ILP_W measurements in flight per thread
       int stt[BA_ILP_W]; double e2[BA_ILP_W], ep0[BA_ILP_W], ep1[BA_ILP_W], sn[BA_ILP_W], dd[BA_ILP_W][4];
       _Pragma("unroll") for (int u = 0; u < BA_ILP_W; u++) {
         const int i = i0 + u * BA_THREADS, ic = i < nm ? i : nm - 1;   // unconditional loads: no branch between them
@@ -814,10 +825,12 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
       __syncthreads();
       BA_STAMP(9);
       // FindNewError (:537-561)
-      double ne = ba_find_new_error(v_, cfg, nm, sigma2);
-      ne = ba_block_sum(ne, red);
+      const BaNewError fne = ba_find_new_error(v_, cfg, nm, sigma2);
+      const double ne = ba_block_sum(fne.ne, red);
+      const int nv_next = ba_block_sum_i(fne.nvalid, ired);
       BA_STAMP(10);
       if (threadIdx.x == 0) {
+        sh_next_nvalid = nv_next;
         if (ssq < cfg.convergence_limit) sh_converged = 1;
         sh_new_err = ne;
         if (ne > sh_cur_err) { sh_lambda = sh_lambda * sh_factor; sh_factor = sh_factor * 2; }   // ModifyLambda_BadStep :614-617
