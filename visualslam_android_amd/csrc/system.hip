@@ -126,6 +126,8 @@ extern "C" int vslam_create(const vslam_params* p, vslam_system** out) {
   sys->have_sbi = false;
   if (p->ba_delay_frames > 0) {
     if (hipStreamCreateWithFlags(&sys->ba_stream, hipStreamNonBlocking) != hipSuccess) { vslam_set_error("create: hipStreamCreate failed"); vslam_destroy(sys); return VSLAM_E_HIP; }
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->device) == hipSuccess && ncu > 0) sys->n_cu = ncu;
     for (int i = 0; i < p->ba_delay_frames + 2; i++) {
       hipEvent_t a = nullptr, b = nullptr;
       if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) { vslam_set_error("create: hipEventCreate failed"); vslam_destroy(sys); return VSLAM_E_HIP; }
