@@ -136,17 +136,34 @@ __global__ __launch_bounds__(TRK_THREADS) void k_plan(MapDev m, TrackParams tp, 
     if (threadIdx.x < NLEV) cnt[threadIdx.x] = 0;
     __syncthreads();
     const int n = st->n_points;
-    for (int base = 0; base < n; base += TRK_THREADS) {             // avPVS[l] in map order (:369-392)
-      const int i = base + threadIdx.x;
-      const int lvl = i < n ? m.pt_level[(size_t)s * P + i] : -1;
-      unsigned long long b[NLEV];
-      for (int l = 0; l < NLEV; l++) { b[l] = __ballot(lvl == l); if (lane == 0) wcnt[wave][l] = __popcll(b[l]); }
+    // avPVS[l] in map order (:369-392).  Every thread owns PLAN_CH consecutive map points: their levels are fetched in one
+    // batch, counted per level in registers, the counts are scanned over the workgroup (one barrier pair per
+    // PLAN_CH * TRK_THREADS points instead of three barriers per TRK_THREADS), and the thread appends its points in order.
+    constexpr int PLAN_CH = 16;
+    for (int base = 0; base < n; base += PLAN_CH * TRK_THREADS) {
+      const int first = base + threadIdx.x * PLAN_CH;
+      int lv[PLAN_CH], c[NLEV] = {0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < PLAN_CH; k++) { const int i = first + k; lv[k] = m.pt_level[(size_t)s * P + (i < n ? i : n - 1)]; if (i >= n) lv[k] = -1; }
+#pragma unroll
+      for (int k = 0; k < PLAN_CH; k++)
+#pragma unroll
+        for (int l = 0; l < NLEV; l++) c[l] += lv[k] == l;
+      int off[NLEV];
+#pragma unroll
+      for (int l = 0; l < NLEV; l++) {                             // exclusive scan of the per-thread counts
+        int inc = c[l];
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+        if (lane == 63) wcnt[wave][l] = inc;
+        off[l] = inc - c[l];
+      }
       __syncthreads();
-      if (lvl >= 0) {
-        int off = cnt[lvl];
-        for (int w = 0; w < wave; w++) off += wcnt[w][lvl];
-        off += __popcll(b[lvl] & ((1ull << lane) - 1ull));
-        pvs[lvl * P + off] = i;
+#pragma unroll
+      for (int l = 0; l < NLEV; l++) { off[l] += cnt[l]; for (int w = 0; w < wave; w++) off[l] += wcnt[w][l]; }
+#pragma unroll
+      for (int k = 0; k < PLAN_CH; k++) {
+#pragma unroll
+        for (int l = 0; l < NLEV; l++) if (lv[k] == l) pvs[l * P + off[l]++] = first + k;
       }
       __syncthreads();
       if (threadIdx.x < NLEV) { int t = cnt[threadIdx.x]; for (int w = 0; w < TRK_THREADS / 64; w++) t += wcnt[w][threadIdx.x]; cnt[threadIdx.x] = t; }
