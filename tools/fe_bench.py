@@ -11,6 +11,9 @@ import torch
 
 from visualslam_android_amd import capi, feeder
 
+if os.environ.get("VSLAM_LIB"):
+    capi.load_library(os.environ["VSLAM_LIB"])      # a diagnostic build from tools/build_variant.sh
+
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 W, H = 640, 480

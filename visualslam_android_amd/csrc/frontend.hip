@@ -103,6 +103,7 @@ __device__ __forceinline__ void fast_band(const uint8_t* tile, int lp, int y0, i
     //     pixels 3 to the left / right assembled from the neighbouring aligned dwords (v_alignbyte).  The compiler reads
     //     the bytes straight out of the registers (SDWA), so the LDS sees 5 dword reads per 4 pixels instead of 20 byte reads.
     const int nq = (w + 3) >> 2;                                     // dwords per row
+#ifndef VSLAM_FE_SKIP_QUICK
     for (int it = wave * 64 + lane; it - lane < gr * nq; it += nwave * 64) {
       const int r = r0 + it / nq, q = it - (it / nq) * nq;
       const int y = y0 + r, x0 = q << 2;
@@ -138,12 +139,15 @@ __device__ __forceinline__ void fast_band(const uint8_t* tile, int lp, int y0, i
         }
       }
     }
+#endif
     __syncthreads();
     const int n = *ncand;
+#ifndef VSLAM_FE_SKIP_FULL
     for (int i = threadIdx.x; i < n; i += blockDim.x) {               // (B) full segment test on packed lanes
       const int r = cand[i] >> 12, x = cand[i] & 4095;
       if (fast10_full(tile + (r + HALO) * lp + x, lp, thr)) atomicOr(&mask_lds[r * nchunk + (x >> 6)], 1ull << (x & 63));
     }
+#endif
     __syncthreads();
   }
   for (int i = threadIdx.x; i < nrows * nchunk; i += blockDim.x) cmask[(size_t)y0 * nchunk + i] = mask_lds[i];
