@@ -363,3 +363,33 @@ def test_save_map_writes_the_reference_dump_format(tmp_path):
     assert len({len(x) for x in lines[0:2]} | {len(lines[2].rsplit("  ", 1)[0])}) == 1          # Eigen's common column width
     assert open(os.path.join(d, "keyframes", "0.info")).read().endswith("\n\n")             # `<< endl` after the matrix
     g.close()
+
+
+def test_tracking_loss_matches_oracle():
+    """Blank frames after a good start: nothing is found, AssessTrackingQuality (jni/Tracker.cc:832-878) reports BAD, the
+    lost-frame counter runs up and from the third lost frame on TrackFrame does no tracking any more (:100-136; the
+    relocaliser that would take over is out of scope).  State, counters and pose against the oracle, frame by frame;
+    a second stream that keeps its real frames is not disturbed."""
+    w, h = 320, 240
+    f, m, frames = make_scene(w, h, seed=12, n_frames=8, per_level=(120, 50, 20, 8))
+    vp = capi.default_params(w, h, 2)
+    o = make_oracle(capi.default_params(w, h, 1), m, f.pose(-1))
+    o_ok = make_oracle(capi.default_params(w, h, 1), m, f.pose(-1))
+    g = capi.System(vp)
+    for s in range(2):
+        g.load_map(s, m); g.set_pose(s, f.pose(-1))
+    blank = np.zeros((h, w), np.uint8)
+    drift, drift_ok = Drift(), Drift()
+    for t in range(8):
+        fr = frames[t] if t < 2 else blank
+        g.track_frame(np.stack([fr, frames[t]])); o.track_frame(fr); o_ok.track_frame(frames[t])
+        so, sg = o.state(), g.state(0)
+        assert (so.quality, so.lost_frames, so.n_keyframes) == (sg.quality, sg.lost_frames, sg.n_keyframes), t
+        assert list(so.attempted) == list(sg.attempted) and list(so.found) == list(sg.found), t
+        assert pose_err(so.pose, sg.pose) < 1e-9, t
+        if t < 2:
+            compare_frame(o, g, 0, "before the loss, frame %d" % t, drift)
+        compare_frame(o_ok, g, 1, "undisturbed stream, frame %d" % t, drift_ok)
+    assert g.state(0).quality == 0 and g.state(0).lost_frames == 3        # the counter stops with the tracking (:100); the per-level counts keep the last tracked frame's values
+    assert g.state(1).quality == 2
+    g.close()
