@@ -103,3 +103,34 @@ def test_keyframe_rest_candidates_bit_exact(oracle):
             total += len(pos)
     assert total > 50
     g.close()
+
+
+@pytest.mark.parametrize("on_device", [0, 1])
+def test_padded_row_and_stream_strides(oracle, on_device):
+    """cv::Mat::step need not equal the width (jni/KeyFrame.cc:12 copies whatever `step` the caller's Mat has), and the
+    frames of a batch need not be adjacent: rows 13 bytes and images 1000 bytes further apart than tight, the gaps filled
+    with noise that must never be read as pixels.  Host and device source buffers."""
+    import torch
+    w, h, S, pad, gap = 200, 136, 3, 13, 1000
+    frames = np.stack([synth_image(7 + s, w, h) for s in range(S)])
+    rng = np.random.default_rng(0)
+    buf = rng.integers(0, 256, size=S * (h * (w + pad) + gap), dtype=np.uint8)
+    sstride = h * (w + pad) + gap
+    for s in range(S):
+        view = buf[s * sstride: s * sstride + h * (w + pad)].reshape(h, w + pad)
+        view[:, :w] = frames[s]
+    g = capi.System(capi.default_params(w, h, S))
+    if on_device:
+        dev = torch.from_numpy(buf).cuda()
+        capi._check(g.lib.vslam_make_keyframe_lite(g.h, dev.data_ptr(), w + pad, sstride, 1))
+    else:
+        capi._check(g.lib.vslam_make_keyframe_lite(g.h, buf.ctypes.data, w + pad, sstride, 0))
+    g.synchronize()
+    for s in range(S):
+        want = oracle.make_keyframe_lite(frames[s])
+        for l in range(4):
+            img, corners, lut = want[l]
+            assert np.array_equal(g.read_level_image(s, l), img), (s, l)
+            assert np.array_equal(g.read_corners(s, l), corners), (s, l)
+            assert np.array_equal(g.read_row_lut(s, l), lut), (s, l)
+    g.close()
