@@ -20,6 +20,7 @@ struct GrowArgs {
   double* cand_score[NLEV];   // a candidate AddPointEpipolar rejects gets its score replaced by -(stage at which it gave up): 1 ray, 2 line,
                               // 3 radius, 4 template border, 5 no corner on the line, 6 sub-pixel, 7 map full (vslam_read_candidates)
   int w[NLEV], h[NLEV], kf_pitch[NLEV]; size_t kf_stride[NLEV];
+  double* tgt_implane; int tgt_cap;   // vImplaneCorners of the target keyframe at the level being processed, [S][tgt_cap][2] (k_target_implane)
 };
 
 struct EpiResult { int ok; double pos[3], right[3], down[3], root[2], sub[2]; int irx, iry; };
@@ -100,9 +101,9 @@ DEVFN bool wave_subpix(const uint8_t* tmpl, const uint8_t* img, int ip, int wl, 
 DEVFN void smallest_eigvec4(const double Sin[16], double out[4]) {
   double S[16], V[16];
   for (int i = 0; i < 16; i++) { S[i] = Sin[i]; V[i] = (i % 5 == 0) ? 1.0 : 0.0; }
-  for (int sweep = 0; sweep < 16; sweep++)
-    for (int p = 0; p < 3; p++)
-      for (int q = p + 1; q < 4; q++) {
+  _Pragma("unroll 1") for (int sweep = 0; sweep < 16; sweep++)
+    _Pragma("unroll") for (int p = 0; p < 3; p++)
+      _Pragma("unroll") for (int q = p + 1; q < 4; q++) {
         const double apq = S[p * 4 + q];
         if (apq == 0.0) continue;
         const double theta = (S[q * 4 + q] - S[p * 4 + p]) / (2.0 * apq);
@@ -170,8 +171,32 @@ DEVFN int closest_keyframe(const Pose* kfp, int n_old, const Pose& self) {
   return n;
 }
 
+// AddPointEpipolar's vImplaneCorners (jni/MapMaker.cc:612-620; the reference caches them per keyframe level): the target
+// keyframe's corners of level nLevel un-projected once per keyframe event instead of once per candidate.
+__global__ __launch_bounds__(256) void k_target_implane(MapDev m, TrackParams tp, GrowArgs a, int nLevel) {
+  const int s = blockIdx.y;
+  const TrackerState* st = &m.st[s];
+  if (!st->kf_pending) return;
+  const int K = tp.max_keyframes, ksrc = st->n_kf;
+  __shared__ int sh_tgt;
+  const Pose* kfp = m.kf_pose + (size_t)s * K;
+  if (threadIdx.x == 0) sh_tgt = closest_keyframe(kfp, ksrc, kfp[ksrc]);
+  __syncthreads();
+  const int ktgt = sh_tgt;
+  if (ktgt < 0) return;
+  const uint32_t* tcorners = m.kf_corners[nLevel] + ((size_t)s * K + ktgt) * tp.kcap[nLevel];
+  const int ntc = m.kf_ncorners[((size_t)s * K + ktgt) * NLEV + nLevel];
+  double* out = a.tgt_implane + (size_t)s * a.tgt_cap * 2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ntc; i += gridDim.x * blockDim.x) {
+    const uint32_t cv = tcorners[i];
+    double v2Im[2];   // UnProject of the level-zero position truncated to integer pixels
+    cam_unproject(tp.cam, (double)(int)level_zero_pos((double)(cv & 0xFFFF), nLevel), (double)(int)level_zero_pos((double)(cv >> 16), nLevel), v2Im);
+    out[2 * i] = v2Im[0]; out[2 * i + 1] = v2Im[1];
+  }
+}
+
 template <int PS>
-__global__ __launch_bounds__(GROW_THREADS) void k_epipolar(MapDev m, TrackParams tp, GrowArgs a, int nLevel) {
+__global__ __launch_bounds__(GROW_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_epipolar(MapDev m, TrackParams tp, GrowArgs a, int nLevel) {
   constexpr int NPIX = PS * PS, HALF = PS / 2;
   const int s = blockIdx.x;
   TrackerState* st = &m.st[s];
@@ -194,6 +219,7 @@ __global__ __launch_bounds__(GROW_THREADS) void k_epipolar(MapDev m, TrackParams
   const uint8_t* img_tgt = m.kf_img[nLevel] + ((size_t)s * K + ktgt) * a.kf_stride[nLevel];
   const uint32_t* tcorners = m.kf_corners[nLevel] + ((size_t)s * K + ktgt) * tp.kcap[nLevel];
   const int ntc = m.kf_ncorners[((size_t)s * K + ktgt) * NLEV + nLevel];
+  const double* timp = a.tgt_implane + (size_t)s * a.tgt_cap * 2;
   const uint32_t* cand = a.cand[nLevel] + (size_t)s * a.cap[nLevel];
   const int ncand = a.ncand[s * NLEV + nLevel];
   const double dMean = m.kf_depth[((size_t)s * K + ksrc) * 2], dSigma = m.kf_depth[((size_t)s * K + ksrc) * 2 + 1];
@@ -267,8 +293,7 @@ __global__ __launch_bounds__(GROW_THREADS) void k_epipolar(MapDev m, TrackParams
         uint32_t cv = 0;
         if (base + lane < ntc) {
           cv = tcorners[base + lane];
-          double v2Im[2];   // vImplaneCorners (:612-620): UnProject of the level-zero position truncated to integer pixels
-          cam_unproject(tp.cam, (double)(int)level_zero_pos((double)(cv & 0xFFFF), nLevel), (double)(int)level_zero_pos((double)(cv >> 16), nLevel), v2Im);
+          const double v2Im[2] = {timp[2 * (base + lane)], timp[2 * (base + lane) + 1]};   // vImplaneCorners (:612-620), k_target_implane
           const double dDistDiff = dNormDist - (v2Im[0] * normal0 + v2Im[1] * normal1);
           const double len = v2Im[0] * along0 + v2Im[1] * along1;
           ok = !(dDistDiff * dDistDiff > dMaxDistSq) && !(len < dMinLen) && !(len > dMaxLen);
@@ -503,6 +528,10 @@ int grow_alloc(vslam_system* sys) {
   HIPCHK(hipMemsetAsync(ptr, 0, S * K * NLEV * sizeof(int) + 64, sys->stream));
   sys->allocs.push_back(ptr);
   sys->map.kf_ncorners = (int*)ptr;
+  ptr = nullptr;
+  HIPCHK(hipMalloc(&ptr, S * (size_t)sys->tp.kcap[0] * 2 * sizeof(double) + 64));
+  sys->allocs.push_back(ptr);
+  sys->grow_implane = (double*)ptr;
   return VSLAM_OK;
 }
 
@@ -517,6 +546,7 @@ int grow_on_keyframe(vslam_system* sys) {
     a.kf_stride[l] = (size_t)g[l].pitch * g[l].h;
   }
   a.ncand = sys->ncand;
+  a.tgt_implane = sys->grow_implane; a.tgt_cap = sys->tp.kcap[0];
   if (sys->p.grow_map & 2) {                                             // ReFindInSingleKeyFrame(*pK), jni/MapMaker.cc:497
     if (sys->tp.P == 8) hipLaunchKernelGGL(k_refind<8>, dim3(REFIND_BLOCKS, sys->S), dim3(GROW_THREADS), 0, sys->stream, sys->map, sys->tp, a);
     else hipLaunchKernelGGL(k_refind<11>, dim3(REFIND_BLOCKS, sys->S), dim3(GROW_THREADS), 0, sys->stream, sys->map, sys->tp, a);
@@ -528,6 +558,7 @@ int grow_on_keyframe(vslam_system* sys) {
   for (int i = 0; i < NLEV; i++) {
     r = fe_thin_new_keyframe(sys, order[i]);
     if (r) return r;
+    hipLaunchKernelGGL(k_target_implane, dim3(8, sys->S), dim3(256), 0, sys->stream, sys->map, sys->tp, a, order[i]);
     if (sys->tp.P == 8) hipLaunchKernelGGL(k_epipolar<8>, dim3(sys->S), dim3(GROW_THREADS), 0, sys->stream, sys->map, sys->tp, a, order[i]);
     else hipLaunchKernelGGL(k_epipolar<11>, dim3(sys->S), dim3(GROW_THREADS), 0, sys->stream, sys->map, sys->tp, a, order[i]);
   }

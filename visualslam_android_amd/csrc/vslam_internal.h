@@ -154,6 +154,7 @@ struct vslam_system {
   hipEvent_t ev_fe_done[2] = {nullptr, nullptr}, ev_track_done[2] = {nullptr, nullptr};
   // asynchronous map-maker (ba_delay_frames > 0): Bundle::Compute runs on ba_stream beside the following frames
   hipStream_t ba_stream = nullptr;
+  double* grow_implane = nullptr;   // [S][kcap_0][2]: the epipolar search's target corners on the image plane (mapgrow.hip)
   int n_cu = 0;             // compute units of the device (asynchronous map-maker: size of the background BA grid)
   std::vector<hipEvent_t> ev_asm, ev_ba;   // rings of ba_delay + 2 events, indexed by frame number
   long frame_no = 0;
