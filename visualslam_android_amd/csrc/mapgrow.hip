@@ -44,6 +44,24 @@ DEVFN int wave_zmssd(const uint8_t* tmpl, const uint8_t* img, int ip, int wl, in
   return ((2 * SA * SB - SA * SA - SB * SB) / NPIX + sQ + tsumsq - 2 * sX);
 }
 
+// Several ZMSSDAtPoint evaluations (jni/PatchFinder.cc:352-380) per wavefront step, the way k_searchN scores its
+// candidates: G lanes per patch (8 for 8x8 -> 8 patches at once, 16 for 11x11 -> 4), lane r < PS owns row r of template
+// and image patch as packed bytes and the three sums are v_dot4_u32_u8 products reduced over the G lanes.
+template <int PS> struct GRow { unsigned w[(PS + 3) / 4]; };
+template <int PS> DEVFN GRow<PS> grow_load_row(const uint8_t* p) {
+  GRow<PS> r;
+  _Pragma("unroll") for (int k = 0; k < (PS + 3) / 4; k++) r.w[k] = 0u;
+  __builtin_memcpy(&r, p, PS);
+  return r;
+}
+template <int PS> DEVFN GRow<PS> grow_load_row_lds(const uint8_t* p) {      // the template row out of LDS (byte reads: 8-byte rows of an 11-byte pitch are unaligned)
+  GRow<PS> r;
+  _Pragma("unroll") for (int k = 0; k < (PS + 3) / 4; k++) r.w[k] = 0u;
+  _Pragma("unroll") for (int x = 0; x < PS; x++) r.w[x >> 2] |= (unsigned)p[x] << (8 * (x & 3));
+  return r;
+}
+template <int G> DEVFN int grow_grp_sum(int v) { for (int d = 1; d < G; d <<= 1) v += __shfl_xor(v, d); return v; }
+
 // MakeSubPixTemplate (jni/PatchFinder.cc:242-271) + IterateSubPixToConvergence (:273-350) by one wavefront, starting from
 // the level-zero position in sub0/sub1; these are left wherever the iteration stopped (ReFind_Common reads them regardless)
 template <int PS>
@@ -207,6 +225,10 @@ __global__ __launch_bounds__(GROW_THREADS) __attribute__((amdgpu_waves_per_eu(2,
   __shared__ int sh_tgt;
   __shared__ EpiResult res[GROW_WAVES];
   __shared__ uint8_t sh_tmpl[GROW_WAVES][128];
+  constexpr int G = PS <= 8 ? 8 : 16, NPW = 64 / G;                 // lanes per patch, patches scored per wavefront step
+  __shared__ int2 sh_sel[GROW_WAVES][NPW];
+  int2* sel = sh_sel[wave];
+  const int grp = lane / G, sub = lane % G;
   const Pose* kfp = m.kf_pose + (size_t)s * K;
   if (threadIdx.x == 0) sh_tgt = closest_keyframe(kfp, ksrc, kfp[ksrc]);
   __syncthreads();
@@ -284,6 +306,9 @@ __global__ __launch_bounds__(GROW_THREADS) __attribute__((amdgpu_waves_per_eu(2,
       tsum = wsum_i(sa); tsumsq = wsum_i(sq);
     }
     __builtin_amdgcn_wave_barrier();
+    GRow<PS> trow;
+    _Pragma("unroll") for (int q = 0; q < (PS + 3) / 4; q++) trow.w[q] = 0u;
+    if (alive && sub < PS) trow = grow_load_row_lds<PS>(tmpl + sub * PS);
     // ---- the target keyframe's corners near the epipolar line, :622-641: filter 64 at a time, score the survivors in order ----
     int nBest = -1, nBestZMSSD = tp.max_ssd + 1;
     if (alive) {
@@ -299,13 +324,37 @@ __global__ __launch_bounds__(GROW_THREADS) __attribute__((amdgpu_waves_per_eu(2,
           ok = !(dDistDiff * dDistDiff > dMaxDistSq) && !(len < dMinLen) && !(len > dMaxLen);
         }
         unsigned long long bm = __ballot(ok);
-        while (bm) {
-          const int k = __ffsll((long long)bm) - 1;
-          bm &= bm - 1;
-          const uint32_t c = __shfl(cv, k);
-          const int cx = c & 0xFFFF, cy = c >> 16;
-          const int ssd = wave_zmssd<PS>(tmpl, img_tgt, ip, wl, hl, cx, cy, tsum, tsumsq, tp.max_ssd, lane);   // ZMSSDAtPoint :352-380
-          if (ssd < nBestZMSSD) { nBest = base + k; nBestZMSSD = ssd; }
+        while (bm) {                                                 // NPW survivors per step, in list order
+          const int rank = __popcll(bm & ((1ull << lane) - 1ull));
+          const bool mine = ((bm >> lane) & 1ull) && rank < NPW;
+          if (mine) sel[rank] = make_int2((int)cv, base + lane);
+          const int nsel = min(NPW, (int)__popcll(bm));
+          bm &= ~__ballot(mine);
+          __builtin_amdgcn_s_waitcnt(0xC07F);
+          __builtin_amdgcn_wave_barrier();
+          const int2 pick = sel[grp < nsel ? grp : 0];
+          const int cx = pick.x & 0xFFFF, cy = (unsigned)pick.x >> 16;
+          int ssd = tp.max_ssd + 1;
+          const bool inb = cx >= HALF && cy >= HALF && cx < wl - HALF && cy < hl - HALF;
+          {
+            int sA = 0, sQ = 0, sX = 0;
+            if (inb && grp < nsel && sub < PS) {
+              const GRow<PS> ir = grow_load_row<PS>(img_tgt + (size_t)(cy - HALF + sub) * ip + (cx - HALF));
+              _Pragma("unroll") for (int q = 0; q < (PS + 3) / 4; q++) {
+                sA = (int)__builtin_amdgcn_udot4(ir.w[q], 0x01010101u, (unsigned)sA, false);
+                sQ = (int)__builtin_amdgcn_udot4(ir.w[q], ir.w[q], (unsigned)sQ, false);
+                sX = (int)__builtin_amdgcn_udot4(ir.w[q], trow.w[q], (unsigned)sX, false);
+              }
+            }
+            sA = grow_grp_sum<G>(sA); sQ = grow_grp_sum<G>(sQ); sX = grow_grp_sum<G>(sX);
+            const int SA = tsum, SB = sA;
+            if (inb) ssd = ((2 * SA * SB - SA * SA - SB * SB) / NPIX + sQ + tsumsq - 2 * sX);   // ZMSSDAtPoint :352-380
+          }
+          _Pragma("unroll") for (int g = 0; g < NPW; g++) {          // first strict minimum in list order (:630-637)
+            const int sg = __shfl(ssd, g * G), ig = __shfl(pick.y, g * G);
+            if (g < nsel && sg < nBestZMSSD) { nBest = ig; nBestZMSSD = sg; }
+          }
+          __builtin_amdgcn_wave_barrier();
         }
       }
       if (nBest == -1) { alive = false; why = 5; }
