@@ -292,6 +292,65 @@ DEVFN bool ba_block_solve_lds(const double* S, double* E, int n, double* A, int*
   return true;
 }
 
+// The reduced camera system of up to BA_WSOLVE_N unknowns (5 adjustable cameras) solved by ONE wavefront with the augmented
+// matrix in registers: lane r holds row r, the pivot row is broadcast with v_readlane, no LDS and no barrier inside.
+// Same pivoting rule (first row of maximal |A[r][k]|) and the same multiply / subtract per element as ba_block_solve, the
+// back-substitution sums in ascending column order like lu_solve_n.  Every index is a compile-time constant after
+// unrolling.  Called by wavefront 0 only; returns false if singular.  Writes the solution to E.
+#define BA_WSOLVE_N 30
+DEVFN double ba_readlane_d(double v, int l) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __attribute__((noinline)) bool ba_solve_wave(const BaView& v_, int n) {
+  const BaViewG v = ba_g(v_);
+  constexpr int N = BA_WSOLVE_N;
+  const int lane = threadIdx.x & 63;
+  double a[N + 1];                                                   // a[0..N-1]: the row; a[N]: right-hand side
+  _Pragma("unroll") for (int c = 0; c < N; c++) a[c] = (lane < n && c < n) ? v.S[(size_t)lane * n + c] : (c == lane ? 1.0 : 0.0);
+  a[N] = lane < n ? v.E[lane] : 0.0;
+  bool ok = true;
+  _Pragma("unroll") for (int k = 0; k < N; k++) {
+    if (k < n && ok) {
+      double best = (lane >= k && lane < n) ? fabs(a[k]) : -1.0;
+      int piv = lane;
+      _Pragma("unroll") for (int d = 32; d > 0; d >>= 1) {
+        const double ob = __shfl_xor(best, d); const int op = __shfl_xor(piv, d);
+        if (ob > best || (ob == best && op < piv)) { best = ob; piv = op; }
+      }
+      piv = __builtin_amdgcn_readfirstlane(piv);
+      if (best == 0.0) ok = false;
+      else {
+        double rowk[N + 1];
+        _Pragma("unroll") for (int c = k; c <= N; c++) {
+          const double vk = ba_readlane_d(a[c], k), vp = ba_readlane_d(a[c], piv);
+          a[c] = lane == k ? vp : (lane == piv ? vk : a[c]);         // rows k and piv change places (a no-op when piv == k)
+          rowk[c] = vp;
+        }
+        const double inv = 1.0 / rowk[k];
+        if (lane > k && lane < n) {
+          const double f = a[k] * inv;
+          _Pragma("unroll") for (int c = k + 1; c <= N; c++) a[c] -= f * rowk[c];
+        }
+      }
+    }
+  }
+  if (!ok) return false;
+  double x[N];
+  _Pragma("unroll") for (int k = N - 1; k >= 0; k--) {
+    x[k] = 0.0;
+    if (k < n) {
+      double s = a[N];
+      _Pragma("unroll") for (int c = k + 1; c < N; c++) if (c < n) s -= a[c] * x[c];
+      const double xk = ba_readlane_d(s / a[k], k);
+      x[k] = xk;
+      if (lane == k) v.E[k] = xk;
+    }
+  }
+  return true;
+}
+
 // pass 1 of Do_LM_Step (jni/Bundle.cc:209-215): project every measurement still in the list; returns this thread's
 // count of valid ones.  Kept out of line (like FindNewError below): the fp64 atan / division sequences of the camera model
 // get their own register allocation instead of inheriting the pressure of the Schur-complement tasks.
@@ -805,7 +864,14 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
       }
       __syncthreads();
       BA_STAMP(7);
-      if (nS > 0 && !(nS <= BA_LDS_N ? ba_block_solve_lds((const double*)v.S, (double*)v.E, nS, lds_A, ired) : ba_block_solve((double*)v.S, (double*)v.E, nS, ired))) { if (threadIdx.x == 0) sh_error = 1; __syncthreads(); break; }
+      bool solved = true;
+      if (nS > 0 && nS <= BA_WSOLVE_N) {                              // one wavefront, registers (the BundleAdjustRecent size)
+        if (wave == 0) { const bool okw = ba_solve_wave(v_, nS); if (lane == 0) ired[0] = okw ? 1 : 0; }
+        __syncthreads();
+        solved = ired[0] != 0;
+        __syncthreads();
+      } else if (nS > 0) solved = nS <= BA_LDS_N ? ba_block_solve_lds((const double*)v.S, (double*)v.E, nS, lds_A, ired) : ba_block_solve((double*)v.S, (double*)v.E, nS, ired);
+      if (!solved) { if (threadIdx.x == 0) sh_error = 1; __syncthreads(); break; }
       for (int t = threadIdx.x; t < nS; t += BA_THREADS) v.cam_up[t] = v.E[t];
       __syncthreads();
       BA_STAMP(8);
