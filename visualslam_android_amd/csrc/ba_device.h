@@ -19,9 +19,10 @@
 #define BA_THREADS 256  // 4 waves; with amdgpu_waves_per_eu(2,2) on the kernel two problems share a CU (measured: 512 x 1 -4 %, 128 x 4 -4 %)
 #define BA_LDS_N 60      // reduced camera systems up to 60 x 60 (10 adjustable cameras) are solved in LDS
 #define BA_WAVES (BA_THREADS / 64)
-#define BA_ILP_PROJ 1   // the two projection passes are bound by fp64 transcendental maths, not by latency: more in flight only spills
+#define BA_ILP_PROJ 4   // projection passes: 4 measurements in flight (1 -> 4: -31 % on FindNewError once the view pointers were global and scalar; 6 spills: 5x slower)
 #define BA_ILP_S 1      // Schur-complement tasks: 36 accumulators + two 6x3 blocks per lane leave no registers for a second point
 #define BA_ILP 4        // independent measurements per thread and loop trip: the loops are memory-latency bound at 2 waves/SIMD
+#define BA_ILP_C 4      // fused weight / derivative pass after an accepted step
 #define BA_ILP_W 8      // pass 2 (weights): 9 operands per measurement, nothing else live
 #define BA_ILP_P 6      // per-point loops over cameras (V, map update): 11 cameras in 2 trips, 5 adjustable ones in 1
 
@@ -391,15 +392,15 @@ __device__ __attribute__((noinline)) double ba_pass12_cached(const BaView& v_, c
   const BaViewG v = ba_g(v_);
   const BaConfig cfg = cfg_;
   double cur = 0.0;
-  for (int i0 = threadIdx.x; i0 < nm; i0 += BA_ILP * BA_THREADS) {
-    int st[BA_ILP]; double c[BA_ILP][3], fac[BA_ILP], e0[BA_ILP], e1[BA_ILP], sn[BA_ILP];
-    _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) {
+  for (int i0 = threadIdx.x; i0 < nm; i0 += BA_ILP_C * BA_THREADS) {
+    int st[BA_ILP_C]; double c[BA_ILP_C][3], fac[BA_ILP_C], e0[BA_ILP_C], e1[BA_ILP_C], sn[BA_ILP_C];
+    _Pragma("unroll") for (int u = 0; u < BA_ILP_C; u++) {
       const int i = i0 + u * BA_THREADS, ic = i < nm ? i : nm - 1;
       st[u] = v.ms_state[ic];
       c[u][0] = MS(ms_tcam, 0, ic); c[u][1] = MS(ms_tcam, 1, ic); c[u][2] = MS(ms_tcam, 2, ic);
       fac[u] = v.ms_tfac[ic]; e0[u] = MS(ms_teps, 0, ic); e1[u] = MS(ms_teps, 1, ic); sn[u] = v.ms_sin[ic];
     }
-    _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) {
+    _Pragma("unroll") for (int u = 0; u < BA_ILP_C; u++) {
       const int i = i0 + u * BA_THREADS;
       if (i >= nm || st[u] == MS_ERASED) continue;
       MS(ms_cam, 0, i) = c[u][0]; MS(ms_cam, 1, i) = c[u][1]; MS(ms_cam, 2, i) = c[u][2];
