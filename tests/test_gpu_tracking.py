@@ -393,3 +393,26 @@ def test_tracking_loss_matches_oracle():
     assert g.state(0).quality == 0 and g.state(0).lost_frames == 3        # the counter stops with the tracking (:100); the per-level counts keep the last tracked frame's values
     assert g.state(1).quality == 2
     g.close()
+
+
+def test_bitwise_determinism_across_runs_and_streams():
+    """Every floating-point reduction of the path has a fixed order (segmented wavefront sums, wave-ordered partials, no
+    fp atomics): two systems fed the same frames, and two streams of one system, end bit-identical -- poses, map points and
+    keyframe poses after tracking, keyframes, the asynchronous bundle adjustment and map growth."""
+    w, h = 320, 240
+    f, m, frames = make_scene(w, h, seed=31, n_frames=30, per_level=(120, 50, 20, 8))
+    outs = []
+    for run in range(2):
+        g = capi.System(capi.default_params(w, h, 2, ba_delay_frames=5, grow_map=3, use_sbi=1))
+        for s in range(2):
+            g.load_map(s, m); g.set_pose(s, f.pose(-1))
+        for t in range(30):
+            g.track_frame(np.stack([frames[t]] * 2))
+        st = [g.state(s) for s in range(2)]
+        outs.append([(np.array(st[s].pose[:]), g.points(s)["pos"].copy(), np.stack([g.keyframe_pose(s, k) for k in range(st[s].n_keyframes)]),
+                      st[s].n_points, st[s].n_ba_trials) for s in range(2)])
+        assert st[0].n_keyframes > 8 and st[0].n_points > len(m["points"])        # keyframes were added and the map grew
+        g.close()
+    for a, b in ((outs[0][0], outs[0][1]), (outs[0][0], outs[1][0]), (outs[0][1], outs[1][1])):
+        assert a[3] == b[3] and a[4] == b[4]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
