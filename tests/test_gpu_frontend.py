@@ -134,3 +134,22 @@ def test_padded_row_and_stream_strides(oracle, on_device):
             assert np.array_equal(g.read_corners(s, l), corners), (s, l)
             assert np.array_equal(g.read_row_lut(s, l), lut), (s, l)
     g.close()
+
+
+def test_fast_symmetries_at_full_size():
+    """Size-independent properties of FAST-10 (jni/vision/cvfast.cpp:6088-9241) checked at 1280x720 without the oracle: the
+    16-pixel ring and the brighter / darker tests are symmetric, so the level-0 corner set of the grey-inverted frame is the
+    same, and that of the mirrored frame is the mirror image (the pyramid's +2 rounding breaks both on the coarser levels)."""
+    w, h = 1280, 720
+    img = synth_image(42, w, h)
+    frames = np.stack([img, 255 - img, img[:, ::-1].copy(), img[::-1, :].copy()])
+    g = run_gpu(frames)
+    c = [g.read_corners(s, 0) for s in range(4)]
+    xy = [set(zip((a & 0xFFFF).tolist(), (a >> 16).tolist())) for a in c]
+    assert len(xy[0]) > 500
+    assert xy[1] == xy[0]
+    assert xy[2] == {(w - 1 - x, y) for (x, y) in xy[0]}
+    assert xy[3] == {(x, h - 1 - y) for (x, y) in xy[0]}
+    for a in c:                                                      # raster order, strictly increasing packed positions
+        assert np.all(np.diff(a.astype(np.int64)) > 0)
+    g.close()
