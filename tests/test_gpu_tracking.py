@@ -416,3 +416,28 @@ def test_bitwise_determinism_across_runs_and_streams():
     for a, b in ((outs[0][0], outs[0][1]), (outs[0][0], outs[1][0]), (outs[0][1], outs[1][1])):
         assert a[3] == b[3] and a[4] == b[4]
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_ragged_batch_map_sizes_and_a_stream_without_a_map():
+    """One batch, three very different sequences: a full map, no map at all (TrackFrame only builds the keyframe,
+    jni/Tracker.cc:141-142) and a map a tenth of the size (so few patches that the per-level counts, the Tukey median and the
+    quality assessment run on short lists).  The two mapped streams follow their oracles; the unmapped one stays untouched."""
+    w, h, n = 320, 240, 6
+    fa, ma, fra = make_scene(w, h, seed=71, n_frames=n, per_level=(120, 50, 20, 8))
+    fc, mc, frc = make_scene(w, h, seed=72, n_frames=n, per_level=(14, 6, 3, 2))
+    g = capi.System(capi.default_params(w, h, 3))
+    g.load_map(0, ma); g.set_pose(0, fa.pose(-1))
+    g.load_map(2, mc); g.set_pose(2, fc.pose(-1))
+    oa = make_oracle(capi.default_params(w, h, 1), ma, fa.pose(-1))
+    oc = make_oracle(capi.default_params(w, h, 1), mc, fc.pose(-1))
+    da, dc = Drift(), Drift()
+    blank = np.zeros((h, w), np.uint8)
+    for t in range(n):
+        g.track_frame(np.stack([fra[t], blank, frc[t]]))
+        oa.track_frame(fra[t]); oc.track_frame(frc[t])
+        compare_frame(oa, g, 0, "full map, frame %d" % t, da)
+        compare_frame(oc, g, 2, "small map, frame %d" % t, dc)
+        s1 = g.state(1)
+        assert s1.frame == t + 1 and s1.n_keyframes == 0 and s1.n_points == 0 and sum(s1.attempted) == 0
+    assert g.state(2).n_points == len(mc["points"]) < 0.2 * len(ma["points"])
+    g.close()
