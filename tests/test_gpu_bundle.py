@@ -88,3 +88,17 @@ def test_edge_cases():
     g.compute()                                                       # only a fixed camera: no unknown camera rows
     assert g.result(1)["accepted"] >= -1
     g.close()
+
+
+@pytest.mark.parametrize("n_cams,n_fixed,n_pts", [(2, 1, 23), (3, 1, 37), (4, 2, 12), (6, 1, 13), (7, 1, 100)])
+def test_window_sizes_around_the_mfma_limit(n_cams, n_fixed, n_pts):
+    # 1, 2 and 5 adjustable cameras take the matrix-core form of the reduced camera system (ba_schur_mfma: point counts that
+    # are not multiples of the 12 points a wavefront stages per trip), 6 the wave-per-block form; all against the oracle
+    sc = ba_scene(n_cams=n_cams, n_pts=n_pts, pixel_noise=0.3, outlier_frac=0.03, seed=40 + n_cams, n_fixed=n_fixed)
+    vp = capi.default_params(640, 480, 1, ba_max_iterations=6)
+    o = orc.OracleBundle(CAM, 640, 480, max_iterations=6)
+    g = capi.Bundle(vp, 1, 8, 128, 1024)
+    load(o, sc); load(g, sc)
+    g.compute()
+    check(o, g, 0, tol=1e-7)
+    g.close()
