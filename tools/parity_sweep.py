@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak check: the frame-by-frame parity of tests/test_gpu_tracking.py over many seeds and configurations
-(python tools/parity_sweep.py [n_seeds]).  Prints one line per run; exits non-zero on the first failure."""
+(python tools/parity_sweep.py [n_seeds] [vga]).  Prints one line per run; exits non-zero on the first failure."""
 import os, sys, itertools
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,11 +10,12 @@ from test_gpu_tracking import compare_frame, Drift
 from visualslam_android_amd import capi
 
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+vga = len(sys.argv) > 2 and sys.argv[2] == "vga"      # 640x480 with the default map density instead of 320x240
 cfgs = [dict(patch_size=8), dict(patch_size=11), dict(patch_size=8, grow_map=3), dict(patch_size=8, use_sbi=1), dict(patch_size=8, ba_delay_frames=7, grow_map=3, use_sbi=1)]
 fails = 0
 for seed, cfg in itertools.product(range(1000, 1000 + n_seeds), cfgs):
-    w, h, n = 320, 240, 34
-    f, m, frames = make_scene(w, h, seed=seed, n_frames=n, per_level=(120, 50, 20, 8))
+    w, h, n = (640, 480, 34) if vga else (320, 240, 34)
+    f, m, frames = make_scene(w, h, seed=seed, n_frames=n) if vga else make_scene(w, h, seed=seed, n_frames=n, per_level=(120, 50, 20, 8))
     g = capi.System(capi.default_params(w, h, 1, **cfg))
     g.load_map(0, m); g.set_pose(0, f.pose(-1))
     o = make_oracle(capi.default_params(w, h, 1, **cfg), m, f.pose(-1))
