@@ -1,7 +1,7 @@
-import sys, ctypes as C; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+import os, sys, ctypes as C; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
 import numpy as np
 from visualslam_android_amd import capi
-capi.load_library('/root/repo/visualslam_android_amd/libvslam_hip_baprof.so')
+capi.load_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'visualslam_android_amd', 'libvslam_hip_baprof.so'))
 from helpers import *
 W,H=640,480
 f,m,frames=make_scene(W,H,n_frames=2)

@@ -1,5 +1,6 @@
+"""Diagnostic: one seed of tools/parity_sweep.py's grow_map = 3 case, every frame printed (python tools/parity_case.py SEED)."""
 import os, sys, traceback
-ROOT = '/root/repo'
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from helpers import make_oracle, make_scene, pose_err
