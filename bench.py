@@ -134,6 +134,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from visualslam_android_amd import capi, feeder
+    if os.environ.get("VSLAM_LIB"):            # diagnostic builds from tools/build_variant.sh (A/B runs on one box)
+        capi.load_library(os.environ["VSLAM_LIB"])
     S, W, H, K, Wm = args.streams, args.width, args.height, args.steps, args.warmup
     T = Wm + K
     nthreads = max(2, min(16, (os.cpu_count() or 8) // max(1, world)))   # set-up threads per rank: the ranks of a node share its cores

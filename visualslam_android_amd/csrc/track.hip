@@ -63,7 +63,12 @@ DEVFN void td_calc_jacobian(const T& td, double* jac) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TRK_THREADS) void k_pvs(MapDev m, TrackParams tp, const double* sbi_rot /* [S][8] or null */) {
+#ifdef VSLAM_PVS_OCC8
+#define VSLAM_PVS_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
+#else
+#define VSLAM_PVS_ATTR
+#endif
+__global__ __launch_bounds__(TRK_THREADS) VSLAM_PVS_ATTR void k_pvs(MapDev m, TrackParams tp, const double* sbi_rot /* [S][8] or null */) {
   const int s = blockIdx.y;
   TrackerState* st = &m.st[s];
   const bool tracking = st->map_good && st->lost_frames < 3;       // jni/Tracker.cc:103-104
