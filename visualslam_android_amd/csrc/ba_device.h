@@ -628,7 +628,9 @@ __device__ __attribute__((noinline)) void ba_task_pair(const BaView& v_, int tas
 // (operand layout: tools/probes/mfma_f64_layout.hip; a = A[l%16][l/16], b = B[l/16][l%16], d[v] = D[l/16+4v][l%16]).
 // Wave partials are added in wave order, the lower triangle is mirrored as the reference mirrors it (:431-434).
 #define BA_MFMA_FREE 5
+#ifndef BA_MFMA_PPC
 #define BA_MFMA_PPC 12                                  // points per wavefront and trip: 12 x 5 cameras = 60 lanes, K = 36
+#endif
 #define BA_MFMA_K (3 * BA_MFMA_PPC)
 #define BA_MFMA_STAGE (4 * BA_MFMA_K * 16)              // doubles per wavefront: Y rows 0-15 / 16-31, W columns 0-15 / 16-31, each [K][16]
 static_assert(BA_MFMA_STAGE >= 32 * 32 && BA_MFMA_K % 4 == 0, "a wavefront's staging area also holds its 32 x 32 partial product");

@@ -588,7 +588,9 @@ __device__ unsigned long long g_pose_prof[16];
 #define POSE_STAMP(id) do { } while (0)
 #endif
 #define POSE_WAVES (POSE_THREADS / 64)
+#ifndef POSE_ILP
 #define POSE_ILP 2
+#endif
 
 struct PoseItem {            // TrackerData fields used by the pose iterations (jni/TrackerData.h:36-66)
   double cam[3], image[2], derivs[4], vfound[2], sqrt_inv_noise;   // the 2x6 Jacobian is re-derived from cam + derivs where used
@@ -717,7 +719,10 @@ DEVFN double kf_linear_dist(const Pose& a, const Pose& b) {
 }
 
 // stage 0: coarse GN iterations (:463-490); stage 1: fine GN iterations + end of TrackMap/TrackFrame.
-__global__ __launch_bounds__(POSE_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pose(MapDev m, TrackParams tp, int stage) {
+#ifndef VSLAM_POSE_WAVES
+#define VSLAM_POSE_WAVES 2
+#endif
+__global__ __launch_bounds__(POSE_THREADS) __attribute__((amdgpu_waves_per_eu(VSLAM_POSE_WAVES, VSLAM_POSE_WAVES))) void k_pose(MapDev m, TrackParams tp, int stage) {
   const int s = blockIdx.x;
   TrackerState* st = &m.st[s];
   if (!(st->map_good && st->lost_frames < 3)) return;
