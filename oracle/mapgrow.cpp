@@ -13,11 +13,12 @@
 
 namespace orc {
 
-// smallest-eigenvalue eigenvector of the symmetric 4x4 matrix S (cyclic Jacobi, fixed number of sweeps)
+// smallest-eigenvalue eigenvector of the symmetric 4x4 matrix S: cyclic Jacobi, at most 16 sweeps, stopping after the sweep
+// that leaves the off-diagonal sum at zero or below 1e-22 of the diagonal sum (further rotations change no bit)
 void smallest_eigvec4(const double Sin[16], double out[4]) {
   double S[16], V[16];
   for (int i = 0; i < 16; i++) { S[i] = Sin[i]; V[i] = (i % 5 == 0) ? 1.0 : 0.0; }
-  for (int sweep = 0; sweep < 16; sweep++)
+  for (int sweep = 0; sweep < 16; sweep++) {
     for (int p = 0; p < 3; p++)
       for (int q = p + 1; q < 4; q++) {
         const double apq = S[p * 4 + q];
@@ -38,6 +39,10 @@ void smallest_eigvec4(const double Sin[16], double out[4]) {
           V[k * 4 + p] = c * vkp - s * vkq; V[k * 4 + q] = s * vkp + c * vkq;
         }
       }
+    const double off = fabs(S[1]) + fabs(S[2]) + fabs(S[3]) + fabs(S[6]) + fabs(S[7]) + fabs(S[11]);
+    const double dia = fabs(S[0]) + fabs(S[5]) + fabs(S[10]) + fabs(S[15]);
+    if (off == 0.0 || off <= 1e-22 * dia) break;
+  }
   int best = 0;
   for (int i = 1; i < 4; i++) if (S[i * 4 + i] < S[best * 4 + best]) best = i;
   for (int k = 0; k < 4; k++) out[k] = V[k * 4 + best];

@@ -12,6 +12,13 @@
 #include "vslam_internal.h"
 
 #define GROW_THREADS 256
+#ifdef VSLAM_BA_PROF
+// Diagnostic build only: clock64() stamps of block 0 / wavefront 0 per stage of k_epipolar (vslam_debug_grow_prof)
+__device__ unsigned long long g_grow_prof[16];
+#define GROW_STAMP(id) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = clock64(); g_grow_prof[id] += t_ - g_grow_prof[15]; g_grow_prof[15] = t_; } } while (0)
+#else
+#define GROW_STAMP(id) do { } while (0)
+#endif
 #define GROW_WAVES (GROW_THREADS / 64)
 #define REFIND_BLOCKS 32
 
@@ -115,11 +122,13 @@ DEVFN bool wave_subpix(const uint8_t* tmpl, const uint8_t* img, int ip, int wl, 
   return false;
 }
 
-// smallest-eigenvalue eigenvector of a symmetric 4x4 matrix: cyclic Jacobi, 16 sweeps (same sequence as the oracle)
+// smallest-eigenvalue eigenvector of a symmetric 4x4 matrix: cyclic Jacobi, the same rotation sequence and the same stopping
+// rule as the oracle (at most 16 sweeps; stop once the off-diagonal sum is zero or below 1e-22 of the diagonal sum: further
+// rotations change no bit -- the fixed 16 sweeps on one lane were 60 % of k_epipolar)
 DEVFN void smallest_eigvec4(const double Sin[16], double out[4]) {
   double S[16], V[16];
   for (int i = 0; i < 16; i++) { S[i] = Sin[i]; V[i] = (i % 5 == 0) ? 1.0 : 0.0; }
-  _Pragma("unroll 1") for (int sweep = 0; sweep < 16; sweep++)
+  _Pragma("unroll 1") for (int sweep = 0; sweep < 16; sweep++) {
     _Pragma("unroll") for (int p = 0; p < 3; p++)
       _Pragma("unroll") for (int q = p + 1; q < 4; q++) {
         const double apq = S[p * 4 + q];
@@ -131,6 +140,10 @@ DEVFN void smallest_eigvec4(const double Sin[16], double out[4]) {
         for (int k = 0; k < 4; k++) { const double a = S[p * 4 + k], b = S[q * 4 + k]; S[p * 4 + k] = c * a - s * b; S[q * 4 + k] = s * a + c * b; }
         for (int k = 0; k < 4; k++) { const double a = V[k * 4 + p], b = V[k * 4 + q]; V[k * 4 + p] = c * a - s * b; V[k * 4 + q] = s * a + c * b; }
       }
+    const double off = fabs(S[1]) + fabs(S[2]) + fabs(S[3]) + fabs(S[6]) + fabs(S[7]) + fabs(S[11]);
+    const double dia = fabs(S[0]) + fabs(S[5]) + fabs(S[10]) + fabs(S[15]);
+    if (off == 0.0 || off <= 1e-22 * dia) break;
+  }
   int best = 0;
   for (int i = 1; i < 4; i++) if (S[i * 4 + i] < S[best * 4 + best]) best = i;
   for (int k = 0; k < 4; k++) out[k] = V[k * 4 + best];
@@ -247,6 +260,9 @@ __global__ __launch_bounds__(GROW_THREADS) __attribute__((amdgpu_waves_per_eu(2,
   const double dMean = m.kf_depth[((size_t)s * K + ksrc) * 2], dSigma = m.kf_depth[((size_t)s * K + ksrc) * 2 + 1];
   uint8_t* tmpl = sh_tmpl[wave];
 
+#ifdef VSLAM_BA_PROF
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_grow_prof[15] = clock64();
+#endif
   for (int c0 = 0; c0 < ncand; c0 += GROW_WAVES) {
     const int ci = c0 + wave;
     bool alive = ci < ncand;
@@ -295,6 +311,7 @@ __global__ __launch_bounds__(GROW_THREADS) __attribute__((amdgpu_waves_per_eu(2,
       const int bord = HALF + 1;
       if (!(ca >= bord && cb >= bord && ca < wl - bord && cb < hl - bord)) { if (alive) why = 4; alive = false; }
     }
+    GROW_STAMP(0);   // geometry
     int tsum = 0, tsumsq = 0;
     if (alive) {
       int sa = 0, sq = 0;
@@ -309,6 +326,7 @@ __global__ __launch_bounds__(GROW_THREADS) __attribute__((amdgpu_waves_per_eu(2,
     GRow<PS> trow;
     _Pragma("unroll") for (int q = 0; q < (PS + 3) / 4; q++) trow.w[q] = 0u;
     if (alive && sub < PS) trow = grow_load_row_lds<PS>(tmpl + sub * PS);
+    GROW_STAMP(1);   // template
     // ---- the target keyframe's corners near the epipolar line, :622-641: filter 64 at a time, score the survivors in order ----
     int nBest = -1, nBestZMSSD = tp.max_ssd + 1;
     if (alive) {
@@ -359,6 +377,7 @@ __global__ __launch_bounds__(GROW_THREADS) __attribute__((amdgpu_waves_per_eu(2,
       }
       if (nBest == -1) { alive = false; why = 5; }
     }
+    GROW_STAMP(2);   // corner filter + ZMSSD
     // ---- MakeSubPixTemplate + SetSubPixPos + IterateSubPixToConvergence(kTarget, 10), :658-664 ----
     double sub0 = 0, sub1 = 0;
     if (alive) {
@@ -367,6 +386,7 @@ __global__ __launch_bounds__(GROW_THREADS) __attribute__((amdgpu_waves_per_eu(2,
       const bool converged = wave_subpix<PS>(tmpl, img_tgt, ip, wl, hl, nLevel, 10, lane, sub0, sub1);
       if (!converged) { alive = false; why = 6; }
     }
+    GROW_STAMP(3);   // sub-pixel
     // ---- triangulation and the new point's patch vectors, :666-702 (lane 0) ----
     if (alive && lane == 0) {
       double uA[2], uB[2], pB[3], pw[3];
@@ -388,8 +408,10 @@ __global__ __launch_bounds__(GROW_THREADS) __attribute__((amdgpu_waves_per_eu(2,
       r.root[0] = root0; r.root[1] = root1; r.sub[0] = sub0; r.sub[1] = sub1; r.irx = ca; r.iry = cb;
       r.ok = 1;
     }
+    GROW_STAMP(4);   // triangulation
     if (lane == 0 && ci < ncand && why) a.cand_score[nLevel][(size_t)s * a.cap[nLevel] + ci] = -(double)why;
     __syncthreads();
+    GROW_STAMP(5);   // waiting for the other wavefronts of the chunk
     // ---- ordered commit: mMap.vpPoints.push_back + the two measurements, :692-701 ----
     if (threadIdx.x == 0) {
       for (int wv = 0; wv < GROW_WAVES; wv++) {
@@ -424,6 +446,7 @@ __global__ __launch_bounds__(GROW_THREADS) __attribute__((amdgpu_waves_per_eu(2,
       }
     }
     __syncthreads();
+    GROW_STAMP(6);   // ordered commit
   }
 }
 
@@ -627,3 +650,12 @@ extern "C" int vslam_get_keyframe_corners(vslam_system* sys, int stream, int key
   if (corners && m > 0) HIPCHK(hipMemcpy(corners, sys->map.kf_corners[level] + slot * sys->tp.kcap[level], (size_t)m * 4, hipMemcpyDeviceToHost));
   return VSLAM_OK;
 }
+
+#ifdef VSLAM_BA_PROF
+extern "C" int vslam_debug_grow_prof(unsigned long long* out16, int reset) {
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_grow_prof), sizeof(unsigned long long) * 16));
+  if (reset) { unsigned long long z[16] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_grow_prof), z, sizeof(z))); }
+  return VSLAM_OK;
+}
+#endif
