@@ -25,3 +25,7 @@ for t in range(26):
         kf += 1
         print('frame %d: keyframe event, k_epipolar block 0 total %.1f kcycles (4 levels), points now %d' % (t, tot / 1e3, g.state(0).n_points))
         for i, n in enumerate(names): print('  %-16s %9.1f kcyc %5.1f%%' % (n, out[i] / 1e3, 100.0 * out[i] / tot))
+        rn = ['loop tail / skipped', 'point + cell loads', 'projection + warp', 'template', 'search + zmssd', 'sub-pixel']
+        rt = sum(out[8 + i] for i in range(6))
+        print('  k_refind block (0,0) wave 0 total %.1f kcycles' % (rt / 1e3))
+        for i, n in enumerate(rn): print('  %-20s %9.1f kcyc %5.1f%%' % (n, out[8 + i] / 1e3, 100.0 * out[8 + i] / max(1, rt)))

@@ -15,8 +15,10 @@
 #ifdef VSLAM_BA_PROF
 // Diagnostic build only: clock64() stamps of block 0 / wavefront 0 per stage of k_epipolar (vslam_debug_grow_prof)
 __device__ unsigned long long g_grow_prof[16];
+#define REFIND_STAMP(id) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { const unsigned long long t_ = clock64(); g_grow_prof[id] += t_ - g_grow_prof[15]; g_grow_prof[15] = t_; } } while (0)
 #define GROW_STAMP(id) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = clock64(); g_grow_prof[id] += t_ - g_grow_prof[15]; g_grow_prof[15] = t_; } } while (0)
 #else
+#define REFIND_STAMP(id) do { } while (0)
 #define GROW_STAMP(id) do { } while (0)
 #endif
 #define GROW_WAVES (GROW_THREADS / 64)
@@ -27,6 +29,7 @@ struct GrowArgs {
   double* cand_score[NLEV];   // a candidate AddPointEpipolar rejects gets its score replaced by -(stage at which it gave up): 1 ray, 2 line,
                               // 3 radius, 4 template border, 5 no corner on the line, 6 sub-pixel, 7 map full (vslam_read_candidates)
   int w[NLEV], h[NLEV], kf_pitch[NLEV]; size_t kf_stride[NLEV];
+  const int* rowlut[NLEV];    // the current frame's row look-up tables [S][h_l + 1] (k_refind searches the new keyframe = this frame)
   double* tgt_implane; int tgt_cap;   // vImplaneCorners of the target keyframe at the level being processed, [S][tgt_cap][2] (k_target_implane)
 };
 
@@ -469,10 +472,15 @@ __global__ __launch_bounds__(GROW_THREADS) void k_refind(MapDev m, TrackParams t
   uint8_t* tmpl = sh_tmpl[wave];
   const Pose Tk = m.kf_pose[(size_t)s * K + ksrc];
   const int npts = st->n_points;
+#ifdef VSLAM_BA_PROF
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_grow_prof[15] = clock64();
+#endif
   for (int pid = blockIdx.x * GROW_WAVES + wave; pid < npts; pid += gridDim.x * GROW_WAVES) {
+    REFIND_STAMP(8);   // previous iteration's tail / skipped points
     MapPointDev& p = m.pts[(size_t)s * P + pid];
     MeasDev& cell = m.kf_meas[((size_t)s * K + ksrc) * P + pid];
     if (p.bad || cell.valid) continue;                               // :971 (and the trash list, jni/Map.cc:16-27)
+    REFIND_STAMP(9);   // point and cell loads
     double c[3];
     pose_xform(Tk, p.pos, c);
     if (c[2] < 0.001) continue;                                      // :979
@@ -495,6 +503,7 @@ __global__ __launch_bounds__(GROW_THREADS) void k_refind(MapDev m, TrackParams t
     int level = 0;
     while (det > 3 && level < NLEV - 1) { level++; det *= 0.25; }
     const int scale = 1 << level;
+    REFIND_STAMP(10);  // projection, derivatives, warp
     // MakeTemplateCoarseCont, :79-125: transform_image with the accumulated stepping of jni/vision/ImageHandler.cpp:21-113
     double inv[4];
     inv2(wi, inv);
@@ -533,9 +542,9 @@ __global__ __launch_bounds__(GROW_THREADS) void k_refind(MapDev m, TrackParams t
     nOutside = wsum_i(nOutside);
     const int tsum = wsum_i(sum), tsumsq = wsum_i(sumsq);
     __builtin_amdgcn_wave_barrier();
+    REFIND_STAMP(11);  // template
     if (nOutside) continue;                                          // TemplateBad, :1004
-    // FindPatchCoarse(v2Image, k, 4), jni/PatchFinder.cc:170-235; the keyframe's corner list is in raster order, the row
-    // look-up table becomes a lower-bound search on the packed (y << 16 | x) positions
+    // FindPatchCoarse(v2Image, k, 4), jni/PatchFinder.cc:170-235
     const int wl = a.w[level], hl = a.h[level], ip = a.kf_pitch[level];
     const uint8_t* img = m.kf_img[level] + ((size_t)s * K + ksrc) * a.kf_stride[level];
     const uint32_t* corners = m.kf_corners[level] + ((size_t)s * K + ksrc) * tp.kcap[level];
@@ -547,11 +556,12 @@ __global__ __launch_bounds__(GROW_THREADS) void k_refind(MapDev m, TrackParams t
     const int nLeft = (int)(irx - nRange), nRight = (int)(irx + nRange);
     if (nTop < 0) nTop = 0;
     if (nTop >= hl || nBottomPlusOne <= 0) continue;
-    int lo = 0, hi = nc;
-    { const uint32_t key = (uint32_t)nTop << 16; while (lo < hi) { const int mid = (lo + hi) >> 1; if (corners[mid] < key) lo = mid + 1; else hi = mid; } }
-    const int i0 = lo;
-    int i1 = nc;
-    if (nBottomPlusOne < hl) { lo = i0; hi = nc; const uint32_t key = (uint32_t)nBottomPlusOne << 16; while (lo < hi) { const int mid = (lo + hi) >> 1; if (corners[mid] < key) lo = mid + 1; else hi = mid; } i1 = lo; }
+    // the new keyframe's corner list is the current frame's (k_copy_kf_corners), so the frame's row look-up table serves
+    // (two loads instead of two binary searches of dependent global loads; indices clamped to the stored list)
+    const int* lut = a.rowlut[level] + (size_t)s * (hl + 1);
+    int i0 = lut[nTop], i1 = nBottomPlusOne >= hl ? nc : lut[nBottomPlusOne];
+    if (i0 > nc) i0 = nc;
+    if (i1 > nc) i1 = nc;
     int bestx = -1, besty = -1, nBest = tp.max_ssd + 1;
     for (int base = i0; base < i1; base += 64) {
       bool ok = false;
@@ -572,10 +582,12 @@ __global__ __launch_bounds__(GROW_THREADS) void k_refind(MapDev m, TrackParams t
         if (ssd < nBest) { bestx = cx; besty = cy; nBest = ssd; }
       }
     }
+    REFIND_STAMP(12);  // corner search + ZMSSD
     if (!(nBest < tp.max_ssd)) continue;                             // :1010
     double sub0 = level_zero_pos((double)bestx, level), sub1 = level_zero_pos((double)besty, level);
     if (level > 0) wave_subpix<PS>(tmpl, img, ip, wl, hl, level, 8, lane, sub0, sub1);   // :1020-1024, convergence not looked at
     __builtin_amdgcn_wave_barrier();
+    REFIND_STAMP(13);  // sub-pixel
     if (lane == 0) {                                                 // :1016-1034
       MeasDev mm;
       mm.valid = 1; mm.level = (signed char)level; mm.subpix = level > 0; mm.source = 1 /* SRC_REFIND */; mm.pad = 0;
@@ -618,6 +630,7 @@ int grow_on_keyframe(vslam_system* sys) {
     a.kf_stride[l] = (size_t)g[l].pitch * g[l].h;
   }
   a.ncand = sys->ncand;
+  for (int l = 0; l < NLEV; l++) a.rowlut[l] = sys->fr.rowlut[l];
   a.tgt_implane = sys->grow_implane; a.tgt_cap = sys->tp.kcap[0];
   if (sys->p.grow_map & 2) {                                             // ReFindInSingleKeyFrame(*pK), jni/MapMaker.cc:497
     if (sys->tp.P == 8) hipLaunchKernelGGL(k_refind<8>, dim3(REFIND_BLOCKS, sys->S), dim3(GROW_THREADS), 0, sys->stream, sys->map, sys->tp, a);
