@@ -516,27 +516,30 @@ __global__ __launch_bounds__(GROW_THREADS) void k_refind(MapDev m, TrackParams t
       const double across[2] = {m2[0], m2[2]}, down[2] = {m2[1], m2[3]};
       double px = (double)p.irx - (m2[0] * HALF + m2[1] * HALF), py = (double)p.iry - (m2[2] * HALF + m2[3] * HALF);
       const double cr[2] = {down[0] - PS * across[0], down[1] - PS * across[1]};
-      if (lane < PS) {
+      // one template pixel per lane (two for 11x11): the lane walks the accumulated sample position to its pixel with exactly
+      // the additions transform_image makes (whole rows with their carriage return, then steps along the row)
+      const float x_bound = (float)(iw - 1), y_bound = (float)(ih - 1);
+      const double px0 = px, py0 = py;
+      for (int q = lane; q < PS * PS; q += 64) {
+        const int r = q / PS, j = q - r * PS;
+        double x = px0, y = py0;
 #pragma unroll 1
-        for (int i = 0; i < lane; i++) {
+        for (int i = 0; i < r; i++) {
 #pragma unroll
-          for (int j = 0; j < PS; j++) { px += across[0]; py += across[1]; }
-          px += cr[0]; py += cr[1];
+          for (int jj = 0; jj < PS; jj++) { x += across[0]; y += across[1]; }
+          x += cr[0]; y += cr[1];
         }
-        const float x_bound = (float)(iw - 1), y_bound = (float)(ih - 1);
-        for (int j = 0; j < PS; j++) {
-          double x = px, y = py;
-          px += across[0]; py += across[1];
-          int v = 0;
-          if (0 <= x && 0 <= y && x < x_bound && y < y_bound) {
-            const int lx = (int)x, ly = (int)y;
-            x -= lx; y -= ly;
-            const uint8_t* q0 = src + (size_t)ly * sp + lx;
-            v = (uint8_t)((1 - y) * ((1 - x) * q0[0] + x * q0[1]) + y * ((1 - x) * q0[sp] + x * q0[sp + 1]));
-          } else nOutside++;
-          tmpl[lane * PS + j] = (uint8_t)v;
-          sum += v; sumsq += v * v;
-        }
+#pragma unroll 1
+        for (int jj = 0; jj < j; jj++) { x += across[0]; y += across[1]; }
+        int v = 0;
+        if (0 <= x && 0 <= y && x < x_bound && y < y_bound) {
+          const int lx = (int)x, ly = (int)y;
+          x -= lx; y -= ly;
+          const uint8_t* q0 = src + (size_t)ly * sp + lx;
+          v = (uint8_t)((1 - y) * ((1 - x) * q0[0] + x * q0[1]) + y * ((1 - x) * q0[sp] + x * q0[sp + 1]));
+        } else nOutside++;
+        tmpl[q] = (uint8_t)v;
+        sum += v; sumsq += v * v;
       }
     }
     nOutside = wsum_i(nOutside);
