@@ -1,37 +1,64 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X PTAM hot path: frames/sec of Tracker::TrackFrame + local bundle adjustment.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no torch.distributed environment, bench.py starts the N ranks itself (python -m torch.distributed.run, one
+rank per GPU over RCCL) and relays rank 0's JSON line; started BY torch.distributed.run (RANK / WORLD_SIZE set) it is one
+of the ranks.  It refuses to run when the world size is not --gpus.
 
 One "step" = one vslam_track_frame over one batch of frames: every one of the S independent sequences (streams) on
-this GPU advances by one 640x480 frame -- MakeKeyFrame_Lite (pyramid + FAST-10), TrackMap (PVS, patch search, 10+10
+this GPU advances by one frame -- MakeKeyFrame_Lite (pyramid + FAST-10), TrackMap (PVS, patch search, 10+10
 Gauss-Newton iterations), and, whenever the tracker asks for a keyframe (every ~21 frames per stream),
 MapMaker::AddKeyFrame + one BundleAdjustRecent, all on device.  Frames are synthetic (seeded feeder) and resident in
-HBM before the timed region.  Sequences shard across GPUs with no data-path collective (weak scaling); RCCL is used only
-to gather the per-rank statistics and the max-over-ranks time.
+HBM before the timed region.  The sequences are independent, so their keyframe phases are spread evenly over the keyframe
+period (--kf-stagger; otherwise all of them would ask for their first keyframe in the same frame and stay in lock-step):
+every step then carries the same mix of work -- S tracked frames and about S / 21 keyframes with their bundle adjustments
+-- and the rate does not depend on where the timed window falls.  Sequences shard across GPUs with no data-path collective
+(weak scaling); RCCL is used only to gather the per-rank statistics and the max-over-ranks time.
 
 Prints ONE JSON line (rank 0) with `roofline` for the dominant kernel (HIP-event time measured live over the timed
-region on the library's own stream) and `cpu_baseline` (the oracle's TrackFrame+BA on one host core, bounded sample).
+region on the library's own streams) and `cpu_baseline` (the oracle's TrackFrame+BA on the host cores, bounded sample).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector (= fp64 matrix) peak, AMD product brief; the guide lists no fp64 figure: 256 CUs x 128 FMA/clk x 2.4 GHz
+KF_PERIOD = 21           # frames between two keyframes of a stream: min_frames_between_kf (20, jni/Tracker.cc:128) + 1
 
 
 def dist_env():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv):
+    """bench.py --gpus N outside torch.distributed.run: start the N ranks (one per GPU) and relay their output.  Runs before
+    anything touches the GPU in this process; the child is a separate process, never an exec."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, env=env)
+    return proc.wait()
 
 
 def aggregate(elapsed_s, stats, world):
@@ -50,54 +77,95 @@ def aggregate(elapsed_s, stats, world):
 
 
 def algorithmic_bytes(stage, S, W, H, P, per_stream):
-    """SURVEY.md 8(d) algorithmic bytes of ONE launch of `stage` over S streams (per-stream averages in per_stream)."""
-    ncorn, npatch, nzm, nfound, ba_m, ba_c, ba_p, ba_trials_per_launch = (per_stream[k] for k in
-        ("corners", "patches", "zmssd", "found", "ba_meas", "ba_cams", "ba_pts", "ba_trials_per_launch"))
+    """SURVEY.md 8(d) algorithmic bytes of ONE launch of `stage` over S streams (per-stream averages in per_stream), formulas
+    unmodified: B_fast = W H (1 + 21/64) + 4 N_c + 4 sum H_l for the whole front end (level re-reads of an unfused FAST pass are
+    implementation overhead and carry no bytes); B_patch = P^2 (N_p + K) + 48 N_p; B_pose = N_found 120 + 216 per iteration;
+    B_ba = M 176 + N_cam 312 + N_pt 168 per LM trial."""
+    ncorn, npatch, nzm, nfound = (per_stream[k] for k in ("corners", "patches", "zmssd", "found"))
     hsum = sum(H >> l for l in range(4))
     b_fast = W * H * (1 + 21.0 / 64.0) + 4 * ncorn + 4 * hsum
     b_patch = P * P * (npatch + nzm) + 48 * npatch
     b_pose = 10 * (nfound * 120 + 216)
-    b_ba = ba_trials_per_launch * (ba_m * 176 + ba_c * 312 + ba_p * 168)
-    table = {"pyr_fast0": W * H * (1 + 21.0 / 64.0) + (W * H) / 8.0, "fast_lvl": W * H * (21.0 / 64.0) * (1 + 1 / 8.0),
-             "compact": 4 * ncorn + 4 * hsum + (W * H * (1 + 21.0 / 64.0)) / 8.0,
-             "search_fine": b_patch, "search_coarse": 0.0, "pose_fine": b_pose, "pose_coarse": 0.0, "ba_compute": b_ba,
-             "fast_stage": b_fast}
+    table = {"front_end": b_fast, "pyr_fast0": W * H * (1 + 21.0 / 64.0), "fast_lvl": 0.0, "compact": 4 * ncorn + 4 * hsum,
+             "search_fine": b_patch, "search_coarse": 0.0, "pose_fine": b_pose, "pose_coarse": 0.0}
     return S * table.get(stage, 0.0)
+
+
+def ba_bytes_per_trial(ps):
+    return ps["ba_meas"] * 176.0 + ps["ba_cams"] * 312.0 + ps["ba_pts"] * 168.0
+
+
+def ba_flops_per_trial(ps):
+    """F_ba = M*780 + sum_pts C(n_free,2)*216 + (6n)^3/3 per LM trial."""
+    n = ps["ba_free"]
+    return ps["ba_meas"] * 780.0 + ps["ba_pts"] * (n * (n - 1) / 2.0) * 216.0 + (6.0 * n) ** 3 / 3.0
 
 
 def baseline_metric():
     """The headline metric exactly as BASELINE.json names it (the file sits beside bench.py and travels with the repository)."""
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "BASELINE.json")) as fh:
+        with open(os.path.join(ROOT, "BASELINE.json")) as fh:
             return json.load(fh)["metric"]
     except (OSError, ValueError, KeyError):
-        return "frames/sec (TrackFrame+local BA) on 640\u00d7480 synthetic, 1/2/4/8 GPU"
+        return "frames/sec (TrackFrame+local BA) on 640×480 synthetic, 1/2/4/8 GPU"
 
 
-def pmc_traffic(kernel, cfg):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*traffic.json), or None.
+def pmc_traffic(kernel):
+    """HBM bytes of `kernel` per unit of its work from the committed rocprofv3 PMC passes (profiles/*traffic*.json), or None.
 
-    bench.py cannot run rocprofv3 on itself; the counters were collected with this same command and configuration
-    (FETCH_SIZE and WRITE_SIZE in separate --pmc passes, kilobytes; FETCH_SIZE doubled as the MI355X guide prescribes for gfx950).
-    """
+    bench.py cannot run rocprofv3 on itself; the counters were collected with this same command (FETCH_SIZE and WRITE_SIZE
+    in separate --pmc passes, kilobytes; FETCH_SIZE doubled as the MI355X guide prescribes for gfx950) and are stored per
+    unit of work (per LM trial of one problem for k_ba_compute, per frame for the front end), so that they can be scaled to
+    the launch mix of THIS run."""
     import glob
-    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*traffic.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
         try:
             with open(f) as fh:
                 t = json.load(fh)
         except (OSError, ValueError):
             continue
-        if t.get("kernel") == kernel and all(cfg.get(k) == v for k, v in t.get("config", {}).items()):
-            return {"bytes_per_launch": round((2.0 * t["fetch_size_kb_per_launch"] + t["write_size_kb_per_launch"]) * 1024.0),
-                    "source": os.path.relpath(f, os.path.dirname(os.path.abspath(__file__)))}
+        if t.get("kernel") == kernel and "bytes_per_unit" in t:
+            return {"bytes_per_unit": float(t["bytes_per_unit"]), "unit": t.get("unit", ""), "source": os.path.relpath(f, ROOT)}
     return None
 
 
-def ba_flops(per_stream):
-    """SURVEY.md 8(d) fp64 flops of ONE k_ba_compute launch per stream: F_ba = M*780 + sum_pts C(n_free,2)*216 + (6n)^3/3 per trial."""
-    n = per_stream["ba_free"]
-    per_trial = per_stream["ba_meas"] * 780.0 + per_stream["ba_pts"] * (n * (n - 1) / 2.0) * 216.0 + (6.0 * n) ** 3 / 3.0
-    return per_stream["ba_trials_per_launch"] * per_trial
+def oracle_corner_fn(gray):
+    """maximal FAST corners per level from the oracle (the CPU legs build their maps without a GPU)"""
+    from oracle import binding as orc
+    out = []
+    for img, c, _lut in orc.make_keyframe_lite(gray, (10, 15, 15, 10)):
+        out.append(orc.nonmax(c, orc.fast_score(img, c, 10)))
+    return out
+
+
+def cpu_worker(job):
+    """One host core: the oracle's TrackFrame + BA over whole synthetic sequences (own seeds, n_frames each, one keyframe with
+    its bundle adjustment per ~21 frames) until the budget is spent; scene set-up is not timed.  Returns (frames, seconds, keyframes)."""
+    vp_kw, seed, W, H, n_frames, budget_s, map_kw = job
+    from oracle import binding as orc
+    from visualslam_android_amd import capi, feeder
+    frames_done, secs, kfs = 0, 0.0, 0
+    while secs < budget_s:
+        f = feeder.Feeder(W, H, seed=seed)
+        seed += 1000
+        m = feeder.build_map(f, oracle_corner_fn, **map_kw)
+        frames = f.render(0, n_frames)
+        vp = capi.default_params(W, H, 1, **vp_kw)
+        o = orc.OracleSystem(orc.params_from_vslam(vp))
+        o.load_map(m)
+        o.set_pose(f.pose(-1))
+        t0 = time.perf_counter()
+        n = 0
+        for t in range(n_frames):
+            o.track_frame(frames[t])
+            n += 1
+            if secs + (time.perf_counter() - t0) > budget_s and n >= KF_PERIOD + 2:
+                break
+        secs += time.perf_counter() - t0
+        frames_done += n
+        kfs += o.state().n_keyframes - len(m["keyframes"])
+        o.close()
+    return frames_done, secs, kfs
 
 
 def main():
@@ -111,9 +179,16 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--patch", type=int, default=8, help="PatchFinder template side (BASELINE configs: 8; reference default 11)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample (per leg)")
     ap.add_argument("--ba-delay", type=int, default=int(os.environ.get("VSLAM_BENCH_BA_DELAY", 16)),
                     help="vslam_params.ba_delay_frames: 0 = synchronous map-maker; D > 0 = Bundle::Compute on its own HIP stream, applied D frames later")
+    ap.add_argument("--ba-batch", type=int, default=int(os.environ.get("VSLAM_BENCH_BA_BATCH", 0)),
+                    help="vslam_params.ba_batch_frames: the keyframes of this many consecutive frames share one Bundle::Compute launch (0 = chosen so that a launch carries about two problems per compute unit)")
+    ap.add_argument("--ba-window", type=int, default=5, help="vslam_params.ba_window (jni/MapMaker.cc:812-820: 5; BASELINE configs[3]: 10)")
+    ap.add_argument("--max-keyframes", type=int, default=32)
+    ap.add_argument("--corners-per-level", type=str, default="", help="map points per pyramid level of the synthetic map, e.g. 1400,420,130,40 (default: the feeder's)")
+    ap.add_argument("--kf-stagger", type=int, default=KF_PERIOD,
+                    help="spread the streams' keyframe phases over this many frames (0: all streams in lock-step, one burst of bundle adjustments per period)")
     ap.add_argument("--use-sbi", type=int, default=int(os.environ.get("VSLAM_BENCH_USE_SBI", 0)),
                     help="vslam_params.use_sbi: 1 = SmallBlurryImage rotation prior in the motion model (the reference's gvnUseSBI)")
     ap.add_argument("--grow-map", type=int, default=int(os.environ.get("VSLAM_BENCH_GROW_MAP", 0)),
@@ -121,17 +196,46 @@ def main():
     ap.add_argument("--diag-kf-dist-mult", type=float, default=None,
                     help="DIAGNOSTIC ONLY (not the metric): overrides vslam_params.max_kf_dist_wiggle_mult, e.g. 1e9 = no keyframes, no BA")
     ap.add_argument("--no-events", action="store_true", help="skip the per-stage HIP events in the timed region")
+    ap.add_argument("--no-flat-out", action="store_true", help="skip the flat-out bundle-adjustment round measured after the timed region")
+    ap.add_argument("--parity-check", type=int, default=1, help="1: compare stream 0's final pose with the oracle run on the same frames")
     args = ap.parse_args()
-    rank, world, local_rank = dist_env()
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
+    stub = os.environ.get("VSLAM_BENCH_STUB") == "1"   # CPU test of the launcher / aggregation path: gloo, no GPU, a stubbed step
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    rank, world, local_rank = dist_env()
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the torch.distributed world has %d ranks" % (args.gpus, world))
+
+    import numpy as np
     import torch
     import torch.distributed as dist
+    if stub:
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        K = args.steps
+        t0 = time.perf_counter()
+        for _ in range(K):
+            time.sleep(0.001 * (1 + rank))
+        elapsed = time.perf_counter() - t0
+        total_t, gathered = aggregate(elapsed, [elapsed, float(args.streams * K)], world)
+        out = None
+        if rank == 0:
+            out = {"metric": baseline_metric(), "value": round(sum(g[1] for g in gathered) / total_t, 2), "unit": "frames/s", "n_gpus": world,
+                   "steps": K, "warmup": args.warmup, "ms_per_step": round(1e3 * total_t / K, 4), "higher_is_better": True, "scaling": "weak",
+                   "vs_baseline": None, "dtype": "f64", "data": "stub", "config": {"workload": "launcher self-test (VSLAM_BENCH_STUB=1): no GPU work"}}
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return out
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: RCCL sees %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
 
     from visualslam_android_amd import capi, feeder
     if os.environ.get("VSLAM_LIB"):            # diagnostic builds from tools/build_variant.sh (A/B runs on one box)
@@ -139,13 +243,15 @@ def main():
     S, W, H, K, Wm = args.streams, args.width, args.height, args.steps, args.warmup
     T = Wm + K
     nthreads = max(2, min(16, (os.cpu_count() or 8) // max(1, world)))   # set-up threads per rank: the ranks of a node share its cores
+    map_kw = {}
+    if args.corners_per_level:
+        map_kw["per_level"] = tuple(int(x) for x in args.corners_per_level.split(","))
 
     # ---- synthetic scenes: one seeded feeder, trajectory and ground-truth map per stream -----------------------------
     t_setup = time.time()
     seeds = [1234 + rank * S + s for s in range(S)]
     with ThreadPoolExecutor(nthreads) as ex:
         feeders = list(ex.map(lambda sd: feeder.Feeder(W, H, seed=sd), seeds))
-    vp = capi.default_params(W, H, S, patch_size=args.patch, device=local_rank)
     fe = capi.System(capi.default_params(W, H, 1, patch_size=args.patch, device=local_rank))   # front-end used to pick map corners
 
     fe_lock = threading.Lock()
@@ -157,12 +263,22 @@ def main():
             return [fe.read_max_corners(0, l)[0] for l in range(4)]
 
     with ThreadPoolExecutor(nthreads) as ex:
-        maps = list(ex.map(lambda f: feeder.build_map(f, corner_fn), feeders))
+        maps = list(ex.map(lambda f: feeder.build_map(f, corner_fn, **map_kw), feeders))
     fe.close()
     NS = max(1, min(args.systems, S))
     assert S % NS == 0, "--streams must be a multiple of --systems"
     Sk = S // NS
-    vpk = capi.default_params(W, H, Sk, patch_size=args.patch, device=local_rank, ba_delay_frames=args.ba_delay, use_sbi=args.use_sbi, grow_map=args.grow_map)
+    ncu = torch.cuda.get_device_properties(local_rank).multi_processor_count
+    stagger = max(0, args.kf_stagger)
+    ba_batch = args.ba_batch
+    if args.ba_delay <= 0:
+        ba_batch = 1
+    elif ba_batch <= 0:                        # about two problems per compute unit per launch, and done well inside the delay window
+        per_frame = Sk / float(stagger) if stagger else float(Sk)
+        ba_batch = int(max(1, min(args.ba_delay - 6, (2 * ncu) // max(1.0, per_frame))))
+    vp_kw = dict(patch_size=args.patch, ba_delay_frames=args.ba_delay, use_sbi=args.use_sbi, grow_map=args.grow_map, ba_window=args.ba_window,
+                 max_keyframes=args.max_keyframes)
+    vpk = capi.default_params(W, H, Sk, device=local_rank, ba_batch_frames=ba_batch, **vp_kw)
     if args.diag_kf_dist_mult is not None:
         vpk.max_kf_dist_wiggle_mult = args.diag_kf_dist_mult
     systems = [capi.System(vpk) for _ in range(NS)]
@@ -174,6 +290,8 @@ def main():
         sy, ls = sys_of(s)
         sy.load_map(ls, maps[s])
         sy.set_pose(ls, feeders[s].pose(-1))
+        if stagger:                            # Tracker::mnLastKeyFrameDropped: stream s asks for its first keyframe in frame 1 + phase
+            sy.set_last_keyframe_dropped(ls, -20 + (s * stagger) // S)
     frames_dev = torch.empty((T, S, H, W), dtype=torch.uint8, device="cuda")
     host_frames0 = None
     with ThreadPoolExecutor(max(1, nthreads // 4)) as ex:
@@ -217,31 +335,16 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
-    stage_ms, nprof = {}, 0
+    stage_ms, stage_n, nprof = {}, {}, 0
     if not args.no_events:
         for sy in systems:                      # per-launch durations: summed over systems, averaged below over launches
             ms, n = sy.profile_end()
+            cnt = sy.profile_launches()
             nprof += n
             for k_, v_ in ms.items():
                 stage_ms[k_] = stage_ms.get(k_, 0.0) + v_
+                stage_n[k_] = stage_n.get(k_, 0) + cnt[k_]
     st1 = [state(s) for s in range(S)]
-
-    # ---- SURVEY 8(f) row 1, outside the timed region: MakeKeyFrame_Rest (non-max + Shi-Tomasi candidates) and
-    #      ThinCandidates of the last frame, all streams; not part of `value` (nothing on the built path consumes them yet)
-    rest_ms = None
-    try:
-        sync_all()
-        t_r = time.perf_counter()
-        reps = 5
-        for _ in range(reps):
-            for sy in systems:
-                sy.make_keyframe_rest(70.0)
-                sy.thin_candidates(-1)
-        sync_all()
-        rest_ms = 1e3 * (time.perf_counter() - t_r) / reps
-        n_cand = [len(systems[0].read_candidates(0, l)[0]) for l in range(4)]
-    except Exception as e:                     # noqa: BLE001 - extra information only
-        n_cand = str(e)
 
     # ---- per-stream workload statistics (for the algorithmic-byte formulas) ---------------------------------------------
     zm = float(np.mean([(b.n_zmssd - a.n_zmssd) / K for a, b in zip(st0, st1)]))
@@ -251,9 +354,36 @@ def main():
     ba_trials = float(np.mean([b.n_ba_trials - a.n_ba_trials for a, b in zip(st0, st1)]))
     good = int(sum(1 for b in st1 if b.quality == 2))
     ncorn = float(len(systems[0].read_corners(0, 0)))
-    bs = systems[0].bundle_stats(0)           # sizes of the last bundle-adjustment problem of stream 0 (all streams alike)
-    per_stream = {"corners": ncorn, "patches": att, "zmssd": zm, "found": fnd, "ba_meas": float(bs["meas"]), "ba_cams": float(bs["cams"]),
-                  "ba_free": float(bs["free_cams"]), "ba_pts": float(bs["points"]), "ba_trials_per_launch": ba_trials / K}
+    bss = [systems[s // Sk].bundle_stats(s % Sk) for s in range(0, S, max(1, S // 64))]   # sizes of the last assembled problems (a sample of streams)
+    bss = [b for b in bss if b["meas"] > 0] or [systems[0].bundle_stats(0)]
+    per_stream = {"corners": ncorn, "patches": att, "zmssd": zm, "found": fnd,
+                  "ba_meas": float(np.mean([b["meas"] for b in bss])), "ba_cams": float(np.mean([b["cams"] for b in bss])),
+                  "ba_free": float(np.mean([b["free_cams"] for b in bss])), "ba_pts": float(np.mean([b["points"] for b in bss])),
+                  "ba_trials_per_problem": float(np.mean([b["trials"] for b in bss]))}
+    ba_launches = max(1, stage_n.get("ba_compute", 0))
+    # LM trials summed over the problems of this GPU that were applied in the window, per k_ba_compute launch of the window
+    trials_per_launch = ba_trials * S / ba_launches
+
+    # ---- a flat-out round of the bundle adjustment: every stream's BundleAdjustRecent in ONE launch, nothing beside it ------
+    flat = None
+    if not args.no_flat_out and args.diag_kf_dist_mult is None:
+        try:
+            sync_all()
+            tr0 = [state(s).n_ba_trials for s in range(S)]
+            t_f = time.perf_counter()
+            for sy in systems:
+                sy.lib.vslam_bundle_adjust_recent(sy.h)
+            sync_all()
+            flat_s = time.perf_counter() - t_f
+            tr1 = [state(s).n_ba_trials for s in range(S)]
+            flat_trials = float(sum(b - a for a, b in zip(tr0, tr1)))
+            fb = flat_trials * ba_bytes_per_trial(per_stream)
+            flat = {"problems": S, "lm_trials": flat_trials, "ms": round(1e3 * flat_s, 3), "algorithmic_bytes": round(fb),
+                    "achieved_GBps": round(fb / flat_s / 1e9, 2), "frac": round(fb / flat_s / 1e9 / HBM_PEAK_GBS, 5),
+                    "fp64_TFLOPs": round(flat_trials * ba_flops_per_trial(per_stream) / flat_s / 1e12, 3),
+                    "timing": "host wall clock around vslam_bundle_adjust_recent + synchronize (assemble + compute + write-back of every stream, one launch each)"}
+        except Exception as e:                 # noqa: BLE001 - extra information only
+            flat = {"error": str(e)}
 
     total_t, gathered = aggregate(elapsed, [elapsed, S * K, zm, att, fnd, kf_adds, ba_trials, good], world)
     frames_total = sum(g[1] for g in gathered)
@@ -265,68 +395,95 @@ def main():
         roof = None
         stages = {}
         if stage_ms:
+            stage_ms["front_end"] = stage_ms.get("pyr_fast0", 0.0) + stage_ms.get("fast_lvl", 0.0) + stage_ms.get("compact", 0.0)
+            stage_n["front_end"] = stage_n.get("pyr_fast0", nprof)
+
+            def stage_bytes(name):
+                if name == "ba_compute":
+                    return trials_per_launch * ba_bytes_per_trial(per_stream)
+                return algorithmic_bytes(name, Sk, W, H, args.patch, per_stream)
+
             for name, ms in stage_ms.items():
-                per_launch_ms = ms / max(1, nprof)
-                ab = algorithmic_bytes(name, Sk, W, H, args.patch, per_stream)
-                stages[name] = {"ms_per_launch": round(per_launch_ms, 5), "algorithmic_GBps": round(ab / (per_launch_ms * 1e-3) / 1e9, 3) if per_launch_ms > 0 and ab > 0 else None}
-            cfg_key = {"streams_per_gpu": S, "patch_size": args.patch, "ba_delay_frames": args.ba_delay, "width": W, "height": H}
+                per_launch_ms = ms / max(1, stage_n.get(name, nprof))
+                ab = stage_bytes(name)
+                stages[name] = {"ms_per_launch": round(per_launch_ms, 5), "launches": stage_n.get(name, nprof),
+                                "algorithmic_GBps": round(ab / (per_launch_ms * 1e-3) / 1e9, 3) if per_launch_ms > 0 and ab > 0 else None}
 
             def roofline_of(name):
-                ms_ = stage_ms[name] / max(1, nprof)
-                ab_ = algorithmic_bytes(name, Sk, W, H, args.patch, per_stream)
-                ach_ = ab_ / (ms_ * 1e-3) / 1e9
+                ms_ = stage_ms[name] / max(1, stage_n.get(name, nprof))
+                ab_ = stage_bytes(name)
+                ach_ = ab_ / (ms_ * 1e-3) / 1e9 if ms_ > 0 else 0.0
                 r_ = {"kernel": name, "bound": "hbm", "achieved": round(ach_, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": round(ach_ / HBM_PEAK_GBS, 6), "traffic": None, "ms_per_launch": round(ms_, 5)}
+                      "frac": round(ach_ / HBM_PEAK_GBS, 6), "traffic": None, "ms_per_launch": round(ms_, 5),
+                      "launches": stage_n.get(name, nprof), "algorithmic_bytes": round(ab_)}
                 if name == "ba_compute":        # supplementary: the same launch against the fp64 vector/matrix peak (78.6 TFLOP/s)
-                    tf = Sk * ba_flops(per_stream) / (ms_ * 1e-3) / 1e12
+                    tf = trials_per_launch * ba_flops_per_trial(per_stream) / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0
                     r_["fp64"] = {"achieved": round(tf, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP64_PEAK_TFLOPS, 5)}
-                tr = pmc_traffic(name, cfg_key)
-                if tr:
-                    r_["traffic"] = tr["bytes_per_launch"]; r_["traffic_source"] = tr["source"]
-                r_["algorithmic_bytes"] = round(ab_)
+                    r_["lm_trials_per_launch"] = round(trials_per_launch, 1)
+                    r_["flat_out_round"] = flat
+                tr = pmc_traffic({"ba_compute": "k_ba_compute", "front_end": "k_front_end"}.get(name, name))
+                if tr:                          # counters per unit of work (profiles/), scaled to this run's launch mix
+                    units = trials_per_launch if name == "ba_compute" else Sk
+                    r_["traffic"] = round(tr["bytes_per_unit"] * units); r_["traffic_source"] = tr["source"]; r_["traffic_unit"] = tr["unit"]
                 return r_
 
-            # the dominant kernel = the largest summed HIP-event time over the timed region among the kernels with a byte model;
-            # k_ba_compute and k_pyr_fast0 are within a few per cent of each other, so the runners-up are listed as well
-            ranked = sorted((n for n in stage_ms if algorithmic_bytes(n, Sk, W, H, args.patch, per_stream) > 0), key=lambda n: -stage_ms[n])
-            roof = roofline_of(ranked[0])
-            roof["others"] = [roofline_of(n) for n in ranked[1:]]
-            roof["problem"] = {k: per_stream[k] for k in ("ba_cams", "ba_free", "ba_pts", "ba_meas", "ba_trials_per_launch")}
-        # ---- CPU baseline: the oracle's TrackFrame + BA on one core over a bounded sample of the same frames -------------
+            # the dominant kernel = the largest summed HIP-event time over the timed region among the kernels with a byte model
+            cands = [n for n in ("ba_compute", "front_end", "search_fine", "pose_fine") if n in stage_ms and stage_bytes(n) > 0]
+            ranked = sorted(cands, key=lambda n: -stage_ms[n])
+            if ranked:
+                roof = roofline_of(ranked[0])
+                roof["others"] = [roofline_of(n) for n in ranked[1:]]
+                roof["problem"] = {k: round(per_stream[k], 1) for k in ("ba_cams", "ba_free", "ba_pts", "ba_meas", "ba_trials_per_problem")}
+        # ---- CPU baseline: the oracle's TrackFrame + BA on the host cores over a bounded sample of the same workload ---------
         from oracle import binding as orc
-        o = orc.OracleSystem(orc.params_from_vslam(vpk))
-        o.load_map(maps[0])
-        o.set_pose(feeders[0].pose(-1))
-        tc = time.perf_counter()
-        n_cpu = 0
-        for t in range(T):
-            o.track_frame(host_frames0[t])
-            n_cpu += 1
-            if time.perf_counter() - tc > args.cpu_seconds:
-                break
-        cpu_s = time.perf_counter() - tc
         pose_diff = None
-        if n_cpu == T:
+        if args.parity_check:
+            # stream 0 keeps the reference's own keyframe schedule (phase 0): the same frames through the oracle end at the same pose
+            vp1 = capi.default_params(W, H, 1, **vp_kw)
+            o = orc.OracleSystem(orc.params_from_vslam(vp1))
+            o.load_map(maps[0])
+            o.set_pose(feeders[0].pose(-1))
+            for t in range(T):
+                o.track_frame(host_frames0[t])
             pose_diff = float(np.abs(np.array(o.state().pose[:]) - np.array(st1[0].pose[:])).max())
+            o.close()
+        n_seq = 400                             # frames per oracle sequence: 19 keyframes, under the 32-keyframe capacity of the device path
+        job = (vp_kw, 900000, W, H, n_seq, args.cpu_seconds, map_kw)
+        n_cpu, cpu_s, cpu_kf = cpu_worker(job)
+        ncores = os.cpu_count() or 1
+        all_cores = None
+        try:                                    # the same on every host core at once (independent sequences, one process each)
+            import multiprocessing as mp
+            with mp.get_context("spawn").Pool(ncores) as pool:
+                t_a = time.perf_counter()
+                res = pool.map(cpu_worker, [(vp_kw, 910000 + c, W, H, n_seq, args.cpu_seconds, map_kw) for c in range(ncores)])
+                wall = time.perf_counter() - t_a
+            all_cores = {"value": round(sum(n / s_ for n, s_, _k in res), 2), "unit": "frames/s", "cores": ncores,
+                         "sample": "%d oracle processes side by side, %d frames in all (own seeds, %d keyframes with their bundle adjustment); sum of the per-process rates; pool wall time %.1f s incl. scene set-up"
+                                   % (ncores, sum(r[0] for r in res), sum(r[2] for r in res), wall)}
+        except Exception as e:                  # noqa: BLE001 - extra information only
+            all_cores = {"error": str(e)}
         out = {
             "metric": baseline_metric(), "value": round(value, 2), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(1e3 * total_t / K, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %dx%d 4-level FAST-10 + %dx%d PatchFinder ZMSSD search, TrackMap pose update, "
-                                   "AddKeyFrame + BundleAdjustRecent on keyframe frames" % (W, H, args.patch, args.patch),
-                       "streams_per_gpu": S, "systems_per_gpu": NS, "ba_delay_frames": args.ba_delay, "use_sbi": args.use_sbi, "grow_map": args.grow_map, "diagnostic_kf_dist_mult": args.diag_kf_dist_mult, "patch_size": args.patch, "corners_l0_per_frame": ncorn,
+            "config": {"workload": "BASELINE configs[%d]: %dx%d 4-level FAST-10 + %dx%d PatchFinder ZMSSD search, TrackMap pose update, "
+                                   "AddKeyFrame + BundleAdjustRecent (%d-keyframe window) on keyframe frames" % (1 if (W, H) == (640, 480) else 3, W, H, args.patch, args.patch, args.ba_window),
+                       "streams_per_gpu": S, "systems_per_gpu": NS, "ba_delay_frames": args.ba_delay, "ba_batch_frames": ba_batch, "ba_window": args.ba_window,
+                       "kf_stagger_frames": stagger, "use_sbi": args.use_sbi, "grow_map": args.grow_map,
+                       "diagnostic_kf_dist_mult": args.diag_kf_dist_mult, "patch_size": args.patch, "corners_l0_per_frame": ncorn,
                        "patches_attempted_per_frame": round(att, 1), "patches_found_per_frame": round(fnd, 1),
-                       "zmssd_evals_per_frame": round(zm, 1), "keyframes_added_per_stream": kf_adds,
-                       "ba_trials_per_stream": ba_trials, "streams_tracking_good": good, "setup_seconds": round(setup_s, 1)},
+                       "zmssd_evals_per_frame": round(zm, 1), "keyframes_per_step": round(kf_adds * S / K, 2),
+                       "keyframes_added_per_stream": round(kf_adds, 3), "ba_trials_per_stream": round(ba_trials, 3),
+                       "streams_tracking_good": good, "setup_seconds": round(setup_s, 1)},
             "roofline": roof,
             "cpu_baseline": {"value": round(n_cpu / cpu_s, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-                             "sample": "oracle TrackFrame+BA on the first %d frames of stream 0 (same frames, same map)" % n_cpu},
+                             "sample": "oracle TrackFrame+BA (oracle/, -O3, one thread) over %d frames of synthetic sequences of the same workload (own seeds; %d keyframes with their bundle adjustment), %.1f s" % (n_cpu, cpu_kf, cpu_s),
+                             "all_cores": all_cores},
             "stages": stages,
             "parity_pose_maxdiff_stream0": pose_diff,
-            "next_rows": {"make_keyframe_rest_plus_thin_ms_per_launch": None if rest_ms is None else round(rest_ms, 4),
-                          "candidates_left_stream0": n_cand},
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

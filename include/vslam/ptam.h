@@ -106,6 +106,11 @@ class MapMaker {
   void RequestReset() {}
   bool ResetDone() { return true; }                                                                    // no spin (survey fact #4)
   int QueueSize() { return 0; }
+  bool NeedNewKeyFrame(KeyFrame&) { int v = 0; vslam_detail::check(vslam_need_new_keyframe(mMap.sys, 0, &v)); return v != 0; }              // :761-773 (the tracker's current frame)
+  bool IsDistanceToNearestKeyFrameExcessive(KeyFrame&) { int v = 0; vslam_detail::check(vslam_distance_to_nearest_keyframe_excessive(mMap.sys, 0, &v)); return v != 0; }   // :1098-1101
+  // :204-376.  The two-view bootstrap (HomographyInit + triangulation + plane alignment) is not built yet: no map is made and the
+  // caller is told so, as the reference tells it when the homography cannot be estimated (:216-220).
+  bool InitFromStereo(KeyFrame&, KeyFrame&, std::vector<std::pair<std::pair<double, double>, std::pair<double, double>>>&, mySE3&) { return false; }
   void BundleAdjustRecent() { vslam_detail::check(vslam_bundle_adjust_recent(mMap.sys)); }             // :801-851
   void BundleAdjustAll() { vslam_detail::check(vslam_bundle_adjust_all(mMap.sys)); }                   // :776-798
   // :393-422, all four levels of the current candidate lists against keyframe nKeyFrame's measurements (< 0: the tracker's)

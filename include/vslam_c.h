@@ -82,6 +82,10 @@ typedef struct vslam_params {
                                       2: ReFindInSingleKeyFrame (:497, 967-1056), so the keyframe also gains measurements of points the
                                          tracker did not measure in it;
                                       3: both, the reference's behaviour; 0 (default): only the tracker's measurements are stored */
+  int ba_batch_frames;             /* asynchronous map-maker only (ba_delay_frames > 0): Bundle::Compute of the keyframes of this many consecutive
+                                      frames is launched together (1 .. ba_delay_frames; 0 = 1).  Independent sequences ask for keyframes in
+                                      different frames; one launch per frame would carry only a few problems.  Does not change any result: a
+                                      keyframe's adjustment is still applied ba_delay_frames frames after the keyframe */
 } vslam_params;
 
 const char* vslam_last_error(void);
@@ -91,6 +95,11 @@ int vslam_default_params(vslam_params* p, int width, int height, int n_streams);
 int vslam_create(const vslam_params* p, vslam_system** out);
 int vslam_destroy(vslam_system* sys);
 int vslam_synchronize(vslam_system* sys);
+/* Self-test hook: the library's own transcendentals (csrc/vslam_libm.h -- the camera model's atan / tan, jni/ATANCamera.h:136-150,
+ * and the sin / cos / asin / acos of SE3 exp and ln, jni/RT.h:134-214, 318-383) over n arguments, on the device or
+ * (on_host != 0) as compiled for the host.  fn: 0 sin, 1 cos, 2 tan, 3 atan, 4 asin, 5 acos, 6 sqrt, 7 reciprocal.  Both sides
+ * must return the same bits: one ulp of difference in a projection flips template pixels (jni/vision/ImageHandler.cpp:12-19). */
+int vslam_eval_transcendental(int fn, int n, const double* x, double* y, int on_host);
 
 /* ---- frame front-end ------------------------------------------------------------------- */
 
@@ -162,8 +171,15 @@ int vslam_map_add_measurement(vslam_system* sys, int stream, int keyframe, int p
 int vslam_map_add_measurements(vslam_system* sys, int stream, int n, const int* keyframe, const int* point,
                                const int* level, const double* root_pos, const int* subpix, const int* source);
 int vslam_map_set_good(vslam_system* sys, int stream);           /* Map::bGood (jni/Map.h:33) */
+/* map editing after the upload (a host-side map-maker, a loaded map, tests that re-synchronise the map to a reference):
+ * MapPoint::v3WorldPos of the points [first, first + n) (pos3: 3n doubles) and KeyFrame::se3CfromW of one keyframe */
+int vslam_map_set_point_positions(vslam_system* sys, int stream, int first, int n, const double* pos3);
+int vslam_map_set_keyframe_pose(vslam_system* sys, int stream, int keyframe, const double pose12[12]);
 int vslam_set_pose(vslam_system* sys, int stream, const double pose12[12]);
 int vslam_set_velocity(vslam_system* sys, int stream, const double v6[6]);
+/* Tracker::mnLastKeyFrameDropped (jni/Tracker.h:118; -20 after Reset, jni/Tracker.cc:59): frame number of the stream's last keyframe;
+ * the tracker asks for the next one more than min_frames_between_kf frames later (jni/Tracker.cc:128) */
+int vslam_set_last_keyframe_dropped(vslam_system* sys, int stream, int frame);
 
 /* ---- tracking ------------------------------------------------------------------------------ */
 
@@ -184,12 +200,33 @@ typedef struct vslam_track_state {
  * Same image arguments as vslam_make_keyframe_lite.  Asynchronous. */
 int vslam_track_frame(vslam_system* sys, const uint8_t* gray, size_t row_stride, size_t stream_stride,
                       int on_device);
+/* Tracker::TrackFrame stage by stage (per-kernel entry points for parity tests and benchmarks).  After
+ * vslam_make_keyframe_lite, on the current frame of every stream:
+ *   vslam_patch_search(sys, 0)  Tracker::ApplyMotionModel (jni/Tracker.cc:781-798), the potentially visible set with
+ *                               TrackerData::Project / PatchFinder::CalcSearchLevelAndWarpMatrix (:369-392), the coarse selection
+ *                               (:399-461) and Tracker::SearchForPoints (:629-674: MakeTemplateCoarseCont, FindPatchCoarse,
+ *                               sub-pixel iterations) of the coarse set;
+ *   vslam_pose_update(sys, 0)   the ten coarse Gauss-Newton iterations (:463-490): CalcJacobian, Tracker::CalcPoseUpdate (:683-774);
+ *   vslam_patch_search(sys, 1)  the fine selection (:493-535) and SearchForPoints of the level-3 points and of the rest;
+ *   vslam_pose_update(sys, 1)   the ten fine iterations (:543-577), measurement export and scene depth (:594-625),
+ *                               UpdateMotionModel (:802-820), AssessTrackingQuality (:832-878), the keyframe decision (:128-132);
+ *   vslam_finish_frame(sys)     MapMaker::AddKeyFrame + BundleAdjustRecent for the streams whose tracker asked for a keyframe.
+ * vslam_track_frame is exactly this sequence.  All asynchronous; the tracker state between two stages is read with
+ * vslam_get_state / vslam_get_point_tracks / vslam_get_template (pose = the tracker's current estimate) . */
+int vslam_patch_search(vslam_system* sys, int stage);
+int vslam_pose_update(vslam_system* sys, int stage);
+int vslam_finish_frame(vslam_system* sys);
 /* the JNI-equivalent per-frame entry: native_update (jni/jni_part.cpp:132-145): host gray image of stream 0..n-1,
  * synchronous; native_touchScreen (:120-124) has no effect once a map exists and is accepted for ABI parity. */
 int vslam_update(vslam_system* sys, const uint8_t* gray, size_t row_stride, size_t stream_stride);
 int vslam_touch(vslam_system* sys);
 
 int vslam_get_state(vslam_system* sys, int stream, vslam_track_state* out);
+/* MapMaker::NeedNewKeyFrame (jni/MapMaker.cc:761-773: distance to the closest keyframe, scaled by the scene depth, against
+ * max_kf_dist_wiggle_mult * mdWiggleScaleDepthNormalized) and MapMaker::IsDistanceToNearestKeyFrameExcessive (:1098-1101: > 10 * wiggle
+ * scale) for the stream's current pose.  The tracker takes both decisions on device; these are the reference's public members. */
+int vslam_need_new_keyframe(vslam_system* sys, int stream, int* need);
+int vslam_distance_to_nearest_keyframe_excessive(vslam_system* sys, int stream, int* excessive);
 /* Tracker::GetMessageForUser (jni/Tracker.cc:880-883): "Tracking Map, quality good. Found: a/b ... Map: nP, nKF" */
 int vslam_get_message(vslam_system* sys, int stream, char* buf, size_t cap);
 /* per map point of a stream (arrays of n_points): TrackerData::bFound/bSearched/nSearchLevel/bDidSubPix,
@@ -208,6 +245,8 @@ int vslam_get_keyframe_measurements(vslam_system* sys, int stream, int keyframe,
                                     double* root_pos, int* source, int cap);
 int vslam_get_template(vslam_system* sys, int stream, int point, uint8_t* tmpl /* P*P */, int* sum, int* sumsq,
                        int* bad);
+/* the same for the points [first, first + n): tmpl n * P * P bytes; sum, sumsq, bad, have n ints each (any may be NULL) */
+int vslam_get_templates(vslam_system* sys, int stream, int first, int n, uint8_t* tmpl, int* sum, int* sumsq, int* bad, int* have);
 /* Size of the last bundle-adjustment problem MapMaker::BundleAdjust (jni/MapMaker.cc:854-960) assembled for the stream:
  * out[0..5] = cameras, adjustable cameras, points, measurements added, LM trials (mnCounter), accepted steps. */
 int vslam_get_bundle_stats(vslam_system* sys, int stream, int out[6]);
@@ -220,6 +259,9 @@ const char* vslam_stage_name(int stage);
 int vslam_profile_begin(vslam_system* sys, int max_frames);
 /* synchronises; stage_ms[VSLAM_N_STAGES] = summed milliseconds over the recorded frames */
 int vslam_profile_end(vslam_system* sys, double* stage_ms, int* n_frames);
+/* launches[VSLAM_N_STAGES] = how many launches of each stage the last vslam_profile_begin/end pair recorded (every frame for all stages
+ * but ba_compute with the asynchronous map-maker, which is launched once per batch of frames) */
+int vslam_profile_launches(vslam_system* sys, int* launches);
 
 /* ---- mapping ------------------------------------------------------------------------------- */
 /* MapMaker::BundleAdjustRecent / BundleAdjustAll (jni/MapMaker.cc:801-851, 776-798) on every stream, followed by

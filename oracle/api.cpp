@@ -45,6 +45,11 @@ void orc_sys_set_velocity(void* sv, const double v6[6]) {
   s->msd_vel = sqrt(ss);
 }
 void orc_sys_track_frame(void* s, const uint8_t* gray, int stride) { ((System*)s)->TrackFrame(gray, stride); }
+// TrackFrame in stages: begin; search 0; pose 0; search 1; pose 1; end (the stages do nothing while there is no map / the tracker is lost)
+void orc_sys_frame_begin(void* s, const uint8_t* gray, int stride) { ((System*)s)->FrameBegin(gray, stride); }
+void orc_sys_search_stage(void* s, int stage) { System* S = (System*)s; if (S->tracked_this_frame) S->SearchStage(stage); }
+void orc_sys_pose_stage(void* s, int stage) { System* S = (System*)s; if (S->tracked_this_frame) S->PoseStage(stage); }
+void orc_sys_frame_end(void* s) { ((System*)s)->FrameEnd(); }
 
 void orc_sys_get_state(void* sv, orc_track_state* o) {
   System* s = (System*)sv;
@@ -95,7 +100,8 @@ int orc_sys_get_keyframe_meas(void* sv, int kf, int* pt, int* level, double* roo
 int orc_sys_get_template(void* sv, int pt, uint8_t* tmpl, int* sum, int* sumsq, int* bad) {
   System* s = (System*)sv;
   const Finder& f = s->pts[pt]->finder;
-  memcpy(tmpl, f.tmpl.data(), f.P * f.P);
+  if ((int)f.tmpl.size() >= f.P * f.P) memcpy(tmpl, f.tmpl.data(), f.P * f.P);   // points the map-maker created have no template until the tracker first searches them
+  else memset(tmpl, 0, f.P * f.P);
   *sum = f.tsum; *sumsq = f.tsumsq; *bad = f.bad;
   return f.have_last;
 }

@@ -205,7 +205,8 @@ class OracleSystem:
         L = lib()
         L.orc_sys_create.restype = C.c_void_p
         for f in ("orc_sys_destroy", "orc_sys_add_meas", "orc_sys_set_map_good", "orc_sys_set_pose", "orc_sys_set_velocity",
-                  "orc_sys_track_frame", "orc_sys_get_state", "orc_sys_get_keyframe_pose"):
+                  "orc_sys_track_frame", "orc_sys_get_state", "orc_sys_get_keyframe_pose", "orc_sys_frame_begin", "orc_sys_search_stage",
+                  "orc_sys_pose_stage", "orc_sys_frame_end"):
             getattr(L, f).restype = None
         self.L = L
         self.p = params
@@ -244,6 +245,20 @@ class OracleSystem:
     def track_frame(self, gray):
         g = np.ascontiguousarray(gray, np.uint8)
         self.L.orc_sys_track_frame(self.h, _p(g), g.shape[1])
+
+    # TrackFrame in stages (jni/Tracker.cc:76-146 cut where the C ABI's stage entry points cut it)
+    def frame_begin(self, gray):
+        g = np.ascontiguousarray(gray, np.uint8)
+        self.L.orc_sys_frame_begin(self.h, _p(g), g.shape[1])
+
+    def search_stage(self, stage):
+        self.L.orc_sys_search_stage(self.h, int(stage))
+
+    def pose_stage(self, stage):
+        self.L.orc_sys_pose_stage(self.h, int(stage))
+
+    def frame_end(self):
+        self.L.orc_sys_frame_end(self.h)
 
     def state(self):
         s = TrackState()
@@ -285,6 +300,18 @@ class OracleSystem:
         s, sq, bad = C.c_int(0), C.c_int(0), C.c_int(0)
         have = self.L.orc_sys_get_template(self.h, pt, _p(t), C.byref(s), C.byref(sq), C.byref(bad))
         return {"tmpl": t.reshape(P, P), "sum": s.value, "sumsq": sq.value, "bad": bad.value, "have": have}
+
+    def templates(self, n=None):
+        """cached warped templates of the first n map points, like capi.System.templates"""
+        n = self.state().n_points if n is None else n
+        P = self.p.patch_size
+        t = np.zeros((n, P, P), np.uint8)
+        s, sq, bad, have = (np.zeros(n, np.int32) for _ in range(4))
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        for i in range(n):
+            have[i] = self.L.orc_sys_get_template(self.h, i, _p(t[i]), C.byref(a), C.byref(b), C.byref(c))
+            s[i], sq[i], bad[i] = a.value, b.value, c.value
+        return {"tmpl": t, "sum": s, "sumsq": sq, "bad": bad, "have": have}
 
     def bundle_adjust_recent(self):
         return self.L.orc_sys_bundle_adjust_recent(self.h)

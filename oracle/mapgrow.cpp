@@ -7,44 +7,65 @@
 //   PatchFinder::MakeTemplateCoarseNoWarp         jni/PatchFinder.cc:130-142
 //   MapMaker::ReFind_Common / ReFindInSingleKeyFrame  jni/MapMaker.cc:967-1056  (grow_map bit 1)
 // Not built (documented in DESIGN.md): ReFindNewlyMade / ReFindFromFailureQueue (run()'s lower-priority jobs).
-// Third-party arithmetic restated (parity unpinned): Eigen::JacobiSVD of the 4x4 triangulation matrix -> smallest
-// eigenvector of A^T A by cyclic Jacobi rotations (the sign of the vector cancels in the projective division).
+// Third-party arithmetic restated (parity unpinned): Eigen::JacobiSVD of the 4x4 triangulation matrix (two-sided Jacobi on A
+// itself, below; the sign of the vector cancels in the projective division).
 #include "ptam_system.hpp"
 
 namespace orc {
 
-// smallest-eigenvalue eigenvector of the symmetric 4x4 matrix S: cyclic Jacobi, at most 16 sweeps, stopping after the sweep
-// that leaves the off-diagonal sum at zero or below 1e-22 of the diagonal sum (further rotations change no bit)
-void smallest_eigvec4(const double Sin[16], double out[4]) {
-  double S[16], V[16];
-  for (int i = 0; i < 16; i++) { S[i] = Sin[i]; V[i] = (i % 5 == 0) ? 1.0 : 0.0; }
-  for (int sweep = 0; sweep < 16; sweep++) {
-    for (int p = 0; p < 3; p++)
-      for (int q = p + 1; q < 4; q++) {
-        const double apq = S[p * 4 + q];
-        if (apq == 0.0) continue;
-        const double theta = (S[q * 4 + q] - S[p * 4 + p]) / (2.0 * apq);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < 4; k++) {                         // S <- S J
-          const double skp = S[k * 4 + p], skq = S[k * 4 + q];
-          S[k * 4 + p] = c * skp - s * skq; S[k * 4 + q] = s * skp + c * skq;
+// Eigen::JacobiSVD of a square real matrix (the 4x4 A of ReprojectPoint, jni/MapMaker.cc:191-192), restated from the
+// published algorithm of Eigen 3.0-3.1 (the reference's Eigen is an un-vendored dependency, version unpinned: PARITY
+// UNPINNED): two-sided Jacobi.  Sweeps over the pairs (p, q), q < p; a pair is rotated while
+// max(|m_pq|, |m_qp|) > 2 eps max(|m_pp|, |m_qq|); the 2x2 step (real_2x2_jacobi_svd) first symmetrises the block with a
+// left rotation rot1 (t = m_pp + m_qq, d = m_qp - m_pq, u = d / t), then diagonalises it with the Jacobi rotation
+// j_right of the symmetric block (JacobiRotation::makeJacobi: tau = (x - z) / (2 |y|), t = 1 / (tau +- sqrt(tau^2 + 1)));
+// j_left = rot1 * j_right^T; m <- j_left m j_right, V <- V j_right.  The singular values are the |m_ii|; JacobiSVD sorts
+// them in decreasing order, so matrixV().col(3) is the column of V of the smallest one.  Eigen iterates until no pair
+// needs a rotation; the cap of 64 sweeps is never reached (4x4 matrices converge in 3-5 sweeps).
+void svd4_smallest_right_vector(const double Ain[16], double out[4]) {
+  double M[16], V[16];
+  for (int i = 0; i < 16; i++) { M[i] = Ain[i]; V[i] = (i % 5 == 0) ? 1.0 : 0.0; }
+  const double precision = 2.0 * 2.220446049250313e-16;
+  for (int sweep = 0; sweep < 64; sweep++) {
+    bool finished = true;
+    for (int p = 1; p < 4; p++)
+      for (int q = 0; q < p; q++) {
+        const double apq = fabs(M[p * 4 + q]), aqp = fabs(M[q * 4 + p]), off = apq > aqp ? apq : aqp;
+        const double app = fabs(M[p * 4 + p]), aqq = fabs(M[q * 4 + q]), dia = app > aqq ? app : aqq;
+        if (!(off > dia * precision)) continue;
+        finished = false;
+        const double m00 = M[p * 4 + p], m01 = M[p * 4 + q], m10 = M[q * 4 + p], m11 = M[q * 4 + q];
+        double c1, s1;                                        // rot1
+        const double t = m00 + m11, d = m10 - m01;
+        if (t == 0.0) { c1 = 0.0; s1 = d > 0.0 ? 1.0 : -1.0; }
+        else { const double u = d / t; c1 = 1.0 / sqrt(1.0 + u * u); s1 = c1 * u; }
+        const double x = c1 * m00 + s1 * m10, y = c1 * m01 + s1 * m11, z = -s1 * m01 + c1 * m11;   // rot1 applied on the left: symmetric [x y; y z]
+        double c2, s2;                                        // j_right = makeJacobi(x, y, z)
+        if (y == 0.0) { c2 = 1.0; s2 = 0.0; }
+        else {
+          const double tau = (x - z) / (2.0 * fabs(y)), w = sqrt(tau * tau + 1.0);
+          const double tt = tau > 0.0 ? 1.0 / (tau + w) : 1.0 / (tau - w);
+          const double sign_t = tt > 0.0 ? 1.0 : -1.0, n = 1.0 / sqrt(tt * tt + 1.0);
+          s2 = -sign_t * (y / fabs(y)) * fabs(tt) * n; c2 = n;
         }
-        for (int k = 0; k < 4; k++) {                         // S <- J^T S
-          const double spk = S[p * 4 + k], sqk = S[q * 4 + k];
-          S[p * 4 + k] = c * spk - s * sqk; S[q * 4 + k] = s * spk + c * sqk;
+        const double cl = c1 * c2 + s1 * s2, sl = s1 * c2 - c1 * s2;   // j_left = rot1 * j_right^T
+        for (int k = 0; k < 4; k++) {                         // m.applyOnTheLeft(p, q, j_left)
+          const double a = M[p * 4 + k], b = M[q * 4 + k];
+          M[p * 4 + k] = cl * a + sl * b; M[q * 4 + k] = -sl * a + cl * b;
         }
-        for (int k = 0; k < 4; k++) {                         // V <- V J
-          const double vkp = V[k * 4 + p], vkq = V[k * 4 + q];
-          V[k * 4 + p] = c * vkp - s * vkq; V[k * 4 + q] = s * vkp + c * vkq;
+        for (int k = 0; k < 4; k++) {                         // m.applyOnTheRight(p, q, j_right)
+          const double a = M[k * 4 + p], b = M[k * 4 + q];
+          M[k * 4 + p] = c2 * a - s2 * b; M[k * 4 + q] = s2 * a + c2 * b;
+        }
+        for (int k = 0; k < 4; k++) {                         // V.applyOnTheRight(p, q, j_right)
+          const double a = V[k * 4 + p], b = V[k * 4 + q];
+          V[k * 4 + p] = c2 * a - s2 * b; V[k * 4 + q] = s2 * a + c2 * b;
         }
       }
-    const double off = fabs(S[1]) + fabs(S[2]) + fabs(S[3]) + fabs(S[6]) + fabs(S[7]) + fabs(S[11]);
-    const double dia = fabs(S[0]) + fabs(S[5]) + fabs(S[10]) + fabs(S[15]);
-    if (off == 0.0 || off <= 1e-22 * dia) break;
+    if (finished) break;
   }
   int best = 0;
-  for (int i = 1; i < 4; i++) if (S[i * 4 + i] < S[best * 4 + best]) best = i;
+  for (int i = 1; i < 4; i++) if (fabs(M[i * 4 + i]) < fabs(M[best * 4 + best])) best = i;
   for (int k = 0; k < 4; k++) out[k] = V[k * 4 + best];
 }
 
@@ -54,10 +75,8 @@ V3 reproject_point(const SE3& AfromB, const double v2A[2], const double v2B[2]) 
   for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) PD[r * 4 + c] = AfromB.R[r * 3 + c]; PD[r * 4 + 3] = AfromB.t[r]; }
   double A[16] = {-1.0, 0.0, v2B[0], 0.0, 0.0, -1.0, v2B[1], 0.0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int c = 0; c < 4; c++) { A[8 + c] = v2A[0] * PD[8 + c] - PD[0 + c]; A[12 + c] = v2A[1] * PD[8 + c] - PD[4 + c]; }
-  double S[16];
-  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { double s = 0; for (int k = 0; k < 4; k++) s += A[k * 4 + i] * A[k * 4 + j]; S[i * 4 + j] = s; }
   double v[4];
-  smallest_eigvec4(S, v);
+  svd4_smallest_right_vector(A, v);                            // svd.matrixV().block(0, 3, 4, 1)
   if (v[3] == 0.0) v[3] = 0.00001;
   return v3(v[0] / v[3], v[1] / v[3], v[2] / v[3]);
 }

@@ -116,6 +116,13 @@ void orc_sys_set_map_good(void* sys);
 void orc_sys_set_pose(void* sys, const double pose12[12]);
 void orc_sys_set_velocity(void* sys, const double v6[6]);
 void orc_sys_track_frame(void* sys, const uint8_t* gray, int stride);   /* Tracker::TrackFrame, jni/Tracker.cc:76-146 */
+/* the same in stages: frame_begin (MakeKeyFrame_Lite, motion model); search_stage(0) = PVS + coarse selection + SearchForPoints (:369-461);
+ * pose_stage(0) = the coarse Gauss-Newton iterations (:463-490); search_stage(1) = fine selection + SearchForPoints (:493-535);
+ * pose_stage(1) = the fine iterations + measurement export + scene depth (:543-625); frame_end = motion model, quality, keyframe (:107-132) */
+void orc_sys_frame_begin(void* sys, const uint8_t* gray, int stride);
+void orc_sys_search_stage(void* sys, int stage);
+void orc_sys_pose_stage(void* sys, int stage);
+void orc_sys_frame_end(void* sys);
 void orc_sys_get_state(void* sys, orc_track_state* out);
 /* per map point: found flag, searched flag, search level, did-subpix, found position (L0), projected position */
 int orc_sys_get_point_tracks(void* sys, int* found, int* searched, int* level, int* subpix, double* vfound, double* image, int cap);

@@ -138,6 +138,10 @@ struct System {
   // Tracker (jni/Tracker.cc)
   void TrackFrame(const uint8_t* gray, int stride);
   void TrackMap();
+  // TrackFrame in stages (same statements, same order): FrameBegin; SearchStage(0); PoseStage(0); SearchStage(1); PoseStage(1); FrameEnd
+  void FrameBegin(const uint8_t* gray, int stride); void FrameEnd(); void SearchStage(int stage); void PoseStage(int stage);
+  bool Tracking() const { return map_good && lost_frames < 3; }
+  std::vector<int> tm_pvs[4], tm_next, tm_iter; bool tm_coarse_tried = false; unsigned tm_coarse_found = 0; bool tracked_this_frame = false;
   int SearchForPoints(std::vector<int>& v, int range, int subpix_its);
   void CalcPoseUpdate(const std::vector<int>& v, double override_sigma, bool mark_outliers, double out[6]);
   void ApplyMotionModel(); void UpdateMotionModel(); void AssessTrackingQuality();
@@ -166,7 +170,7 @@ void make_keyframe_lite(KeyFrame& k, const uint8_t* gray, int w, int h, int stri
 void make_keyframe_rest_nonmax(KeyFrame& k, int barrier, bool quirk);
 void make_keyframe_rest_candidates(KeyFrame& k, double min_score);
 V3 reproject_point(const SE3& AfromB, const double v2A[2], const double v2B[2]);
-void smallest_eigvec4(const double S[16], double out[4]);
+void svd4_smallest_right_vector(const double A[16], double out[4]);
 
 // PatchFinder pieces exposed for unit tests
 int transform_image(const uint8_t* in, int iw, int ih, int istride, uint8_t* out, int P, const double M[4],

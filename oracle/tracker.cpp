@@ -126,6 +126,15 @@ static void td_linear_update(MapPoint& td, const double v6[6]) {
 // ---- Tracker -----------------------------------------------------------------------------------------------------
 void System::TrackFrame(const uint8_t* gray, int stride) {
   // jni/Tracker.cc:76-146
+  FrameBegin(gray, stride);
+  if (tracked_this_frame) TrackMap();
+  FrameEnd();
+}
+
+// TrackFrame in pieces (the stage entry points of the C ABI, vslam_patch_search / vslam_pose_update, are compared against these):
+// FrameBegin = :76-105 + ApplyMotionModel; TrackMap = SearchStage(0), PoseStage(0), SearchStage(1), PoseStage(1);
+// FrameEnd = UpdateMotionModel, AssessTrackingQuality and the keyframe decision (:107-132).
+void System::FrameBegin(const uint8_t* gray, int stride) {
   kf_added_this_frame = false;
   if (pending && --pending->countdown == 0) { ApplyBundle(*pending); delete pending; pending = nullptr; HandleBadPoints(); }   // deferred map-maker results
   cur.meas.clear();
@@ -141,20 +150,21 @@ void System::TrackFrame(const uint8_t* gray, int stride) {
     }
   }
   frame++;
-  if (map_good) {
-    if (lost_frames < 3) {
-      if (p.use_sbi) calc_sbi_rotation(sbi_this, sbi_last, camera, (p.quirks & ORC_Q_CAM_INT_RADIUS) != 0, sbi_rot, &sbi_score);   // :104-105
-      ApplyMotionModel();
-      TrackMap();
-      UpdateMotionModel();
-      AssessTrackingQuality();
-      if (quality == 2 && NeedNewKeyFrame() && frame - last_kf_dropped > p.min_frames_between_kf) {   // :128-132
-        AddKeyFrame();                     // Tracker::AddNewKeyFrame :823-827
-        last_kf_dropped = frame;
-        kf_added_this_frame = true;
-      }
-    }
-    // else: AttemptRecovery (relocaliser) is out of scope
+  if (Tracking()) {
+    if (p.use_sbi) calc_sbi_rotation(sbi_this, sbi_last, camera, (p.quirks & ORC_Q_CAM_INT_RADIUS) != 0, sbi_rot, &sbi_score);   // :104-105
+    ApplyMotionModel();
+  }
+  tracked_this_frame = Tracking();
+}
+
+void System::FrameEnd() {
+  if (!tracked_this_frame) return;           // no map, or lost: AttemptRecovery (relocaliser) is out of scope
+  UpdateMotionModel();
+  AssessTrackingQuality();
+  if (quality == 2 && NeedNewKeyFrame() && frame - last_kf_dropped > p.min_frames_between_kf) {   // :128-132
+    AddKeyFrame();                     // Tracker::AddNewKeyFrame :823-827
+    last_kf_dropped = frame;
+    kf_added_this_frame = true;
   }
 }
 
@@ -267,55 +277,59 @@ void System::CalcPoseUpdate(const std::vector<int>& vTD, double dOverrideSigma, 
 
 void System::TrackMap() {
   // jni/Tracker.cc:358-626
-  for (int i = 0; i < 4; i++) attempted[i] = found[i] = 0;
-  std::vector<int> avPVS[4];
-  for (size_t i = 0; i < pts.size(); i++) {         // :369-392
-    MapPoint& TD = *pts[i];
-    if (TD.bad) continue;                           // bad points live in the trash list (jni/Map.cc:16-27)
-    Camera::Proj pr; bool projected;
-    td_project(TD, pose, camera, pr, projected);
-    if (!TD.in_image) continue;
-    camera.derivs(pr, TD.derivs);                   // GetDerivsUnsafe
-    TD.search_level = finder_calc_level_and_warp(TD.finder, TD, pose, TD.derivs);
-    if (TD.search_level == -1) continue;
-    TD.searched = false; TD.found = false;
-    avPVS[TD.search_level].push_back((int)i);
-  }
-  // :396-397 random_shuffle -> identity permutation
-  std::vector<int> vNext, vIter;
-  unsigned nCoarseMax = p.coarse_max, nCoarseRange = p.coarse_range;
-  did_coarse = false;
-  bool bTryCoarse = true;
-  if (p.coarse_disabled || msd_vel < p.coarse_min_vel || nCoarseMax == 0) bTryCoarse = false;
-  if (just_recovered) { bTryCoarse = true; nCoarseMax *= 2; nCoarseRange *= 2; just_recovered = false; }
-  if (bTryCoarse && avPVS[3].size() + avPVS[2].size() > (unsigned)p.coarse_min) {   // :437-491
-    if (avPVS[3].size() <= nCoarseMax) { vNext = avPVS[3]; avPVS[3].clear(); }
-    else {
-      for (unsigned i = 0; i < nCoarseMax; i++) vNext.push_back(avPVS[3][i]);
-      avPVS[3].erase(avPVS[3].begin(), avPVS[3].begin() + nCoarseMax);
+  SearchStage(0); PoseStage(0); SearchStage(1); PoseStage(1);
+}
+
+void System::SearchStage(int stage) {
+  if (stage == 0) {
+    for (int i = 0; i < 4; i++) attempted[i] = found[i] = 0;
+    for (int l = 0; l < 4; l++) tm_pvs[l].clear();
+    std::vector<int>* avPVS = tm_pvs;
+    for (size_t i = 0; i < pts.size(); i++) {         // :369-392
+      MapPoint& TD = *pts[i];
+      if (TD.bad) continue;                           // bad points live in the trash list (jni/Map.cc:16-27)
+      Camera::Proj pr; bool projected;
+      td_project(TD, pose, camera, pr, projected);
+      if (!TD.in_image) continue;
+      camera.derivs(pr, TD.derivs);                   // GetDerivsUnsafe
+      TD.search_level = finder_calc_level_and_warp(TD.finder, TD, pose, TD.derivs);
+      if (TD.search_level == -1) continue;
+      TD.searched = false; TD.found = false;
+      avPVS[TD.search_level].push_back((int)i);
     }
-    if (vNext.size() < nCoarseMax) {
-      const unsigned more = nCoarseMax - vNext.size();
-      if (avPVS[2].size() <= more) { vNext = avPVS[2]; avPVS[2].clear(); }   // :454-456 replaces, not appends (PTAM bug kept)
+    // :396-397 random_shuffle -> identity permutation
+    tm_next.clear(); tm_iter.clear();
+    std::vector<int>& vNext = tm_next;
+    unsigned nCoarseMax = p.coarse_max, nCoarseRange = p.coarse_range;
+    did_coarse = false;
+    tm_coarse_tried = false; tm_coarse_found = 0;
+    bool bTryCoarse = true;
+    if (p.coarse_disabled || msd_vel < p.coarse_min_vel || nCoarseMax == 0) bTryCoarse = false;
+    if (just_recovered) { bTryCoarse = true; nCoarseMax *= 2; nCoarseRange *= 2; just_recovered = false; }
+    if (bTryCoarse && avPVS[3].size() + avPVS[2].size() > (unsigned)p.coarse_min) {   // :437-491
+      if (avPVS[3].size() <= nCoarseMax) { vNext = avPVS[3]; avPVS[3].clear(); }
       else {
-        for (unsigned i = 0; i < more; i++) vNext.push_back(avPVS[2][i]);
-        avPVS[2].erase(avPVS[2].begin(), avPVS[2].begin() + more);
+        for (unsigned i = 0; i < nCoarseMax; i++) vNext.push_back(avPVS[3][i]);
+        avPVS[3].erase(avPVS[3].begin(), avPVS[3].begin() + nCoarseMax);
       }
-    }
-    const unsigned nFound = SearchForPoints(vNext, nCoarseRange, p.coarse_subpix_its);
-    vIter = vNext;
-    if (nFound >= (unsigned)p.coarse_min) {
-      did_coarse = true;
-      for (int iter = 0; iter < 10; iter++) {
-        if (iter != 0) for (int i : vIter) if (pts[i]->found) td_project_and_derivs(*pts[i], pose, camera);
-        for (int i : vIter) if (pts[i]->found) td_calc_jacobian(*pts[i]);
-        double up[6];
-        CalcPoseUpdate(vIter, iter > 5 ? 1.0 : 0.0, false, up);
-        pose = mul(se3_exp(up), pose);
+      if (vNext.size() < nCoarseMax) {
+        const unsigned more = nCoarseMax - vNext.size();
+        if (avPVS[2].size() <= more) { vNext = avPVS[2]; avPVS[2].clear(); }   // :454-456 replaces, not appends (PTAM bug kept)
+        else {
+          for (unsigned i = 0; i < more; i++) vNext.push_back(avPVS[2][i]);
+          avPVS[2].erase(avPVS[2].begin(), avPVS[2].begin() + more);
+        }
       }
+      tm_coarse_found = SearchForPoints(vNext, nCoarseRange, p.coarse_subpix_its);
+      tm_iter = vNext;
+      tm_coarse_tried = true;
     }
+    return;
   }
-  int nFineRange = did_coarse ? 5 : 10;   // :495-497
+  std::vector<int>* avPVS = tm_pvs;
+  std::vector<int>& vNext = tm_next;
+  std::vector<int>& vIter = tm_iter;
+  const int nFineRange = did_coarse ? 5 : 10;   // :495-497
   {
     const int l = 3;                      // :501-508
     for (int i : avPVS[l]) td_project_and_derivs(*pts[i], pose, camera);
@@ -330,6 +344,22 @@ void System::TrackMap() {
   if (did_coarse) for (int i : vNext) td_project_and_derivs(*pts[i], pose, camera);
   SearchForPoints(vNext, nFineRange, 0);
   for (int i : vNext) vIter.push_back(i);
+}
+
+void System::PoseStage(int stage) {
+  std::vector<int>& vIter = tm_iter;
+  if (stage == 0) {
+    if (!tm_coarse_tried || tm_coarse_found < (unsigned)p.coarse_min) return;   // :465
+    did_coarse = true;
+    for (int iter = 0; iter < 10; iter++) {
+      if (iter != 0) for (int i : vIter) if (pts[i]->found) td_project_and_derivs(*pts[i], pose, camera);
+      for (int i : vIter) if (pts[i]->found) td_calc_jacobian(*pts[i]);
+      double up[6];
+      CalcPoseUpdate(vIter, iter > 5 ? 1.0 : 0.0, false, up);
+      pose = mul(se3_exp(up), pose);
+    }
+    return;
+  }
   double last_up[6] = {0, 0, 0, 0, 0, 0};
   for (int iter = 0; iter < 10; iter++) {   // :543-577
     const bool nonlinear = (iter == 0 || iter == 4 || iter == 9);

@@ -44,6 +44,40 @@ def test_aggregate_single_process():
     sys.path.insert(0, ROOT)
     import bench
     assert bench.aggregate(0.5, [1, 2], 1) == (0.5, [[1, 2]])
-    b = bench.algorithmic_bytes("fast_stage", 2, 640, 480, 8, {"corners": 1000, "patches": 0, "zmssd": 0, "found": 0, "ba_meas": 0,
-                                                               "ba_cams": 0, "ba_pts": 0, "ba_trials_per_launch": 0})
-    assert b == 2 * 415600                                        # 408,000 + 4,000 + 3,600 per frame
+    ps = {"corners": 1000, "patches": 1000, "zmssd": 8000, "found": 500, "ba_meas": 1500, "ba_cams": 5, "ba_free": 4, "ba_pts": 300}
+    assert bench.algorithmic_bytes("front_end", 2, 640, 480, 8, ps) == 2 * 415600     # 408,000 + 4,000 + 3,600 per frame
+    assert bench.algorithmic_bytes("search_fine", 1, 640, 480, 8, ps) == 624000      # 8(d) example: P = 8, N_p = 1000, K = 8 per patch
+    assert bench.ba_bytes_per_trial(ps) == 315960                                     # 8(d) config 3: 1500 * 176 + 5 * 312 + 300 * 168 (quoted there as 316,000)
+    assert abs(bench.ba_flops_per_trial(ps) - 1.56e6) < 0.01e6                        # ~1.56 MFLOP per trial
+
+
+def _run_bench(args, env_extra):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    return out, [json.loads(l) for l in lines]
+
+
+def test_gpus_n_starts_n_ranks_itself():
+    """`python bench.py --gpus 2` with no torch.distributed environment: bench.py starts the two ranks (torch.distributed.run),
+    they rendezvous (gloo here: VSLAM_BENCH_STUB=1 replaces the GPU step by a sleep), and rank 0's ONE line says n_gpus 2 with
+    the whole-job value = all ranks' frames / the slowest rank's time."""
+    out, lines = _run_bench(["--gpus", "2", "--steps", "20", "--warmup", "1", "--streams", "10"], {"VSLAM_BENCH_STUB": "1"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["data"] == "stub"
+    assert abs(d["value"] - 2 * 10 * 20 / (d["ms_per_step"] * 20e-3)) < 0.01 * d["value"]
+    assert d["ms_per_step"] >= 2.0                                  # rank 1 sleeps 2 ms per step: the max over ranks counts
+
+
+def test_world_size_must_equal_gpus():
+    """Started with a world of one while --gpus says 2 (what a broken launcher would do): refuse, do not report n_gpus 1."""
+    out, lines = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "0"], {"VSLAM_BENCH_STUB": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert out.returncode != 0 and not lines
+    assert "--gpus 2" in (out.stderr + out.stdout)

@@ -37,7 +37,7 @@ def test_make_from_keyframe_properties():
 def test_rotation_prior_known_answers():
     l3 = smooth_image(seed=9)
     r, score = orc.sbi_rotation(l3, l3, REF_CAM)
-    assert np.abs(r).max() == 0.0 and score == 0.0                        # identical frames: no motion
+    assert np.abs(r).max() < 1e-15 and score == 0.0                       # identical frames: no motion (project/unproject round trips are not the identity in the last bit)
     # the current frame shows the scene shifted by +2 level-3 pixels in x: with
     # this = last(x + t) the ESM translation is -t/2 small-image pixels and the equivalent camera rotation is about the y axis
     y, x = np.mgrid[0:60, 0:80]

@@ -38,7 +38,8 @@ def test_quirk_cam_int_radius_disables_tracking():
 
 
 def test_reproject_point_recovers_a_known_point():
-    """MapMaker::ReprojectPoint (jni/MapMaker.cc:174-200) on exact projections; the 4x4 SVD is restated as a Jacobi eigen-solve."""
+    """MapMaker::ReprojectPoint (jni/MapMaker.cc:174-200) on exact projections; Eigen::JacobiSVD of the 4x4 A is restated as
+    the two-sided Jacobi SVD of A itself (parity unpinned: the reference's Eigen is not vendored)."""
     from oracle import binding as orc
     rng = np.random.default_rng(3)
     for _ in range(20):
@@ -49,6 +50,28 @@ def test_reproject_point_recovers_a_known_point():
         XA = R @ XB + t
         got = orc.reproject_point(T, XA[:2] / XA[2], XB[:2] / XB[2])
         assert np.abs(got - XB).max() < 1e-9
+
+
+def test_reproject_point_small_baseline_and_numpy_svd():
+    """Known answers for the restated JacobiSVD: (1) low-parallax pairs (baseline 1e-3 .. 1e-5 of the depth), where an
+    eigen-solve of A^T A would square the condition number, still return the point to the accuracy the geometry allows;
+    (2) on random and on triangulation matrices the chosen vector is numpy's last right singular vector (LAPACK) up to sign."""
+    from oracle import binding as orc
+    rng = np.random.default_rng(11)
+    for base in (1e-3, 1e-4, 1e-5):
+        for _ in range(10):
+            T = orc.se3_exp(np.concatenate([rng.normal(0, 1.0, 3) * base, rng.normal(0, 0.3, 3) * base]))
+            R, t = np.array(T[:9]).reshape(3, 3), np.array(T[9:])
+            XB = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(1.0, 3.0)])
+            XA = R @ XB + t
+            vA, vB = XA[:2] / XA[2], XB[:2] / XB[2]
+            got = orc.reproject_point(T, vA, vB)
+            A = np.zeros((4, 4)); PD = np.hstack([R, t[:, None]])
+            A[0] = [-1, 0, vB[0], 0]; A[1] = [0, -1, vB[1], 0]; A[2] = vA[0] * PD[2] - PD[0]; A[3] = vA[1] * PD[2] - PD[1]
+            v = np.linalg.svd(A)[2][-1]
+            want = v[:3] / v[3]
+            assert np.abs(got - want).max() < 1e-6 * max(1.0, 1e-4 / base), (base, got, want)    # the two SVDs agree far inside the geometric error
+            assert np.abs(got - XB).max() < 2e-11 / base ** 1.0 * 10, (base, got, XB)            # error ~ eps * depth / parallax
 
 
 def test_map_growth_adds_points_on_the_scene_plane():

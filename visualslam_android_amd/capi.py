@@ -32,7 +32,7 @@ class Params(C.Structure):
         ("wiggle_scale", C.c_double), ("ba_max_iterations", C.c_int), ("ba_convergence_limit", C.c_double),
         ("ba_min_tukey_sigma", C.c_double), ("ba_window", C.c_int), ("ba_min_keyframes", C.c_int),
         ("cam", C.c_double * 5), ("quirks", C.c_int), ("device", C.c_int), ("ba_delay_frames", C.c_int),
-        ("grow_map", C.c_int),
+        ("grow_map", C.c_int), ("ba_batch_frames", C.c_int),
     ]
 
 
@@ -58,6 +58,7 @@ SYMBOLS = {
     "vslam_create": (_i, [C.POINTER(Params), C.POINTER(_sys)]),
     "vslam_destroy": (_i, [_sys]),
     "vslam_synchronize": (_i, [_sys]),
+    "vslam_eval_transcendental": (_i, [_i, _i, _vp, _vp, _i]),
     "vslam_make_keyframe_lite": (_i, [_sys, _vp, _sz, _sz, _i]),
     "vslam_fast_nonmax": (_i, [_sys]),
     "vslam_read_level_image": (_i, [_sys, _i, _i, _vp, _sz]),
@@ -80,11 +81,19 @@ SYMBOLS = {
     "vslam_map_set_good": (_i, [_sys, _i]),
     "vslam_set_pose": (_i, [_sys, _i, _vp]),
     "vslam_set_velocity": (_i, [_sys, _i, _vp]),
+    "vslam_set_last_keyframe_dropped": (_i, [_sys, _i, _i]),
     "vslam_track_frame": (_i, [_sys, _vp, _sz, _sz, _i]),
     "vslam_update": (_i, [_sys, _vp, _sz, _sz]),
+    "vslam_patch_search": (_i, [_sys, _i]),
+    "vslam_pose_update": (_i, [_sys, _i]),
+    "vslam_finish_frame": (_i, [_sys]),
+    "vslam_map_set_point_positions": (_i, [_sys, _i, _i, _i, _vp]),
+    "vslam_map_set_keyframe_pose": (_i, [_sys, _i, _i, _vp]),
     "vslam_touch": (_i, [_sys]),
     "vslam_get_state": (_i, [_sys, _i, C.POINTER(TrackState)]),
     "vslam_get_message": (_i, [_sys, _i, C.c_char_p, _sz]),
+    "vslam_need_new_keyframe": (_i, [_sys, _i, _ip]),
+    "vslam_distance_to_nearest_keyframe_excessive": (_i, [_sys, _i, _ip]),
     "vslam_get_point_tracks": (_i, [_sys, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "vslam_get_points": (_i, [_sys, _i, _vp, _vp, _vp, _vp, _i]),
     "vslam_get_keyframe_pose": (_i, [_sys, _i, _i, _vp]),
@@ -92,9 +101,11 @@ SYMBOLS = {
     "vslam_get_bundle_stats": (_i, [_sys, _i, _vp]),
     "vslam_get_keyframe_measurements": (_i, [_sys, _i, _i, _vp, _vp, _vp, _vp, _i]),
     "vslam_get_template": (_i, [_sys, _i, _i, _vp, _ip, _ip, _ip]),
+    "vslam_get_templates": (_i, [_sys, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "vslam_stage_name": (C.c_char_p, [_i]),
     "vslam_profile_begin": (_i, [_sys, _i]),
     "vslam_profile_end": (_i, [_sys, _vp, _ip]),
+    "vslam_profile_launches": (_i, [_sys, _vp]),
     "vslam_bundle_adjust_recent": (_i, [_sys]),
     "vslam_bundle_adjust_all": (_i, [_sys]),
     "vslam_bundle_create": (_i, [C.POINTER(Params), _i, _i, _i, _i, C.POINTER(_vp)]),
@@ -176,6 +187,17 @@ def default_params(width, height, n_streams=1, **overrides):
 
 def _f64(a):
     return np.ascontiguousarray(a, np.float64)
+
+
+TRANSCENDENTALS = ("sin", "cos", "tan", "atan", "asin", "acos", "sqrt", "rcp")
+
+
+def eval_transcendental(name, x, on_host=False):
+    """csrc/vslam_libm.h (plus sqrt and the reciprocal) over the array x, on the device or as compiled for the host."""
+    x = _f64(x).reshape(-1)
+    y = np.zeros_like(x)
+    _check(load_library().vslam_eval_transcendental(TRANSCENDENTALS.index(name), len(x), x.ctypes.data, y.ctypes.data, int(on_host)))
+    return y
 
 
 class System:
@@ -315,6 +337,9 @@ class System:
     def set_velocity(self, stream, v6):
         _check(self.lib.vslam_set_velocity(self.h, stream, _f64(v6).ctypes.data))
 
+    def set_last_keyframe_dropped(self, stream, frame):
+        _check(self.lib.vslam_set_last_keyframe_dropped(self.h, stream, int(frame)))
+
     # ---- tracking ----------------------------------------------------------------------------
     def track_frame(self, gray):
         """Tracker::TrackFrame on host frames [S, H, W]; synchronous (vslam_update)."""
@@ -324,10 +349,38 @@ class System:
     def track_frame_device(self, dev_ptr, row_stride, stream_stride):
         _check(self.lib.vslam_track_frame(self.h, dev_ptr, row_stride, stream_stride, 1))
 
+    # TrackFrame stage by stage: make_keyframe_lite, patch_search(0), pose_update(0), patch_search(1), pose_update(1), finish_frame
+    def patch_search(self, stage):
+        _check(self.lib.vslam_patch_search(self.h, int(stage)))
+
+    def pose_update(self, stage):
+        _check(self.lib.vslam_pose_update(self.h, int(stage)))
+
+    def finish_frame(self):
+        _check(self.lib.vslam_finish_frame(self.h))
+        self.synchronize()
+
+    def set_point_positions(self, stream, pos, first=0):
+        a = _f64(pos).reshape(-1, 3)
+        _check(self.lib.vslam_map_set_point_positions(self.h, stream, int(first), len(a), a.ctypes.data))
+
+    def set_keyframe_pose(self, stream, kf, pose12):
+        _check(self.lib.vslam_map_set_keyframe_pose(self.h, stream, int(kf), _f64(pose12).ctypes.data))
+
     def state(self, stream):
         s = TrackState()
         _check(self.lib.vslam_get_state(self.h, stream, C.byref(s)))
         return s
+
+    def need_new_keyframe(self, stream):
+        v = C.c_int(0)
+        _check(self.lib.vslam_need_new_keyframe(self.h, stream, C.byref(v)))
+        return bool(v.value)
+
+    def distance_to_nearest_keyframe_excessive(self, stream):
+        v = C.c_int(0)
+        _check(self.lib.vslam_distance_to_nearest_keyframe_excessive(self.h, stream, C.byref(v)))
+        return bool(v.value)
 
     def message(self, stream):
         buf = C.create_string_buffer(512)
@@ -401,6 +454,15 @@ class System:
         have = _check(self.lib.vslam_get_template(self.h, stream, pt, t.ctypes.data, C.byref(s), C.byref(sq), C.byref(bad)))
         return {"tmpl": t.reshape(P, P), "sum": s.value, "sumsq": sq.value, "bad": bad.value, "have": have}
 
+    def templates(self, stream, n=None):
+        """cached warped templates of the first n map points: (tmpl [n, P, P], sum, sumsq, bad, have)"""
+        n = self.state(stream).n_points if n is None else n
+        P = self.params.patch_size
+        t = np.zeros((n, P, P), np.uint8)
+        s, sq, bad, have = (np.zeros(n, np.int32) for _ in range(4))
+        _check(self.lib.vslam_get_templates(self.h, stream, 0, n, t.ctypes.data, s.ctypes.data, sq.ctypes.data, bad.ctypes.data, have.ctypes.data))
+        return {"tmpl": t, "sum": s, "sumsq": sq, "bad": bad, "have": have}
+
     def profile_begin(self, max_frames):
         _check(self.lib.vslam_profile_begin(self.h, max_frames))
 
@@ -410,6 +472,12 @@ class System:
         n = C.c_int(0)
         _check(self.lib.vslam_profile_end(self.h, ms.ctypes.data, C.byref(n)))
         return {self.lib.vslam_stage_name(k).decode(): float(ms[k]) for k in range(N_STAGES)}, n.value
+
+    def profile_launches(self):
+        """-> {stage name: launches recorded by the last profile_begin/profile_end pair}"""
+        c = np.zeros(N_STAGES, np.int32)
+        _check(self.lib.vslam_profile_launches(self.h, c.ctypes.data))
+        return {self.lib.vslam_stage_name(k).decode(): int(c[k]) for k in range(N_STAGES)}
 
     def bundle_adjust_recent(self):
         _check(self.lib.vslam_bundle_adjust_recent(self.h))

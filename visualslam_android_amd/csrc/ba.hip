@@ -13,11 +13,17 @@ struct BaPool {            // device arrays for N problems
   int N, max_cams, max_pts, max_meas, max_free;
   BaResult* res;
   Pose* cam_pose; Pose* cam_new; int* cam_fixed; int* cam_row; double* cam_U; double* cam_ea;
-  double* pt_pos; double* pt_new; double* pt_V; double* pt_eb; double* pt_Vinv; int* pt_nmeas; int* pt_nout;
-  int* ms_p; int* ms_c; int* ms_state; double* ms_found; double* ms_sin; double* ms_cam; double* ms_eps; double* ms_err2;
-  double* ms_derivs; double* ms_tcam; double* ms_tfac; double* ms_teps;
-  int* lut; double* S; double* E; double* cam_up; double* map_up; double* scratch; int* outl; int* free_cams;
+  double* pt_pos; double* pt_new; double* pt_V; double* pt_eb; int* pt_nmeas; int* pt_nout;
+  int* ms_p; int* ms_c; int* ms_state; double* ms_found; double* ms_sin;
+  int* lut;
+  int* sl_info; int* sl_pt; int* sl_logical; double* sl_found; double* sl_sin; double* sl_cm; double* sl_d; double* sl_eps;
+  int* pt_offF; int* pt_offX; unsigned long long* pt_maskF; int* chF; int* chX; int* ch_n;
+  double* S; double* E; double* cam_up; double* scratch; int* outl; int* free_cams;
   int* id_view; int* id_point;   // BundleAdjust translation tables (:861-864)
+  // asynchronous map-maker: the problems k_ba_assemble built in frame t, as a list per slot (t mod slots).  The compute launch
+  // of that frame walks exactly this list: it never looks at a problem a later frame's assemble (running beside it on the
+  // main stream) is still writing.
+  int* work; int* work_n; int work_slots;
 };
 
 __host__ __device__ inline BaView ba_view(const BaPool& b, int n) {
@@ -27,18 +33,25 @@ __host__ __device__ inline BaView ba_view(const BaPool& b, int n) {
   v.res = b.res + n;
   v.cam_pose = b.cam_pose + n * C; v.cam_new = b.cam_new + n * C; v.cam_fixed = b.cam_fixed + n * C; v.cam_row = b.cam_row + n * C;
   v.cam_U = b.cam_U + n * C * 36; v.cam_ea = b.cam_ea + n * C * 6;
-  v.pt_pos = b.pt_pos + n * P * 3; v.pt_new = b.pt_new + n * P * 3; v.pt_V = b.pt_V + n * P * 9; v.pt_eb = b.pt_eb + n * P * 3;
-  v.pt_Vinv = b.pt_Vinv + n * P * 9; v.pt_nmeas = b.pt_nmeas + n * P; v.pt_nout = b.pt_nout + n * P;
-  v.ms_p = b.ms_p + n * M; v.ms_c = b.ms_c + n * M; v.ms_state = b.ms_state + n * M; v.ms_found = b.ms_found + n * M * 2;
-  v.ms_sin = b.ms_sin + n * M; v.ms_cam = b.ms_cam + n * M * 3; v.ms_eps = b.ms_eps + n * M * 2; v.ms_err2 = b.ms_err2 + n * M;
-  v.ms_derivs = b.ms_derivs + n * M * 4; v.ms_tcam = b.ms_tcam + n * M * 3; v.ms_tfac = b.ms_tfac + n * M; v.ms_teps = b.ms_teps + n * M * 2;
-  v.lut = b.lut + n * C * P; v.S = b.S + n * F * F; v.E = b.E + n * F; v.cam_up = b.cam_up + n * F; v.map_up = b.map_up + n * P * 3;
+  v.pt_pos = b.pt_pos + n * P * 3; v.pt_new = b.pt_new + n * P * 3; v.pt_V = b.pt_V + n * P * 6; v.pt_eb = b.pt_eb + n * P * 3;
+  v.pt_nmeas = b.pt_nmeas + n * P; v.pt_nout = b.pt_nout + n * P;
+  v.ms_p = b.ms_p + n * M; v.ms_c = b.ms_c + n * M; v.ms_state = b.ms_state + n * M; v.ms_found = b.ms_found + n * M * 2; v.ms_sin = b.ms_sin + n * M;
+  v.lut = b.lut + n * C * P;
+  v.sl_info = b.sl_info + n * M; v.sl_pt = b.sl_pt + n * M; v.sl_logical = b.sl_logical + n * M; v.sl_found = b.sl_found + n * M * 2; v.sl_sin = b.sl_sin + n * M;
+  v.sl_cm = b.sl_cm + n * M * 3; v.sl_d = b.sl_d + n * M * 4; v.sl_eps = b.sl_eps + n * M * 2;
+  v.pt_offF = b.pt_offF + n * (P + 1); v.pt_offX = b.pt_offX + n * (P + 1); v.pt_maskF = b.pt_maskF + n * P;
+  v.chF = b.chF + n * (P + 2); v.chX = b.chX + n * (P + 2); v.ch_n = b.ch_n + n * 4;
+  v.S = b.S + n * F * F; v.E = b.E + n * F; v.cam_up = b.cam_up + n * F;
   v.scratch = b.scratch + n * M; v.outl = b.outl + n * M * 2; v.free_cams = b.free_cams + n * C;
   return v;
 }
 
-__global__ __launch_bounds__(BA_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ba_compute(BaPool pool, BaConfig cfg) {
-  for (int n = blockIdx.x; n < pool.N; n += gridDim.x) {            // a capped grid walks the problems (vslam: ba_grid)
+__global__ __launch_bounds__(BA_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ba_compute(BaPool pool, BaConfig cfg, int slot) {
+  // slot < 0: one workgroup per problem of the pool (synchronous map-maker, stand-alone Bundle); slot >= 0: the grid walks the
+  // work list of one frame (asynchronous map-maker)
+  const int count = slot < 0 ? pool.N : pool.work_n[slot];
+  for (int i = blockIdx.x; i < count; i += gridDim.x) {
+    const int n = slot < 0 ? i : pool.work[(size_t)slot * pool.N + i];
     const BaView v = ba_view(pool, n);
     if (!v.res->active || v.res->computed) continue;
     ba_compute(v, cfg);
@@ -58,17 +71,22 @@ static int pool_alloc(std::vector<void*>& allocs, hipStream_t st, T** out, size_
 }
 #define PALLOC(field, count) do { int _r = pool_alloc(allocs, st, &b.field, (count)); if (_r) return _r; } while (0)
 
-static int pool_create(BaPool& b, std::vector<void*>& allocs, hipStream_t st, int N, int max_cams, int max_pts, int max_meas) {
+static int pool_create(BaPool& b, std::vector<void*>& allocs, hipStream_t st, int N, int max_cams, int max_pts, int max_meas, int work_slots = 1) {
   b.N = N; b.max_cams = max_cams; b.max_pts = max_pts; b.max_meas = max_meas; b.max_free = max_cams;
   const size_t n = N, C = max_cams, P = max_pts, M = max_meas, F = (size_t)max_cams * 6;
   PALLOC(res, n);
   PALLOC(cam_pose, n * C); PALLOC(cam_new, n * C); PALLOC(cam_fixed, n * C); PALLOC(cam_row, n * C); PALLOC(cam_U, n * C * 36); PALLOC(cam_ea, n * C * 6);
-  PALLOC(pt_pos, n * P * 3); PALLOC(pt_new, n * P * 3); PALLOC(pt_V, n * P * 9); PALLOC(pt_eb, n * P * 3); PALLOC(pt_Vinv, n * P * 9);
+  PALLOC(pt_pos, n * P * 3); PALLOC(pt_new, n * P * 3); PALLOC(pt_V, n * P * 6); PALLOC(pt_eb, n * P * 3);
   PALLOC(pt_nmeas, n * P); PALLOC(pt_nout, n * P);
-  PALLOC(ms_p, n * M); PALLOC(ms_c, n * M); PALLOC(ms_state, n * M); PALLOC(ms_found, n * M * 2); PALLOC(ms_sin, n * M); PALLOC(ms_cam, n * M * 3);
-  PALLOC(ms_eps, n * M * 2); PALLOC(ms_err2, n * M); PALLOC(ms_derivs, n * M * 4); PALLOC(ms_tcam, n * M * 3); PALLOC(ms_tfac, n * M); PALLOC(ms_teps, n * M * 2);
-  PALLOC(lut, n * C * P); PALLOC(S, n * F * F); PALLOC(E, n * F); PALLOC(cam_up, n * F); PALLOC(map_up, n * P * 3);
+  PALLOC(ms_p, n * M); PALLOC(ms_c, n * M); PALLOC(ms_state, n * M); PALLOC(ms_found, n * M * 2); PALLOC(ms_sin, n * M);
+  PALLOC(lut, n * C * P);
+  PALLOC(sl_info, n * M); PALLOC(sl_pt, n * M); PALLOC(sl_logical, n * M); PALLOC(sl_found, n * M * 2); PALLOC(sl_sin, n * M);
+  PALLOC(sl_cm, n * M * 3); PALLOC(sl_d, n * M * 4); PALLOC(sl_eps, n * M * 2);
+  PALLOC(pt_offF, n * (P + 1)); PALLOC(pt_offX, n * (P + 1)); PALLOC(pt_maskF, n * P); PALLOC(chF, n * (P + 2)); PALLOC(chX, n * (P + 2)); PALLOC(ch_n, n * 4);
+  PALLOC(S, n * F * F); PALLOC(E, n * F); PALLOC(cam_up, n * F);
   PALLOC(scratch, n * M); PALLOC(outl, n * M * 2); PALLOC(free_cams, n * C); PALLOC(id_view, n * C); PALLOC(id_point, n * P);
+  b.work_slots = work_slots > 0 ? work_slots : 1;
+  PALLOC(work, n * b.work_slots); PALLOC(work_n, (size_t)b.work_slots);
   return VSLAM_OK;
 }
 
@@ -90,7 +108,9 @@ struct vslam_bundle {
 
 
 extern "C" int vslam_bundle_create(const vslam_params* p, int n_problems, int max_cameras, int max_points, int max_meas, vslam_bundle** out) {
-  if (!p || !out || n_problems < 1 || max_cameras < 1 || max_points < 1 || max_meas < 1) { vslam_set_error("bundle_create: bad argument"); return VSLAM_E_INVALID; }
+  if (!p || !out || n_problems < 1 || max_cameras < 1 || max_cameras > 64 || max_points < 1 || max_points > 4096 || max_meas < 1 || max_meas > 65536) {
+    vslam_set_error("bundle_create: bad argument (1..64 cameras, 1..4096 points, 1..65536 measurements per problem)"); return VSLAM_E_INVALID;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { vslam_set_error("bundle_create: no HIP device visible (no CPU fallback)"); return VSLAM_E_HIP; }
   HIPCHK(hipSetDevice(p->device));
@@ -178,7 +198,7 @@ extern "C" int vslam_bundle_compute(vslam_bundle* b) {
     HIPCHK(hipStreamSynchronize(b->stream));   // host vectors go out of scope
   }
   b->uploaded = true;
-  hipLaunchKernelGGL(k_ba_compute, dim3(P.N), dim3(BA_THREADS), 0, b->stream, b->pool, b->cfg);
+  hipLaunchKernelGGL(k_ba_compute, dim3(P.N), dim3(BA_THREADS), 0, b->stream, b->pool, b->cfg, -1);
   HIPCHK(hipGetLastError());
   return VSLAM_OK;
 }
@@ -285,7 +305,7 @@ DEVFN double kfdist(const Pose& a, const Pose& b) {   // KeyFrameLinearDist :705
 
 // mode 0: after AddKeyFrame (only streams with kf_pending) -> BundleAdjustRecent; 1: BundleAdjustRecent on every
 // stream; 2: BundleAdjustAll on every stream.  Builds the Bundle problem of BundleAdjust (:854-902) in the pool.
-__global__ __launch_bounds__(BA_THREADS) void k_ba_assemble(MapDev m, TrackParams tp, BaPool pool, int mode) {
+__global__ __launch_bounds__(BA_THREADS) void k_ba_assemble(MapDev m, TrackParams tp, BaPool pool, int mode, int slot /* work list to enter, or -1 */) {
   const int s = blockIdx.x;
   TrackerState* st = &m.st[s];
   const BaView v = ba_view(pool, s);
@@ -438,6 +458,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_assemble(MapDev m, TrackParam
   if (threadIdx.x == 0) {
     R->n_cams = ncam; R->n_pts = np; R->n_meas = nm; R->active = (ncam > 0 && np > 0 && nm > 0); R->accepted = 0; R->n_outlier_meas = 0; R->computed = 0;
     if (mode == 0 && tp.ba_delay > 0) st->ba_countdown = tp.ba_delay;   // results are applied ba_delay frames from now
+    if (slot >= 0 && R->active) pool.work[(size_t)slot * pool.N + atomicAdd(&pool.work_n[slot], 1)] = s;   // list order is immaterial: the problems are independent
   }
 }
 
@@ -508,7 +529,7 @@ int ba_alloc(vslam_system* sys) {
   // worst case of BundleAdjust: every keyframe a camera, every point, every (kf, point) slot a measurement
   size_t M = (size_t)K * P;
   if (M > 65536) M = 65536;
-  return pool_create(ws->pool, sys->allocs, sys->stream, sys->S, K, P, (int)M);
+  return pool_create(ws->pool, sys->allocs, sys->stream, sys->S, K, P, (int)M, sys->p.ba_delay_frames > 0 ? sys->p.ba_delay_frames + 2 : 1);
 }
 
 static void fill_kfcopy(vslam_system* sys, KfCopyArgs& a) {
@@ -519,17 +540,53 @@ static void fill_kfcopy(vslam_system* sys, KfCopyArgs& a) {
   }
 }
 
-// Asynchronous map-maker (ba_delay_frames = D > 0): make the main stream wait for the bundle adjustment launched D frames
-// ago and apply whatever is due (k_ba_writeback decides per stream with its countdown).
+// Asynchronous map-maker: launch Bundle::Compute for the open batch -- every problem the last ba_batch_fill frames assembled -- on
+// the next map-maker stream of the ring, behind the main stream's last k_ba_assemble.
+static int ba_launch_batch(vslam_system* sys) {
+  if (sys->ba_batch_fill == 0) return VSLAM_OK;
+  BaSystemWs* ws = (BaSystemWs*)sys->ba_ws;
+  const BaConfig cfg = make_cfg(sys->tp);
+  const int R = (int)sys->ev_ba.size(), slot = (int)(sys->ba_batch_id % R);
+  sys->ba_stream = sys->ba_streams[(size_t)(sys->ba_batch_id % (long)sys->ba_streams.size())];
+  HIPCHK(hipEventRecord(sys->ev_asm[slot], sys->stream));
+  HIPCHK(hipStreamWaitEvent(sys->ba_stream, sys->ev_asm[slot], 0));
+  prof_mark(sys, 12);
+  // one workgroup per problem up to two per compute unit; the grid walks the batch's work list
+  const int cap = 2 * (sys->n_cu > 0 ? sys->n_cu : 256);
+  const int ba_grid = sys->S < cap ? sys->S : cap;
+  hipLaunchKernelGGL(k_ba_compute, dim3(ba_grid), dim3(BA_THREADS), 0, sys->ba_stream, ws->pool, cfg, slot);
+  prof_mark(sys, PROF_BA_END);
+  if (sys->prof_on && sys->prof_frame < sys->prof_cap && sys->prof_frame < (int)sys->prof_ba_launched.size()) sys->prof_ba_launched[sys->prof_frame] = 1;
+  HIPCHK(hipEventRecord(sys->ev_ba[slot], sys->ba_stream));
+  HIPCHK(hipGetLastError());
+  sys->ba_batch_id++;
+  sys->ba_batch_fill = 0;
+  return VSLAM_OK;
+}
+
+// Asynchronous map-maker (ba_delay_frames = D > 0): make the main stream wait for the bundle adjustment of the keyframes of
+// D frames ago and apply whatever is due (k_ba_writeback decides per stream with its countdown).
 int ba_frame_start(vslam_system* sys) {
   const int D = sys->tp.ba_delay;
   if (D <= 0) return VSLAM_OK;
   BaSystemWs* ws = (BaSystemWs*)sys->ba_ws;
-  const int R = (int)sys->ev_ba.size();
+  const int R = (int)sys->ev_ba.size(), FB = (int)sys->frame_batch.size();
   prof_mark(sys, 13);
-  if (sys->frame_no >= D) HIPCHK(hipStreamWaitEvent(sys->stream, sys->ev_ba[(sys->frame_no - D) % R], 0));
+  if (sys->frame_no >= D) {
+    const long b = sys->frame_batch[(size_t)((sys->frame_no - D) % FB)];
+    if (b >= 0) {
+      if (b == sys->ba_batch_id) { int r = ba_launch_batch(sys); if (r) return r; }   // still open (only after a host-driven flush pattern): launch it now
+      HIPCHK(hipStreamWaitEvent(sys->stream, sys->ev_ba[(size_t)(b % R)], 0));
+    }
+  }
   hipLaunchKernelGGL(k_ba_writeback, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, 3);
   HIPCHK(hipGetLastError());
+  return VSLAM_OK;
+}
+
+int ba_sync_streams(vslam_system* sys) {
+  if (sys->tp.ba_delay > 0) { int r = ba_launch_batch(sys); if (r) return r; }
+  for (hipStream_t st : sys->ba_streams) HIPCHK(hipStreamSynchronize(st));
   return VSLAM_OK;
 }
 
@@ -537,7 +594,7 @@ int ba_frame_start(vslam_system* sys) {
 static int ba_drain(vslam_system* sys) {
   if (sys->tp.ba_delay <= 0) return VSLAM_OK;
   BaSystemWs* ws = (BaSystemWs*)sys->ba_ws;
-  HIPCHK(hipStreamSynchronize(sys->ba_stream));
+  { int rs = ba_sync_streams(sys); if (rs) return rs; }
   hipLaunchKernelGGL(k_ba_writeback, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, 4);
   HIPCHK(hipGetLastError());
   return VSLAM_OK;
@@ -557,26 +614,26 @@ int ba_run(vslam_system* sys, int mode) {
     if (rg) return rg;
   }
   if (mode == 0) prof_mark(sys, 11);
-  hipLaunchKernelGGL(k_ba_assemble, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, mode);
   if (async) {
-    // Bundle::Compute on the BA stream, beside the next frames; its write-back is launched by ba_frame_start D frames later
-    const int R = (int)sys->ev_ba.size(), slot = (int)(sys->frame_no % R);
-    HIPCHK(hipEventRecord(sys->ev_asm[slot], sys->stream));
-    HIPCHK(hipStreamWaitEvent(sys->ba_stream, sys->ev_asm[slot], 0));
-    prof_mark(sys, 12);
-    // a background job: one workgroup per CU walks the problems, so that the bundle adjustment holds about half the
-    // registers of every CU for the whole delay window instead of every CU entirely in two bursts, and the tracking
-    // kernels of the frames in between always find room (measured at 1024 streams: +2 %, and steadier, than one workgroup per problem)
-    const int ba_grid = sys->n_cu > 0 && sys->n_cu < sys->S ? sys->n_cu : sys->S;
-    hipLaunchKernelGGL(k_ba_compute, dim3(ba_grid), dim3(BA_THREADS), 0, sys->ba_stream, ws->pool, cfg);
-    prof_mark(sys, PROF_BA_END);
-    HIPCHK(hipEventRecord(sys->ev_ba[slot], sys->ba_stream));
+    // Bundle::Compute on a map-maker stream, beside the next frames; its write-back is launched by ba_frame_start D frames later.
+    // The keyframe frames of independent sequences do not coincide, so a frame brings only a few problems, and an adjustment
+    // outlasts a frame (one persistent workgroup per problem, latency-bound): the problems of ba_batch consecutive frames are
+    // collected in one work list and launched together; successive launches go to a ring of streams and may overlap.
+    // A launch walks exactly its batch's list -- never a problem a later frame's k_ba_assemble is writing beside it.
+    const int R = (int)sys->ev_ba.size(), slot = (int)(sys->ba_batch_id % R);
+    if (sys->ba_batch_fill == 0)
+      HIPCHK(hipMemsetAsync(ws->pool.work_n + slot, 0, sizeof(int), sys->stream));   // the launch that read this slot R batches ago was waited for (ba_frame_start)
+    hipLaunchKernelGGL(k_ba_assemble, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, mode, slot);
+    sys->frame_batch[(size_t)(sys->frame_no % (long)sys->frame_batch.size())] = sys->ba_batch_id;
+    sys->ba_batch_fill++;
+    if (sys->ba_batch_fill >= sys->tp.ba_batch) { int rl = ba_launch_batch(sys); if (rl) return rl; }
     hipLaunchKernelGGL(k_ba_writeback, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, 0);   // HandleBadPoints of streams without a pending BA
     HIPCHK(hipGetLastError());
     return VSLAM_OK;
   }
+  hipLaunchKernelGGL(k_ba_assemble, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, mode, -1);
   if (mode == 0) prof_mark(sys, 12);
-  hipLaunchKernelGGL(k_ba_compute, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, ws->pool, cfg);
+  hipLaunchKernelGGL(k_ba_compute, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, ws->pool, cfg, -1);
   if (mode == 0) prof_mark(sys, 13);
   hipLaunchKernelGGL(k_ba_writeback, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, mode);
   HIPCHK(hipGetLastError());
@@ -589,7 +646,7 @@ extern "C" int vslam_get_bundle_stats(vslam_system* sys, int s, int out[6]) {
   if (!sys || !out || s < 0 || s >= sys->S || !sys->ba_ws) { vslam_set_error("get_bundle_stats: bad argument"); return VSLAM_E_INVALID; }
   BaSystemWs* ws = (BaSystemWs*)sys->ba_ws;
   HIPCHK(hipStreamSynchronize(sys->stream));
-  if (sys->ba_stream) HIPCHK(hipStreamSynchronize(sys->ba_stream));
+  { int rs = ba_sync_streams(sys); if (rs) return rs; }
   BaResult r;
   HIPCHK(hipMemcpy(&r, ws->pool.res + s, sizeof(r), hipMemcpyDeviceToHost));
   out[0] = r.n_cams; out[1] = r.n_free; out[2] = r.n_pts; out[3] = r.n_meas; out[4] = r.counter; out[5] = r.accepted;

@@ -1,18 +1,25 @@
 // Bundle::Compute (jni/Bundle.cc:136-178) / Do_LM_Step (:202-532) as ONE persistent workgroup per problem:
 // the whole Levenberg-Marquardt loop runs inside one launch, no host round-trip.
 //
-// Data layout (per problem, struct-of-arrays in HBM, fp64):
+// The kernel is bound by HBM traffic (512 problems resident, every sweep goes to memory), so the layout is built around the
+// bytes an LM trial has to move (fp64, struct-of-arrays, component-major):
 //   cameras: pose, trial pose, fixed flag, start row, U (6x6 lower), epsilon_a
-//   points : position, trial position, V (3x3 lower), epsilon_b, V*^-1
-//   measurements in AddMeas order: (p, c), found, sqrt-inv-noise, state, v3Cam, weighted camera derivatives, epsilon.
+//   points : position, trial position, V (3x3 lower), epsilon_b                      (V*^-1 is recomputed where it is used)
+//   measurements: the caller's list (AddMeas order = the reference's std::list order: ms_p, ms_c, ms_found, ms_sin, lut[c][p])
+//     is re-laid once per Compute into SLOTS: region F = the measurements in adjustable cameras, region X = those in fixed
+//     cameras, each point-major (points ascending, cameras ascending within a point).  A point's F slots are
+//     [pt_offF[p], pt_offF[p+1]) with pt_maskF[p] = set of adjustable-camera ordinals present, so "the measurement of point
+//     p in adjustable camera f" is an offset + a popcount instead of the lut's dependent 4-byte gather, and every sweep
+//     reads contiguous slots.  Per slot: static (camera | state, point, found position, sqrt-inv-noise = 32 B, logical
+//     index for the outlier order) and, rewritten once per LM step, v3Cam, the weighted camera derivatives and epsilon (72 B).
 //   The Jacobians A (2x6), B (2x3) and W = A^T B (6x3) are NOT stored: every consumer re-derives them from v3Cam, the
-//   weighted derivatives and the camera rotation (about 150 flops instead of 288 B written and up to 1 KB re-read per
-//   measurement and LM trial).  At 256-512 concurrent problems the kernel is bound by dependent-load latency and fp64
-//   issue at 2 waves per SIMD, not by HBM or flops (profiles/README.md): hence the batched loads and the per-phase
-//   functions below.
-//   lut[c][p] -> measurement index (GenerateMeasLUTs :566-575)
-// Reductions are deterministic: "segmented" per-camera / per-camera-pair sums are taken by one wavefront each
-// (lanes stride over the points, then __shfl_xor butterflies), per-point sums by one lane in camera order.
+//   weighted derivatives and the camera rotation.  Nothing of FindNewError's trial projection is stored either (the
+//   accepted state is projected again by the next step's sweep: same expressions, same bits): a trial writes 8 B per
+//   measurement (the squared error for the median).
+// Sweeps per accepted LM trial: one fused step sweep over all slots (projection, Tukey weight, V / epsilon_b by the point's
+// first lane out of LDS in slot order, U / epsilon_a by masked wavefront sums), then per trial the Schur operands (F slots), the
+// map update (F slots) and the trial error (all slots, static part only).
+// Reductions are deterministic (fixed lane / wave order, no floating-point atomics).
 #pragma once
 #include "dev_math.h"
 
@@ -46,13 +53,19 @@ struct BaView {          // pointers already offset to one problem
   int max_cams, max_pts, max_meas;
   BaResult* res;
   Pose* cam_pose; Pose* cam_new; int* cam_fixed; int* cam_row; double* cam_U; double* cam_ea;
-  double* pt_pos; double* pt_new; double* pt_V; double* pt_eb; double* pt_Vinv; int* pt_nmeas; int* pt_nout;
-  int* ms_p; int* ms_c; int* ms_state; double* ms_found; double* ms_sin; double* ms_cam; double* ms_eps; double* ms_err2;
-  double* ms_derivs;
-  double* ms_tcam; double* ms_tfac; double* ms_teps;   // FindNewError's projection of the trial state, reused by pass 1 after an accepted step
-  int* lut;              // [max_cams][max_pts]
-  double* S; double* E; double* cam_up; double* map_up;
-  double* scratch;       // [max_meas]
+  double* pt_pos; double* pt_new; double* pt_V; double* pt_eb; int* pt_nmeas; int* pt_nout;
+  // the caller's measurement list (AddMeas order)
+  int* ms_p; int* ms_c; int* ms_state; double* ms_found; double* ms_sin;
+  int* lut;              // [max_cams][max_pts] -> list index or -1 (GenerateMeasLUTs :566-575); input of the slot layout
+  // slots (see the header comment)
+  int* sl_info;          // camera | state << 8
+  int* sl_pt; int* sl_logical; double* sl_found; double* sl_sin;
+  double* sl_cm; double* sl_d; double* sl_eps;
+  int* pt_offF; int* pt_offX;                      // [max_pts + 1] slot offsets per point inside region F / region X
+  unsigned long long* pt_maskF;                    // [max_pts] adjustable-camera ordinals that measure the point
+  int* chF; int* chX; int* ch_n;                   // chunk tables of the step sweep: first point of every chunk (<= 64 slots, whole points); ch_n[0..3] = chunks F, chunks X, slots F, slots
+  double* S; double* E; double* cam_up;
+  double* scratch;       // [max_meas] squared error per slot (+inf: not in the median)
   int* outl;             // [max_meas][2] (p, c) in erase order
   int* free_cams;        // [max_cams] indices of the adjustable cameras
 };
@@ -68,12 +81,14 @@ struct BaViewG {
   int max_cams, max_pts, max_meas;
   BaResult AS1* res;
   Pose AS1* cam_pose; Pose AS1* cam_new; int AS1* cam_fixed; int AS1* cam_row; double AS1* cam_U; double AS1* cam_ea;
-  double AS1* pt_pos; double AS1* pt_new; double AS1* pt_V; double AS1* pt_eb; double AS1* pt_Vinv; int AS1* pt_nmeas; int AS1* pt_nout;
-  int AS1* ms_p; int AS1* ms_c; int AS1* ms_state; double AS1* ms_found; double AS1* ms_sin; double AS1* ms_cam; double AS1* ms_eps; double AS1* ms_err2;
-  double AS1* ms_derivs;
-  double AS1* ms_tcam; double AS1* ms_tfac; double AS1* ms_teps;
+  double AS1* pt_pos; double AS1* pt_new; double AS1* pt_V; double AS1* pt_eb; int AS1* pt_nmeas; int AS1* pt_nout;
+  int AS1* ms_p; int AS1* ms_c; int AS1* ms_state; double AS1* ms_found; double AS1* ms_sin;
   int AS1* lut;
-  double AS1* S; double AS1* E; double AS1* cam_up; double AS1* map_up;
+  int AS1* sl_info; int AS1* sl_pt; int AS1* sl_logical; double AS1* sl_found; double AS1* sl_sin;
+  double AS1* sl_cm; double AS1* sl_d; double AS1* sl_eps;
+  int AS1* pt_offF; int AS1* pt_offX; unsigned long long AS1* pt_maskF;
+  int AS1* chF; int AS1* chX; int AS1* ch_n;
+  double AS1* S; double AS1* E; double AS1* cam_up;
   double AS1* scratch;
   int AS1* outl;
   int AS1* free_cams;
@@ -88,9 +103,11 @@ DEVFN BaViewG ba_g(const BaView& v) {
   g.max_cams = __builtin_amdgcn_readfirstlane(v.max_cams); g.max_pts = __builtin_amdgcn_readfirstlane(v.max_pts); g.max_meas = __builtin_amdgcn_readfirstlane(v.max_meas);
 #define BA_G(f) g.f = ba_uniform_ptr(v.f)
   BA_G(res); BA_G(cam_pose); BA_G(cam_new); BA_G(cam_fixed); BA_G(cam_row); BA_G(cam_U); BA_G(cam_ea);
-  BA_G(pt_pos); BA_G(pt_new); BA_G(pt_V); BA_G(pt_eb); BA_G(pt_Vinv); BA_G(pt_nmeas); BA_G(pt_nout);
-  BA_G(ms_p); BA_G(ms_c); BA_G(ms_state); BA_G(ms_found); BA_G(ms_sin); BA_G(ms_cam); BA_G(ms_eps); BA_G(ms_err2); BA_G(ms_derivs);
-  BA_G(ms_tcam); BA_G(ms_tfac); BA_G(ms_teps); BA_G(lut); BA_G(S); BA_G(E); BA_G(cam_up); BA_G(map_up); BA_G(scratch); BA_G(outl); BA_G(free_cams);
+  BA_G(pt_pos); BA_G(pt_new); BA_G(pt_V); BA_G(pt_eb); BA_G(pt_nmeas); BA_G(pt_nout);
+  BA_G(ms_p); BA_G(ms_c); BA_G(ms_state); BA_G(ms_found); BA_G(ms_sin); BA_G(lut);
+  BA_G(sl_info); BA_G(sl_pt); BA_G(sl_logical); BA_G(sl_found); BA_G(sl_sin); BA_G(sl_cm); BA_G(sl_d); BA_G(sl_eps);
+  BA_G(pt_offF); BA_G(pt_offX); BA_G(pt_maskF); BA_G(chF); BA_G(chX); BA_G(ch_n);
+  BA_G(S); BA_G(E); BA_G(cam_up); BA_G(scratch); BA_G(outl); BA_G(free_cams);
 #undef BA_G
   return g;
 }
@@ -145,37 +162,34 @@ DEVFN int ba_block_sum_i(int v, int* red) {
   return t;
 }
 
-// ProjectAndFindSquaredError, jni/Bundle.cc:181-199, on operands already in registers (camera pose T, point X, found
-// position f, sqrt-inv-noise sn).  Stores v3Cam, state, derivatives, epsilon, error^2 of measurement i.
-DEVFN int ba_project_meas(const BaViewG& v, const BaConfig& cfg, int i, const Pose& T, const double X[3], double f0, double f1, double sn, double& e2) {
-  double c[3];
-  pose_xform(T, X, c);
-  MS(ms_cam, 0, i) = c[0]; MS(ms_cam, 1, i) = c[1]; MS(ms_cam, 2, i) = c[2];
-  if (c[2] <= 0) { v.ms_state[i] = MS_BAD; return MS_BAD; }
-  v.ms_state[i] = MS_OK;
-  const CamProj pr = cam_project(cfg.cam, c[0] / c[2], c[1] / c[2]);
-  double dd[4];
-  cam_derivs(cfg.cam, pr, dd);
-  MS(ms_derivs, 0, i) = dd[0]; MS(ms_derivs, 1, i) = dd[1]; MS(ms_derivs, 2, i) = dd[2]; MS(ms_derivs, 3, i) = dd[3];
-  const double e0 = (f0 - pr.im[0]) * sn, e1 = (f1 - pr.im[1]) * sn;
-  MS(ms_eps, 0, i) = e0; MS(ms_eps, 1, i) = e1;
-  e2 = e0 * e0 + e1 * e1;
-  v.ms_err2[i] = e2;
-  return MS_OK;
-}
+// Slot accessors: component k of slot i of a measurement-indexed fp64 array (component-major, see MS()).
+#define SL(arr, k, i) v.arr[(size_t)(k) * v.max_meas + (i)]
+#define SL_CAM(info) ((info) & 255)
+#define SL_STATE(info) (((info) >> 8) & 3)
+#define SL_INFO(cam, st) ((cam) | ((st) << 8))
 
 // Jacobians of one measurement from its stored state (jni/Bundle.cc:262-300): cm = v3Cam, d = sqrt-inv-noise * weight *
 // camera derivatives (2x2 row-major), R = rotation of the camera.  Same expressions wherever they are re-derived.
-// The loops over measurements are memory-latency bound (one workgroup per problem, 2 waves per SIMD): each thread
-// first loads the operands of BA_ILP (or 2) independent measurements unconditionally -- index clamped, no branch
-// between the loads -- and only then computes, so the round trips overlap.  Accumulation order is unchanged.
 struct MeasState { double cm[3], d[4]; int st; };
-DEVFN void ba_load_state(const BaViewG& v, int i, MeasState& m) {      // i < 0: loads measurement 0, state forced to erased
+DEVFN void ba_load_state(const BaViewG& v, int i, MeasState& m) {      // i < 0: loads slot 0, state forced to erased
   const int ic = i < 0 ? 0 : i;
-  m.st = v.ms_state[ic];
-  m.cm[0] = MS(ms_cam, 0, ic); m.cm[1] = MS(ms_cam, 1, ic); m.cm[2] = MS(ms_cam, 2, ic);
-  m.d[0] = MS(ms_derivs, 0, ic); m.d[1] = MS(ms_derivs, 1, ic); m.d[2] = MS(ms_derivs, 2, ic); m.d[3] = MS(ms_derivs, 3, ic);
+  m.st = SL_STATE(v.sl_info[ic]);
+  m.cm[0] = SL(sl_cm, 0, ic); m.cm[1] = SL(sl_cm, 1, ic); m.cm[2] = SL(sl_cm, 2, ic);
+  m.d[0] = SL(sl_d, 0, ic); m.d[1] = SL(sl_d, 1, ic); m.d[2] = SL(sl_d, 2, ic); m.d[3] = SL(sl_d, 3, ic);
   if (i < 0) m.st = MS_ERASED;
+}
+// the F slot of point p in the adjustable camera of ordinal f, or -1
+DEVFN int ba_slot_of(const BaViewG& v, int p, int f) {
+  const unsigned long long mk = v.pt_maskF[p];
+  if (!((mk >> f) & 1ull)) return -1;
+  return v.pt_offF[p] + __popcll(mk & ((1ull << f) - 1ull));
+}
+// V*^-1 of point p (jni/Bundle.cc:329-347): V with its diagonal scaled by 1 + lambda, inverted; zero if a diagonal element of V is zero
+DEVFN void ba_vstar_inv(const BaViewG& v, int p, double lambda, double Vi[9]) {
+  const double v00 = PT(pt_V, 0, p), v10 = PT(pt_V, 1, p), v11 = PT(pt_V, 2, p), v20 = PT(pt_V, 3, p), v21 = PT(pt_V, 4, p), v22 = PT(pt_V, 5, p);
+  if (v00 * v11 * v22 == 0) { _Pragma("unroll") for (int k = 0; k < 9; k++) Vi[k] = 0.0; return; }
+  const double Vs[9] = {v00 * (1.0 + lambda), v10, v20, v10, v11 * (1.0 + lambda), v21, v20, v21, v22 * (1.0 + lambda)};
+  inv3(Vs, Vi);
 }
 DEVFN void ba_jac_A(const double cm[3], const double d[4], double A[12]) {
   const double ooz = 1.0 / cm[2];
@@ -352,112 +366,122 @@ __device__ __attribute__((noinline)) bool ba_solve_wave(const BaView& v_, int n)
   return true;
 }
 
-// pass 1 of Do_LM_Step (jni/Bundle.cc:209-215): project every measurement still in the list; returns this thread's
-// count of valid ones.  Kept out of line (like FindNewError below): the fp64 atan / division sequences of the camera model
-// get their own register allocation instead of inheriting the pressure of the Schur-complement tasks.
-__device__ __attribute__((noinline)) int ba_pass1_project(const BaView& v_, const BaConfig& cfg_, int nm) {
-  const BaViewG v = ba_g(v_);
-  const BaConfig cfg = cfg_;
-  int nvalid = 0;
-  for (int i0 = threadIdx.x; i0 < nm; i0 += BA_ILP_PROJ * BA_THREADS) {
-    int st[BA_ILP_PROJ], mc[BA_ILP_PROJ], mp[BA_ILP_PROJ]; double f0[BA_ILP_PROJ], f1[BA_ILP_PROJ], sn[BA_ILP_PROJ];
-    _Pragma("unroll") for (int u = 0; u < BA_ILP_PROJ; u++) {
-      const int i = i0 + u * BA_THREADS, ic = i < nm ? i : nm - 1;
-      st[u] = v.ms_state[ic]; mc[u] = v.ms_c[ic]; mp[u] = v.ms_p[ic];
-      f0[u] = MS(ms_found, 0, ic); f1[u] = MS(ms_found, 1, ic); sn[u] = v.ms_sin[ic];
-    }
-    Pose T[BA_ILP_PROJ]; double X[BA_ILP_PROJ][3];
-    _Pragma("unroll") for (int u = 0; u < BA_ILP_PROJ; u++) {
-      T[u] = ba_load_pose(v.cam_pose + mc[u]);
-      _Pragma("unroll") for (int k = 0; k < 3; k++) X[u][k] = v.pt_pos[3 * mp[u] + k];
-    }
-    _Pragma("unroll") for (int u = 0; u < BA_ILP_PROJ; u++) {
-      const int i = i0 + u * BA_THREADS;
-      if (i >= nm) continue;
-      double e2 = __builtin_huge_val(), e2p;
-      if (st[u] != MS_ERASED && ba_project_meas(v, cfg, i, T[u], X[u], f0[u], f1[u], sn[u], e2p) == MS_OK) { e2 = e2p; nvalid++; }
-      v.scratch[i] = e2;
-    }
-  }
-  return nvalid;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Slot layout, built once per Compute from the caller's list + lut.
+// ---------------------------------------------------------------------------------------------------------------------
+#define SL_FORD(info) (((info) >> 16) & 255)                 // ordinal of the (adjustable) camera, 255 for a fixed one
+#define SL_MAKE(cam, st, ford) ((cam) | ((st) << 8) | ((ford) << 16))
+#define SL_WITH_STATE(info, st) (((info) & ~(3 << 8)) | ((st) << 8))
+
+// a[0..n) counts -> exclusive offsets, a[n] = total (returned); all threads call
+DEVFN int ba_block_excl_scan(int AS1* a, int n, int* ired) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int per = (n + BA_THREADS - 1) / BA_THREADS;
+  const int lo = min((int)threadIdx.x * per, n), hi = min(lo + per, n);
+  int sum = 0;
+  for (int i = lo; i < hi; i++) sum += a[i];
+  int inc = sum;
+  for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+  __syncthreads();
+  if (lane == 63) ired[wave] = inc;
+  __syncthreads();
+  int run = inc - sum, total = 0;
+  for (int w = 0; w < BA_WAVES; w++) { if (w < wave) run += ired[w]; total += ired[w]; }
+  for (int i = lo; i < hi; i++) { const int t = a[i]; a[i] = run; run += t; }
+  if (threadIdx.x == 0) a[n] = total;
+  __syncthreads();
+  return total;
 }
 
-// Passes 1 and 2 right after an accepted step, in one sweep: the committed cameras / points are the trial state
-// FindNewError has just projected, so v3Cam, the radial factor (the atan), the residual and its square are taken from
-// its stores instead of being recomputed -- the same values, bit for bit -- and the median of the squared errors (sigma) is
-// already known, because FindNewError also left them in `scratch`.  What is left is the camera derivatives and the Tukey
-// weights; the unweighted epsilon / derivatives / error^2 of the two-pass form are never written or read back
-// (136 instead of 264 B per measurement).  Returns this thread's share of the objective (pass 2's `cur`).
-__device__ __attribute__((noinline)) double ba_pass12_cached(const BaView& v_, const BaConfig& cfg_, int nm, double sigma2) {
+__device__ __attribute__((noinline)) void ba_build_layout(const BaView& v_, int nc, int np, int* ired, int* lds_i /* LDS, 2 * (max_pts + 1) ints */) {
   const BaViewG v = ba_g(v_);
-  const BaConfig cfg = cfg_;
-  double cur = 0.0;
-  for (int i0 = threadIdx.x; i0 < nm; i0 += BA_ILP_C * BA_THREADS) {
-    int st[BA_ILP_C]; double c[BA_ILP_C][3], fac[BA_ILP_C], e0[BA_ILP_C], e1[BA_ILP_C], sn[BA_ILP_C];
-    _Pragma("unroll") for (int u = 0; u < BA_ILP_C; u++) {
-      const int i = i0 + u * BA_THREADS, ic = i < nm ? i : nm - 1;
-      st[u] = v.ms_state[ic];
-      c[u][0] = MS(ms_tcam, 0, ic); c[u][1] = MS(ms_tcam, 1, ic); c[u][2] = MS(ms_tcam, 2, ic);
-      fac[u] = v.ms_tfac[ic]; e0[u] = MS(ms_teps, 0, ic); e1[u] = MS(ms_teps, 1, ic); sn[u] = v.ms_sin[ic];
+  // 1. per point: how many adjustable / fixed cameras measure it, which adjustable ones; V and epsilon_b start at zero
+  for (int p = threadIdx.x; p < np; p += BA_THREADS) {
+    int nF = 0, nX = 0; unsigned long long mk = 0;
+    for (int c = 0; c < nc; c++) {
+      if (v.lut[(size_t)c * v.max_pts + p] < 0) continue;
+      if (v.cam_fixed[c]) nX++; else { nF++; mk |= 1ull << (v.cam_row[c] / 6); }
     }
-    _Pragma("unroll") for (int u = 0; u < BA_ILP_C; u++) {
-      const int i = i0 + u * BA_THREADS;
-      if (i >= nm || st[u] == MS_ERASED) continue;
-      MS(ms_cam, 0, i) = c[u][0]; MS(ms_cam, 1, i) = c[u][1]; MS(ms_cam, 2, i) = c[u][2];
-      if (c[u][2] <= 0) { v.ms_state[i] = MS_BAD; cur += 1.0; continue; }          // pass 1: bBad; pass 2 (:243-246)
-      CamProj pr;                                                     // cam_project minus its atan
-      pr.cam[0] = c[u][0] / c[u][2]; pr.cam[1] = c[u][1] / c[u][2];
-      pr.r = sqrt(pr.cam[0] * pr.cam[0] + pr.cam[1] * pr.cam[1]);
-      pr.factor = fac[u]; pr.invalid = 0; pr.im[0] = 0; pr.im[1] = 0;
-      double dd[4];
-      cam_derivs(cfg.cam, pr, dd);
-      const double e2 = e0[u] * e0[u] + e1[u] * e1[u];
-      const double dWeight = tukey_sqrt_weight(e2, sigma2);
-      MS(ms_eps, 0, i) = e0[u] * dWeight; MS(ms_eps, 1, i) = e1[u] * dWeight;
-      if (dWeight == 0) { v.ms_state[i] = MS_BAD; cur += 1.0; continue; }
-      v.ms_state[i] = MS_OK;
-      cur += tukey_objective(e2, sigma2);
-      _Pragma("unroll") for (int k = 0; k < 4; k++) MS(ms_derivs, k, i) = sn[u] * (dWeight * dd[k]);
+    v.pt_offF[p] = nF; v.pt_offX[p] = nX; v.pt_maskF[p] = mk;
+    _Pragma("unroll") for (int k = 0; k < 6; k++) PT(pt_V, k, p) = 0.0;
+    _Pragma("unroll") for (int k = 0; k < 3; k++) PT(pt_eb, k, p) = 0.0;
+  }
+  __syncthreads();
+  const int MF = ba_block_excl_scan(v.pt_offF, np, ired);
+  const int MX = ba_block_excl_scan(v.pt_offX, np, ired);
+  // 2. the slots: adjustable cameras in ordinal order, then (region X) fixed cameras in index order
+  for (int p = threadIdx.x; p < np; p += BA_THREADS) {
+    int kf = v.pt_offF[p], kx = MF + v.pt_offX[p];
+    for (int c = 0; c < nc; c++) {
+      const int i = v.lut[(size_t)c * v.max_pts + p];
+      if (i < 0) continue;
+      const bool fx = v.cam_fixed[c] != 0;
+      const int s = fx ? kx++ : kf++;
+      v.sl_info[s] = SL_MAKE(c, MS_OK, fx ? 255 : v.cam_row[c] / 6);
+      v.sl_pt[s] = p; v.sl_logical[s] = i;
+      SL(sl_found, 0, s) = MS(ms_found, 0, i); SL(sl_found, 1, s) = MS(ms_found, 1, i);
+      v.sl_sin[s] = v.ms_sin[i];
     }
   }
-  return cur;
+  // 3. chunk tables of the step sweep: consecutive whole points, at most 64 slots (one lane each)
+  int* oF = lds_i; int* oX = lds_i + (np + 1);
+  for (int p = threadIdx.x; p <= np; p += BA_THREADS) { oF[p] = v.pt_offF[p]; oX[p] = v.pt_offX[p]; }
+  __syncthreads();
+  if (threadIdx.x == 0 || threadIdx.x == 64) {
+    const int* o = threadIdx.x == 0 ? oF : oX;
+    int AS1* ch = threadIdx.x == 0 ? v.chF : v.chX;
+    int k = 0, start = 0;
+    if (np > 0) ch[0] = 0;
+    for (int p = 0; p < np; p++) {
+      if (o[p + 1] - o[start] > 64) { ch[++k] = p; start = p; }
+    }
+    if (np > 0) ch[++k] = np;
+    v.ch_n[threadIdx.x == 0 ? 0 : 1] = k;
+    if (threadIdx.x == 0) { v.ch_n[2] = MF; v.ch_n[3] = MF + MX; }
+  }
+  __syncthreads();
 }
 
-// FindNewError (jni/Bundle.cc:537-561): this thread's share of the objective at the trial state.
-// It also prepares the next Do_LM_Step in case this trial is accepted: the squared error of every measurement that stays
-// in the list (state OK now, in front of the trial camera) goes to `scratch` for the median, +inf for the others, and
-// their number is returned.
+// ---------------------------------------------------------------------------------------------------------------------
+// FindNewError (jni/Bundle.cc:537-561) at the trial state, or -- trial == 0 -- pass 1 of Do_LM_Step (:209-215) at the committed
+// state: this thread's share of the objective.  It also prepares the median of the next Do_LM_Step: the squared error of every
+// measurement that stays in the list (state OK now, in front of the camera) goes to `scratch`, +inf for the others, and their
+// number is returned.  Reads the static 32 B of a slot, writes 8 B.
+// ---------------------------------------------------------------------------------------------------------------------
 struct BaNewError { double ne; int nvalid; };
-__device__ __attribute__((noinline)) BaNewError ba_find_new_error(const BaView& v_, const BaConfig& cfg_, int nm, double sigma2) {
+__device__ __attribute__((noinline)) BaNewError ba_find_new_error(const BaView& v_, const BaConfig& cfg_, int M, double sigma2, int trial) {
   const BaViewG v = ba_g(v_);
   const BaConfig cfg = cfg_;
+  const Pose AS1* cams = trial ? v.cam_new : v.cam_pose;
+  const double AS1* pts = trial ? v.pt_new : v.pt_pos;
   double ne = 0.0;
   int nv = 0;
-  for (int i0 = threadIdx.x; i0 < nm; i0 += BA_ILP_PROJ * BA_THREADS) {
-    int st[BA_ILP_PROJ], mc[BA_ILP_PROJ], mp[BA_ILP_PROJ]; double f0[BA_ILP_PROJ], f1[BA_ILP_PROJ], sn[BA_ILP_PROJ];
+  for (int i0 = threadIdx.x; i0 < M; i0 += BA_ILP_PROJ * BA_THREADS) {
+    int info[BA_ILP_PROJ], mp[BA_ILP_PROJ]; double f0[BA_ILP_PROJ], f1[BA_ILP_PROJ], sn[BA_ILP_PROJ];
     _Pragma("unroll") for (int u = 0; u < BA_ILP_PROJ; u++) {
-      const int i = i0 + u * BA_THREADS, ic = i < nm ? i : nm - 1;
-      st[u] = i < nm ? v.ms_state[ic] : MS_ERASED; mc[u] = v.ms_c[ic]; mp[u] = v.ms_p[ic];
-      f0[u] = MS(ms_found, 0, ic); f1[u] = MS(ms_found, 1, ic); sn[u] = v.ms_sin[ic];
+      const int i = i0 + u * BA_THREADS, ic = i < M ? i : M - 1;
+      info[u] = v.sl_info[ic]; mp[u] = v.sl_pt[ic];
+      if (i >= M) info[u] = SL_WITH_STATE(info[u], MS_ERASED);
+      f0[u] = SL(sl_found, 0, ic); f1[u] = SL(sl_found, 1, ic); sn[u] = v.sl_sin[ic];
     }
     Pose T[BA_ILP_PROJ]; double X[BA_ILP_PROJ][3];
     _Pragma("unroll") for (int u = 0; u < BA_ILP_PROJ; u++) {
-      T[u] = ba_load_pose(v.cam_new + mc[u]);
-      _Pragma("unroll") for (int k = 0; k < 3; k++) X[u][k] = v.pt_new[3 * mp[u] + k];
+      T[u] = ba_load_pose(cams + SL_CAM(info[u]));
+      _Pragma("unroll") for (int k = 0; k < 3; k++) X[u][k] = pts[3 * mp[u] + k];
     }
     _Pragma("unroll") for (int u = 0; u < BA_ILP_PROJ; u++) {
-      if (st[u] == MS_ERASED) continue;
+      const int st = SL_STATE(info[u]);
+      if (st == MS_ERASED) continue;
       const int i = i0 + u * BA_THREADS;
       double c[3];
       pose_xform(T[u], X[u], c);
-      MS(ms_tcam, 0, i) = c[0]; MS(ms_tcam, 1, i) = c[1]; MS(ms_tcam, 2, i) = c[2];
       if (c[2] <= 0) { ne += 1.0; v.scratch[i] = __builtin_huge_val(); continue; }
       const CamProj pr = cam_project(cfg.cam, c[0] / c[2], c[1] / c[2]);
       const double e0 = (f0[u] - pr.im[0]) * sn[u], e1 = (f1[u] - pr.im[1]) * sn[u];
-      v.ms_tfac[i] = pr.factor; MS(ms_teps, 0, i) = e0; MS(ms_teps, 1, i) = e1;
       const double e2 = e0 * e0 + e1 * e1;
       ne += tukey_objective(e2, sigma2);
-      const bool stays = st[u] == MS_OK;                              // MS_BAD ones are erased at the end of this step
+      const bool stays = st == MS_OK;                                 // MS_BAD ones are erased at the end of this step
       v.scratch[i] = stays ? e2 : __builtin_huge_val();
       nv += stays ? 1 : 0;
     }
@@ -466,60 +490,143 @@ __device__ __attribute__((noinline)) BaNewError ba_find_new_error(const BaView& 
   return r;
 }
 
-// V, epsilon_b (jni/Bundle.cc:49-56, :312-316).  Each phase below is its own function so that it gets its own register
-// allocation (see ba_pass1_project).
-__device__ __attribute__((noinline)) void ba_accum_V(const BaView& v_, int nc, int np) {
+// ---------------------------------------------------------------------------------------------------------------------
+// The step sweep: passes 1 and 2 of Do_LM_Step (jni/Bundle.cc:209-321) over the slots of one region, one lane per slot, a chunk
+// of whole points per wavefront trip.  Per slot: projection, camera derivatives, Tukey weight (the median is known: the
+// squared errors are those FindNewError left), weighted epsilon / derivatives stored for the consumers of this step; the
+// objective.  V and epsilon_b (:49-56, :312-316): every lane leaves its 9 products in LDS and the first lane of each point adds
+// the point's entries in slot order (region F: the adjustable cameras in order; region X continues the sum with the fixed
+// ones).  U and epsilon_a (:40-47, :306-311; region F, up to BA_MFMA_FREE adjustable cameras): 27 products per lane, summed per
+// camera by masked wavefront reductions and carried in registers over the chunks; left per wavefront in `ured`.
+// Returns this thread's share of the objective (pass 2's dCurrentError).
+// ---------------------------------------------------------------------------------------------------------------------
+#define BA_MFMA_FREE 5
+__device__ __attribute__((noinline)) double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int region, double sigma2, int nfree,
+                                                        double* stg_ /* LDS [BA_WAVES][64][9] */, double* ured_ /* LDS [BA_WAVES][BA_MFMA_FREE][32] */) {
   const BaViewG v = ba_g(v_);
-  // V, epsilon_b per point: one lane per point, cameras in id order
-  for (int p = threadIdx.x; p < np; p += BA_THREADS) {
-    double V[6] = {0, 0, 0, 0, 0, 0}, eb[3] = {0, 0, 0};
-    for (int c0 = 0; c0 < nc; c0 += BA_ILP_P) {
-      int ii[BA_ILP_P]; MeasState ms[BA_ILP_P]; double e[BA_ILP_P][2];
-      _Pragma("unroll") for (int u = 0; u < BA_ILP_P; u++) ii[u] = c0 + u < nc ? v.lut[(size_t)(c0 + u) * v.max_pts + p] : -1;
-      _Pragma("unroll") for (int u = 0; u < BA_ILP_P; u++) {
-        ba_load_state(v, ii[u], ms[u]);
-        const int ic = ii[u] < 0 ? 0 : ii[u];
-        e[u][0] = MS(ms_eps, 0, ic); e[u][1] = MS(ms_eps, 1, ic);
+  const BaConfig cfg = cfg_;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double AS3* stg = (double AS3*)stg_ + wave * 64 * 9;
+  const int nch = v.ch_n[region];
+  const int AS1* ch = region ? v.chX : v.chF;
+  const int AS1* off = region ? v.pt_offX : v.pt_offF;
+  const int base = region ? v.ch_n[2] : 0;
+  const bool fastU = region == 0 && nfree <= BA_MFMA_FREE;
+  double cur = 0.0;
+  double uacc[BA_MFMA_FREE];
+  _Pragma("unroll") for (int f = 0; f < BA_MFMA_FREE; f++) uacc[f] = 0.0;
+  for (int k = wave; k < nch; k += BA_WAVES) {
+    const int p0 = ch[k], p1 = ch[k + 1];
+    const int a = base + off[p0], n = base + off[p1] - a;              // n <= 64 slots
+    const bool act = lane < n;
+    const int s = a + (act ? lane : 0);
+    const int info = v.sl_info[s], pt = v.sl_pt[s];
+    const double f0 = SL(sl_found, 0, s), f1 = SL(sl_found, 1, s), sn = v.sl_sin[s];
+    const int cam = SL_CAM(info);
+    const Pose T = ba_load_pose(v.cam_pose + cam);
+    double X[3];
+    _Pragma("unroll") for (int q = 0; q < 3; q++) X[q] = v.pt_pos[3 * pt + q];
+    int st = act ? SL_STATE(info) : MS_ERASED;
+    bool valid = false;
+    double c[3] = {0, 0, 1}, d[4] = {0, 0, 0, 0}, e0 = 0, e1 = 0;
+    if (st != MS_ERASED) {
+      pose_xform(T, X, c);
+      SL(sl_cm, 0, s) = c[0]; SL(sl_cm, 1, s) = c[1]; SL(sl_cm, 2, s) = c[2];
+      if (c[2] <= 0) { st = MS_BAD; cur += 1.0; }                       // pass 1: bBad (:186-189); pass 2: :243-246
+      else {
+        const CamProj pr = cam_project(cfg.cam, c[0] / c[2], c[1] / c[2]);
+        double dd[4];
+        cam_derivs(cfg.cam, pr, dd);
+        e0 = (f0 - pr.im[0]) * sn; e1 = (f1 - pr.im[1]) * sn;
+        const double e2 = e0 * e0 + e1 * e1;
+        const double dWeight = tukey_sqrt_weight(e2, sigma2);
+        e0 *= dWeight; e1 *= dWeight;
+        SL(sl_eps, 0, s) = e0; SL(sl_eps, 1, s) = e1;
+        if (dWeight == 0) { st = MS_BAD; cur += 1.0; }
+        else {
+          st = MS_OK; valid = true;
+          cur += tukey_objective(e2, sigma2);
+          _Pragma("unroll") for (int q = 0; q < 4; q++) { d[q] = sn * (dWeight * dd[q]); SL(sl_d, q, s) = d[q]; }   // weighted from here on
+        }
       }
-      _Pragma("unroll") for (int u = 0; u < BA_ILP_P; u++) {
-        if (ms[u].st != MS_OK) continue;
+      v.sl_info[s] = SL_WITH_STATE(info, st);
+    }
+    // ---- V, epsilon_b ----
+    {
+      double pr9[9];
+      _Pragma("unroll") for (int q = 0; q < 9; q++) pr9[q] = 0.0;
+      if (valid) {
         double B[6];
-        ba_jac_B(v.cam_pose[c0 + u].R, ms[u].cm, ms[u].d, B);
+        ba_jac_B(T.R, c, d, B);
         int q = 0;
-        _Pragma("unroll") for (int r = 0; r < 3; r++) for (int cc = 0; cc <= r; cc++) V[q++] += B[r] * B[cc] + B[3 + r] * B[3 + cc];   // :49-56 LL triangle
-        _Pragma("unroll") for (int r = 0; r < 3; r++) eb[r] += B[r] * e[u][0] + B[3 + r] * e[u][1];
+        _Pragma("unroll") for (int r = 0; r < 3; r++) for (int cc = 0; cc <= r; cc++) pr9[q++] = B[r] * B[cc] + B[3 + r] * B[3 + cc];   // :49-56 LL triangle
+        _Pragma("unroll") for (int r = 0; r < 3; r++) pr9[6 + r] = B[r] * e0 + B[3 + r] * e1;
+      }
+      _Pragma("unroll") for (int q = 0; q < 9; q++) stg[lane * 9 + q] = pr9[q];
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_wave_barrier();
+      const int ptprev = __shfl_up(pt, 1);
+      if (act && (lane == 0 || ptprev != pt)) {                       // first slot of the point in this region
+        const int cnt = off[pt + 1] - off[pt];
+        double acc[9];
+        const bool cont = region == 1 && v.pt_offF[pt + 1] - v.pt_offF[pt] > 0;   // continue the sum the F sweep left
+        _Pragma("unroll") for (int q = 0; q < 6; q++) acc[q] = cont ? PT(pt_V, q, pt) : 0.0;
+        _Pragma("unroll") for (int q = 0; q < 3; q++) acc[6 + q] = cont ? PT(pt_eb, q, pt) : 0.0;
+        for (int j = 0; j < cnt; j++) {
+          _Pragma("unroll") for (int q = 0; q < 9; q++) acc[q] += stg[(lane + j) * 9 + q];
+        }
+        // lower triangle of V: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) -> components 0..5
+        _Pragma("unroll") for (int q = 0; q < 6; q++) PT(pt_V, q, pt) = acc[q];
+        _Pragma("unroll") for (int q = 0; q < 3; q++) PT(pt_eb, q, pt) = acc[6 + q];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // ---- U, epsilon_a ----
+    if (fastU) {
+      double A[12];
+      _Pragma("unroll") for (int q = 0; q < 12; q++) A[q] = 0.0;
+      if (valid) ba_jac_A(c, d, A);
+      const int ford = valid ? SL_FORD(info) : 255;
+      _Pragma("unroll") for (int f = 0; f < BA_MFMA_FREE; f++) {
+        if (f < nfree) {
+          const double m = ford == f ? 1.0 : 0.0;
+          double t32[32];
+          int q = 0;
+          _Pragma("unroll") for (int r = 0; r < 6; r++) for (int cc = 0; cc <= r; cc++) t32[q++] = m * (A[r] * A[cc] + A[6 + r] * A[6 + cc]);       // :40-47
+          _Pragma("unroll") for (int r = 0; r < 6; r++) t32[21 + r] = m * (A[r] * e0 + A[6 + r] * e1);
+          _Pragma("unroll") for (int r = 27; r < 32; r++) t32[r] = 0.0;
+          uacc[f] += wave_multi_sum<32>(t32);
+        }
       }
     }
-    // lower triangle of V: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) -> components 0..5
-    _Pragma("unroll") for (int k = 0; k < 6; k++) PT(pt_V, k, p) = V[k];
-    PT(pt_eb, 0, p) = eb[0]; PT(pt_eb, 1, p) = eb[1]; PT(pt_eb, 2, p) = eb[2];
   }
+  if (fastU) {
+    double AS3* ured = (double AS3*)ured_ + wave * BA_MFMA_FREE * 32;
+    const int vi = wave_multi_index<32>(lane);
+    _Pragma("unroll") for (int f = 0; f < BA_MFMA_FREE; f++) if (!(lane & 1) && f < nfree) ured[f * 32 + vi] = uacc[f];
+  }
+  return cur;
 }
 
-__device__ __attribute__((noinline)) void ba_accum_U(const BaView& v_, int nfree, int np) {
+// U, epsilon_a for more than BA_MFMA_FREE adjustable cameras: one wavefront per camera, lanes stride over the points
+__device__ __attribute__((noinline)) void ba_accum_U_generic(const BaView& v_, int nfree, int np) {
   const BaViewG v = ba_g(v_);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // U, epsilon_a per adjustable camera: one wavefront per camera (segmented wave reduction)
   for (int f = wave; f < nfree; f += BA_WAVES) {
     const int j = v.free_cams[f];
     double acc[27];
     _Pragma("unroll") for (int k = 0; k < 27; k++) acc[k] = 0.0;
-    for (int p0 = lane; p0 < np; p0 += 64 * BA_ILP) {
-      int ii[BA_ILP]; MeasState ms[BA_ILP]; double e[BA_ILP][2];
-      _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) ii[u] = p0 + 64 * u < np ? v.lut[(size_t)j * v.max_pts + p0 + 64 * u] : -1;
-      _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) {
-        ba_load_state(v, ii[u], ms[u]);
-        const int ic = ii[u] < 0 ? 0 : ii[u];
-        e[u][0] = MS(ms_eps, 0, ic); e[u][1] = MS(ms_eps, 1, ic);
-      }
-      _Pragma("unroll") for (int u = 0; u < BA_ILP; u++) {
-        if (ms[u].st != MS_OK) continue;
-        double A[12];
-        ba_jac_A(ms[u].cm, ms[u].d, A);
-        int q = 0;
-        _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) acc[q++] += A[r] * A[c] + A[6 + r] * A[6 + c];       // :40-47
-        _Pragma("unroll") for (int r = 0; r < 6; r++) acc[21 + r] += A[r] * e[u][0] + A[6 + r] * e[u][1];
-      }
+    for (int p = lane; p < np; p += 64) {
+      const int s = ba_slot_of(v, p, f);
+      MeasState ms;
+      ba_load_state(v, s, ms);
+      if (ms.st != MS_OK) continue;
+      const double e0 = SL(sl_eps, 0, s), e1 = SL(sl_eps, 1, s);
+      double A[12];
+      ba_jac_A(ms.cm, ms.d, A);
+      int q = 0;
+      _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) acc[q++] += A[r] * A[c] + A[6 + r] * A[6 + c];
+      _Pragma("unroll") for (int r = 0; r < 6; r++) acc[21 + r] += A[r] * e0 + A[6 + r] * e1;
     }
     _Pragma("unroll") for (int k = 0; k < 27; k++) acc[k] = ba_wave_sum(acc[k]);
     if (lane == 0) {
@@ -531,33 +638,27 @@ __device__ __attribute__((noinline)) void ba_accum_U(const BaView& v_, int nfree
   }
 }
 
-// S diagonal block + E of one adjustable camera (jni/Bundle.cc:362-396); called by one wavefront.
+// S diagonal block + E of one adjustable camera (jni/Bundle.cc:362-396); called by one wavefront.  (More than BA_MFMA_FREE cameras.)
 __device__ __attribute__((noinline)) void ba_task_diag(const BaView& v_, int task, int np, int nS, double lambda) {
   const BaViewG v = ba_g(v_);
   const int lane = threadIdx.x & 63;
   const int j = v.free_cams[task], row = v.cam_row[j];
   double acc[27];
   _Pragma("unroll") for (int k = 0; k < 27; k++) acc[k] = 0.0;
-  for (int p0 = lane; p0 < np; p0 += 64 * BA_ILP_S) {
-    int ii[BA_ILP_S]; MeasState ms[BA_ILP_S]; double Vi[BA_ILP_S][9], eb[BA_ILP_S][3];
-    _Pragma("unroll") for (int u = 0; u < BA_ILP_S; u++) ii[u] = p0 + 64 * u < np ? v.lut[(size_t)j * v.max_pts + p0 + 64 * u] : -1;
-    _Pragma("unroll") for (int u = 0; u < BA_ILP_S; u++) {
-      const int p = p0 + 64 * u < np ? p0 + 64 * u : np - 1;
-      ba_load_state(v, ii[u], ms[u]);
-      _Pragma("unroll") for (int k = 0; k < 9; k++) Vi[u][k] = PT(pt_Vinv, k, p);
-      _Pragma("unroll") for (int k = 0; k < 3; k++) eb[u][k] = PT(pt_eb, k, p);
-    }
-    _Pragma("unroll") for (int u = 0; u < BA_ILP_S; u++) {
-      if (ms[u].st != MS_OK) continue;
-      double W[18], Y[18];
-      ba_jac_W(ms[u], v.cam_pose[j].R, W);
-      _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c < 3; c++) Y[r * 3 + c] = W[r * 3] * Vi[u][c] + W[r * 3 + 1] * Vi[u][3 + c] + W[r * 3 + 2] * Vi[u][6 + c];
-      int q = 0;
-      _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) acc[q++] += Y[r * 3] * W[c * 3] + Y[r * 3 + 1] * W[c * 3 + 1] + Y[r * 3 + 2] * W[c * 3 + 2];
-      double ve[3];
-      _Pragma("unroll") for (int r = 0; r < 3; r++) ve[r] = Vi[u][r * 3] * eb[u][0] + Vi[u][r * 3 + 1] * eb[u][1] + Vi[u][r * 3 + 2] * eb[u][2];
-      _Pragma("unroll") for (int r = 0; r < 6; r++) acc[21 + r] += W[r * 3] * ve[0] + W[r * 3 + 1] * ve[1] + W[r * 3 + 2] * ve[2];
-    }
+  for (int p = lane; p < np; p += 64) {
+    MeasState ms;
+    ba_load_state(v, ba_slot_of(v, p, task), ms);
+    if (ms.st != MS_OK) continue;
+    double Vi[9], W[18], Y[18];
+    ba_vstar_inv(v, p, lambda, Vi);
+    const double eb[3] = {PT(pt_eb, 0, p), PT(pt_eb, 1, p), PT(pt_eb, 2, p)};
+    ba_jac_W(ms, v.cam_pose[j].R, W);
+    _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c < 3; c++) Y[r * 3 + c] = W[r * 3] * Vi[c] + W[r * 3 + 1] * Vi[3 + c] + W[r * 3 + 2] * Vi[6 + c];
+    int q = 0;
+    _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) acc[q++] += Y[r * 3] * W[c * 3] + Y[r * 3 + 1] * W[c * 3 + 1] + Y[r * 3 + 2] * W[c * 3 + 2];
+    double ve[3];
+    _Pragma("unroll") for (int r = 0; r < 3; r++) ve[r] = Vi[r * 3] * eb[0] + Vi[r * 3 + 1] * eb[1] + Vi[r * 3 + 2] * eb[2];
+    _Pragma("unroll") for (int r = 0; r < 6; r++) acc[21 + r] += W[r * 3] * ve[0] + W[r * 3 + 1] * ve[1] + W[r * 3 + 2] * ve[2];
   }
   _Pragma("unroll") for (int k = 0; k < 27; k++) acc[k] = ba_wave_sum(acc[k]);
   if (lane == 0) {
@@ -575,7 +676,7 @@ __device__ __attribute__((noinline)) void ba_task_diag(const BaView& v_, int tas
 }
 
 // S off-diagonal block of one pair of adjustable cameras (:400-426); called by one wavefront.
-__device__ __attribute__((noinline)) void ba_task_pair(const BaView& v_, int task, int np, int nS) {
+__device__ __attribute__((noinline)) void ba_task_pair(const BaView& v_, int task, int np, int nS, double lambda) {
   const BaViewG v = ba_g(v_);
   const int lane = threadIdx.x & 63;
   int t = task, fj = 1;
@@ -585,31 +686,21 @@ __device__ __attribute__((noinline)) void ba_task_pair(const BaView& v_, int tas
   const int jrow = v.cam_row[j], krow = v.cam_row[k];
   double acc[36];
   _Pragma("unroll") for (int q = 0; q < 36; q++) acc[q] = 0.0;
-  for (int p0 = lane; p0 < np; p0 += 64 * BA_ILP_S) {
-    int ij[BA_ILP_S], ik[BA_ILP_S]; MeasState mj[BA_ILP_S], mk[BA_ILP_S]; double Vi[BA_ILP_S][9];
-    _Pragma("unroll") for (int u = 0; u < BA_ILP_S; u++) {
-      const bool in = p0 + 64 * u < np;
-      ij[u] = in ? v.lut[(size_t)j * v.max_pts + p0 + 64 * u] : -1;
-      ik[u] = in ? v.lut[(size_t)k * v.max_pts + p0 + 64 * u] : -1;
+  for (int p = lane; p < np; p += 64) {
+    MeasState mj, mk;
+    ba_load_state(v, ba_slot_of(v, p, fj), mj);
+    ba_load_state(v, ba_slot_of(v, p, fk), mk);
+    if (mj.st != MS_OK || mk.st != MS_OK) continue;
+    double Vi[9], Y[18];
+    ba_vstar_inv(v, p, lambda, Vi);
+    {
+      double Wj[18];
+      ba_jac_W(mj, v.cam_pose[j].R, Wj);
+      _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c < 3; c++) Y[r * 3 + c] = Wj[r * 3] * Vi[c] + Wj[r * 3 + 1] * Vi[3 + c] + Wj[r * 3 + 2] * Vi[6 + c];
     }
-    _Pragma("unroll") for (int u = 0; u < BA_ILP_S; u++) {
-      const int p = p0 + 64 * u < np ? p0 + 64 * u : np - 1;
-      ba_load_state(v, ij[u], mj[u]);
-      ba_load_state(v, ik[u], mk[u]);
-      _Pragma("unroll") for (int q = 0; q < 9; q++) Vi[u][q] = PT(pt_Vinv, q, p);
-    }
-    _Pragma("unroll") for (int u = 0; u < BA_ILP_S; u++) {
-      if (mj[u].st != MS_OK || mk[u].st != MS_OK) continue;
-      double Y[18];
-      {
-        double Wj[18];
-        ba_jac_W(mj[u], v.cam_pose[j].R, Wj);
-        _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c < 3; c++) Y[r * 3 + c] = Wj[r * 3] * Vi[u][c] + Wj[r * 3 + 1] * Vi[u][3 + c] + Wj[r * 3 + 2] * Vi[u][6 + c];
-      }
-      double Wk[18];
-      ba_jac_W(mk[u], v.cam_pose[k].R, Wk);
-      _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) acc[r * 6 + c] += Y[r * 3] * Wk[c * 3] + Y[r * 3 + 1] * Wk[c * 3 + 1] + Y[r * 3 + 2] * Wk[c * 3 + 2];
-    }
+    double Wk[18];
+    ba_jac_W(mk, v.cam_pose[k].R, Wk);
+    _Pragma("unroll") for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) acc[r * 6 + c] += Y[r * 3] * Wk[c * 3] + Y[r * 3 + 1] * Wk[c * 3 + 1] + Y[r * 3 + 2] * Wk[c * 3 + 2];
   }
   _Pragma("unroll") for (int q = 0; q < 36; q++) acc[q] = ba_wave_sum(acc[q]);
   if (lane == 0)
@@ -622,12 +713,11 @@ __device__ __attribute__((noinline)) void ba_task_pair(const BaView& v_, int tas
 // The whole reduced camera system of one LM trial, S = U* - sum_p Y_p W_p^T and E = ea - sum_p Y_p eb_p (jni/Bundle.cc:362-434),
 // for problems with at most BA_MFMA_FREE adjustable cameras (BundleAdjustRecent: 5) as ONE fp64 matrix product on the
 // matrix cores: per point p the 6 n_free x 3 stack Y_p (= W_j V*^-1 of every adjustable camera that measures p, zero rows
-// otherwise, plus one row V*^-1 eb_p) times the 3 x 6 n_free stack W_p^T.  The wave-per-block form above re-derives W_j and Y_j for
-// every camera pair (10 x 650 + 5 x 400 fp64 instructions per point); here each (point, camera) is derived once (one lane
-// each, BA_MFMA_PPC points per wavefront and trip), staged k-major in LDS and multiplied by v_mfma_f64_16x16x4_f64
+// otherwise, plus one row V*^-1 eb_p) times the 3 x 6 n_free stack W_p^T.  One lane per (point, adjustable camera) derives W and Y
+// once, BA_MFMA_PPC points per wavefront and trip -- their F slots are contiguous, so the operands are read coalesced --
+// staged k-major in LDS and multiplied by v_mfma_f64_16x16x4_f64
 // (operand layout: tools/probes/mfma_f64_layout.hip; a = A[l%16][l/16], b = B[l/16][l%16], d[v] = D[l/16+4v][l%16]).
 // Wave partials are added in wave order, the lower triangle is mirrored as the reference mirrors it (:431-434).
-#define BA_MFMA_FREE 5
 #ifndef BA_MFMA_PPC
 #define BA_MFMA_PPC 12                                  // points per wavefront and trip: 12 x 5 cameras = 60 lanes, K = 36
 #endif
@@ -649,32 +739,34 @@ __device__ __attribute__((noinline)) void ba_schur_mfma(const BaView& v_, int nf
   ba_v4d d00 = {0, 0, 0, 0}, d10 = {0, 0, 0, 0}, d11 = {0, 0, 0, 0};
   __builtin_amdgcn_s_waitcnt(0);
   __builtin_amdgcn_wave_barrier();
-  // two-deep software pipeline over the trips: the measurement index of trip t+2 and the operands of trip t+1 are in
-  // flight while trip t is derived, staged and multiplied (lut -> state is a dependent pair of global round trips)
+  // software pipeline over the trips: the operands of trip t+1 are in flight while trip t is derived, staged and multiplied
   constexpr int STRIDE = BA_WAVES * BA_MFMA_PPC;
   const int pfirst = wave * BA_MFMA_PPC;
-  auto lut_of = [&](int p0) -> int { const int p = p0 + pl; return (active && p < np) ? v.lut[(size_t)j * v.max_pts + p] : -1; };
-  int i_nxt = lut_of(pfirst + STRIDE);
-  MeasState ms_n; double Vi_n[9], eb_n[3];
+  auto slot_at = [&](int p0) -> int { const int p = p0 + pl; return (active && p < np) ? ba_slot_of(v, p, f) : -1; };
+  MeasState ms_n; double V_n[6], eb_n[3];
   {
     const int pc = pfirst + pl < np ? pfirst + pl : np - 1;
-    ba_load_state(v, lut_of(pfirst), ms_n);
-    _Pragma("unroll") for (int k = 0; k < 9; k++) Vi_n[k] = PT(pt_Vinv, k, pc);
+    ba_load_state(v, slot_at(pfirst), ms_n);
+    _Pragma("unroll") for (int k = 0; k < 6; k++) V_n[k] = PT(pt_V, k, pc);
     _Pragma("unroll") for (int k = 0; k < 3; k++) eb_n[k] = PT(pt_eb, k, pc);
   }
   for (int p0 = pfirst; p0 < np; p0 += STRIDE) {
     const int p = p0 + pl;
     const MeasState ms = ms_n;
-    double Vi[9], eb[3];
-    _Pragma("unroll") for (int k = 0; k < 9; k++) Vi[k] = Vi_n[k];
+    double Vl[6], eb[3];
+    _Pragma("unroll") for (int k = 0; k < 6; k++) Vl[k] = V_n[k];
     _Pragma("unroll") for (int k = 0; k < 3; k++) eb[k] = eb_n[k];
     {
-      const int i_cur = i_nxt;
-      i_nxt = lut_of(p0 + 2 * STRIDE);
       const int pn = p0 + STRIDE + pl, pc = pn < np ? pn : np - 1;
-      ba_load_state(v, i_cur, ms_n);
-      _Pragma("unroll") for (int k = 0; k < 9; k++) Vi_n[k] = PT(pt_Vinv, k, pc);
+      ba_load_state(v, slot_at(p0 + STRIDE), ms_n);
+      _Pragma("unroll") for (int k = 0; k < 6; k++) V_n[k] = PT(pt_V, k, pc);
       _Pragma("unroll") for (int k = 0; k < 3; k++) eb_n[k] = PT(pt_eb, k, pc);
+    }
+    double Vi[9];                                                       // V*^-1 (:329-347)
+    if (Vl[0] * Vl[2] * Vl[5] == 0) { _Pragma("unroll") for (int k = 0; k < 9; k++) Vi[k] = 0.0; }
+    else {
+      const double Vs[9] = {Vl[0] * (1.0 + lambda), Vl[1], Vl[3], Vl[1], Vl[2] * (1.0 + lambda), Vl[4], Vl[3], Vl[4], Vl[5] * (1.0 + lambda)};
+      inv3(Vs, Vi);
     }
     double W[18], Y[18];
     if (ms.st == MS_OK) {
@@ -729,33 +821,122 @@ __device__ __attribute__((noinline)) void ba_schur_mfma(const BaView& v_, int nf
 }
 
 // map updates (jni/Bundle.cc:440-462, :484): trial point positions; returns this thread's share of |update|^2.
-__device__ __attribute__((noinline)) double ba_map_update(const BaView& v_, int nfree, int np) {
+// Up to BA_MFMA_FREE adjustable cameras: the lane mapping of ba_schur_mfma (one lane per (point, camera), contiguous F slots);
+// the first lane of a point adds the cameras' terms in camera order.
+__device__ __attribute__((noinline)) double ba_map_update(const BaView& v_, int nfree, int np, double lambda) {
   const BaViewG v = ba_g(v_);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double ssq = 0.0;
-  for (int p = threadIdx.x; p < np; p += BA_THREADS) {
-    double sum[3] = {0, 0, 0};
-    for (int f0 = 0; f0 < nfree; f0 += BA_ILP_P) {
-      int jj[BA_ILP_P]; MeasState ms[BA_ILP_P];
-      _Pragma("unroll") for (int u = 0; u < BA_ILP_P; u++) jj[u] = v.free_cams[f0 + u < nfree ? f0 + u : nfree - 1];
-      _Pragma("unroll") for (int u = 0; u < BA_ILP_P; u++) ba_load_state(v, f0 + u < nfree ? v.lut[(size_t)jj[u] * v.max_pts + p] : -1, ms[u]);
-      _Pragma("unroll") for (int u = 0; u < BA_ILP_P; u++) {
-        if (ms[u].st != MS_OK) continue;
+  if (nfree > 0 && nfree <= BA_MFMA_FREE) {
+    const bool active = lane < BA_MFMA_PPC * nfree;
+    const int pl = active ? lane / nfree : 0, f = active ? lane - pl * nfree : 0;
+    const int j = v.free_cams[f];
+    double Rj[9], cu[6];
+    _Pragma("unroll") for (int k = 0; k < 9; k++) Rj[k] = v.cam_pose[j].R[k];
+    _Pragma("unroll") for (int k = 0; k < 6; k++) cu[k] = v.cam_up[v.cam_row[j] + k];
+    for (int p0 = wave * BA_MFMA_PPC; p0 < np; p0 += BA_WAVES * BA_MFMA_PPC) {
+      const int p = p0 + pl;
+      const bool inr = active && p < np;
+      MeasState ms;
+      ba_load_state(v, inr ? ba_slot_of(v, p, f) : -1, ms);
+      double t[3] = {0, 0, 0};
+      if (ms.st == MS_OK) {
         double W[18];
-        ba_jac_W(ms[u], v.cam_pose[jj[u]].R, W);
-        const double AS1* cu = v.cam_up + v.cam_row[jj[u]];
-        _Pragma("unroll") for (int c = 0; c < 3; c++) { double s = 0; for (int r = 0; r < 6; r++) s += W[r * 3 + c] * cu[r]; sum[c] += s; }
+        ba_jac_W(ms, Rj, W);
+        _Pragma("unroll") for (int c = 0; c < 3; c++) { double s = 0; for (int r = 0; r < 6; r++) s += W[r * 3 + c] * cu[r]; t[c] = s; }
+      }
+      double sum[3] = {0, 0, 0};
+      for (int ff = 0; ff < nfree; ff++) {
+        const int src = pl * nfree + ff;
+        const double a0 = __shfl(t[0], src), a1 = __shfl(t[1], src), a2 = __shfl(t[2], src);
+        // a camera that does not measure the point (or whose measurement is bad) contributes nothing, as in the reference's loop
+        const bool has = __shfl(ms.st == MS_OK ? 1 : 0, src) != 0;
+        if (has) { sum[0] += a0; sum[1] += a1; sum[2] += a2; }
+      }
+      if (inr && f == 0) {
+        const double eb[3] = {PT(pt_eb, 0, p), PT(pt_eb, 1, p), PT(pt_eb, 2, p)};
+        double Vi[9];
+        ba_vstar_inv(v, p, lambda, Vi);
+        const double x[3] = {eb[0] - sum[0], eb[1] - sum[1], eb[2] - sum[2]};
+        _Pragma("unroll") for (int r = 0; r < 3; r++) {
+          const double u = Vi[r * 3] * x[0] + Vi[r * 3 + 1] * x[1] + Vi[r * 3 + 2] * x[2];
+          ssq += u * u;
+          v.pt_new[3 * p + r] = v.pt_pos[3 * p + r] + u;               // :484
+        }
       }
     }
+    return ssq;
+  }
+  for (int p = threadIdx.x; p < np; p += BA_THREADS) {               // any number of adjustable cameras: one lane per point, its F slots in order
+    double sum[3] = {0, 0, 0};
+    const int s0 = v.pt_offF[p], s1 = v.pt_offF[p + 1];
+    for (int s = s0; s < s1; s++) {
+      MeasState ms;
+      ba_load_state(v, s, ms);
+      if (ms.st != MS_OK) continue;
+      const int jj = SL_CAM(v.sl_info[s]);
+      double W[18];
+      ba_jac_W(ms, v.cam_pose[jj].R, W);
+      const double AS1* cu = v.cam_up + v.cam_row[jj];
+      _Pragma("unroll") for (int c = 0; c < 3; c++) { double sx = 0; for (int r = 0; r < 6; r++) sx += W[r * 3 + c] * cu[r]; sum[c] += sx; }
+    }
     const double eb[3] = {PT(pt_eb, 0, p), PT(pt_eb, 1, p), PT(pt_eb, 2, p)};
-    double Vi[9]; _Pragma("unroll") for (int k = 0; k < 9; k++) Vi[k] = PT(pt_Vinv, k, p);
+    double Vi[9];
+    ba_vstar_inv(v, p, lambda, Vi);
     const double x[3] = {eb[0] - sum[0], eb[1] - sum[1], eb[2] - sum[2]};
     _Pragma("unroll") for (int r = 0; r < 3; r++) {
       const double u = Vi[r * 3] * x[0] + Vi[r * 3 + 1] * x[1] + Vi[r * 3 + 2] * x[2];
       ssq += u * u;
-      v.pt_new[3 * p + r] = v.pt_pos[3 * p + r] + u;               // :484
+      v.pt_new[3 * p + r] = v.pt_pos[3 * p + r] + u;
     }
   }
   return ssq;
+}
+
+// Erase the outliers of this step in LIST order (jni/Bundle.cc:517-528).  The slots are point-major, the reference's list is
+// whatever order AddMeas was called in: the bad slots mark their list index in an LDS bit map, then the map is expanded in
+// index order (popcount scan) into the (p, c) pairs.  Returns the new total of outlier measurements.
+__device__ __attribute__((noinline)) int ba_erase_outliers(const BaView& v_, int M, int nm, int nout, unsigned* bits /* LDS [(max_meas + 31) / 32] */, int* ired) {
+  const BaViewG v = ba_g(v_);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nwords = (nm + 31) >> 5;
+  for (int t = threadIdx.x; t < nwords; t += BA_THREADS) bits[t] = 0u;
+  __syncthreads();
+  int mine = 0;
+  for (int s = threadIdx.x; s < M; s += BA_THREADS) {
+    const int info = v.sl_info[s];
+    if (SL_STATE(info) != MS_BAD) continue;
+    v.sl_info[s] = SL_WITH_STATE(info, MS_ERASED);
+    v.scratch[s] = __builtin_huge_val();
+    const int i = v.sl_logical[s];
+    atomicOr(&bits[i >> 5], 1u << (i & 31));
+    atomicAdd((int*)&v.pt_nout[v.sl_pt[s]], 1);
+    mine++;
+  }
+  const int total = ba_block_sum_i(mine, ired);                     // (barriers inside: the bit map is complete)
+  if (total == 0) return nout;
+  int base = nout;
+  for (int w0 = 0; w0 < nwords; w0 += BA_THREADS) {
+    const int w = w0 + threadIdx.x;
+    unsigned m = w < nwords ? bits[w] : 0u;
+    const int cnt = __popc(m);
+    int inc = cnt;
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+    __syncthreads();
+    if (lane == 63) ired[wave] = inc;
+    __syncthreads();
+    int off = base + inc - cnt;
+    for (int ww = 0; ww < BA_WAVES; ww++) { if (ww < wave) off += ired[ww]; base += ired[ww]; }
+    while (m) {
+      const int b = __ffs((int)m) - 1;
+      m &= m - 1;
+      const int i = (w << 5) + b;
+      v.outl[2 * off] = v.ms_p[i]; v.outl[2 * off + 1] = v.ms_c[i];
+      off++;
+    }
+  }
+  __syncthreads();
+  return base;
 }
 
 // Bundle::Compute.  Called by all BA_THREADS threads of one workgroup.
@@ -787,18 +968,23 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
 #ifdef VSLAM_BA_PROF
   unsigned long long ba_t0 = clock64();
 #endif
+  static_assert(sizeof(lds_buf) >= 2 * 4097 * sizeof(int) && sizeof(lds_buf) >= (65536 / 32) * sizeof(unsigned) &&
+                sizeof(lds_buf) >= (BA_WAVES * 64 * 9 + BA_WAVES * BA_MFMA_FREE * 32) * sizeof(double), "the LDS buffer serves the layout, the step sweep and the erase");
+  ba_build_layout(v_, nc, np, ired, (int*)lds_buf);
+  const int M = v.ch_n[3];                                            // slots = measurements of the list
+  BA_STAMP(0);
 
   while (!sh_converged && !sh_hitmax && !sh_error) {             // :153 (no abort signal: the map-maker runs synchronously)
     // ================= Do_LM_Step =================
-    // pass 1 (:209-215): project every measurement still in the list
-    const bool cached = sh_cache_valid != 0;                       // the previous step was accepted: FindNewError has projected this state
+    // pass 1 (:209-215): the squared errors of the measurements still in the list, for the median
+    const bool cached = sh_cache_valid != 0;                       // the previous step was accepted: FindNewError has left them
     int nvalid;
     if (cached) nvalid = sh_next_nvalid;
-    else nvalid = ba_block_sum_i(ba_pass1_project(v_, cfg, nm), ired);
+    else nvalid = ba_block_sum_i(ba_find_new_error(v_, cfg, M, 1.0, 0).nvalid, ired);
     BA_STAMP(1);
     if (nvalid == 0) { if (threadIdx.x == 0) sh_error = 1; __syncthreads(); break; }
     {                                                              // :220-227 Tukey sigma, clamped
-      const double med = block_radix_select(v.scratch, nm, nvalid / 2, hist, sel);
+      const double med = block_radix_select(v.scratch, M, nvalid / 2, hist, sel);
       double s2 = tukey_sigma_squared(med, (unsigned long)nvalid);
       if (s2 < cfg.min_sigma2) s2 = cfg.min_sigma2;
       if (threadIdx.x == 0) sh_sigma2 = s2;
@@ -806,63 +992,43 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
     }
     const double sigma2 = sh_sigma2;
     BA_STAMP(2);
-    // pass 2 (:241-321): weights and objective; A, B, W are re-derived by their consumers
-    double cur = 0.0;
-    if (cached) cur = ba_pass12_cached(v_, cfg, nm, sigma2);
-    else for (int i0 = threadIdx.x; i0 < nm; i0 += BA_ILP_W * BA_THREADS) {   // BA_ILP_W measurements in flight per thread
-      int stt[BA_ILP_W]; double e2[BA_ILP_W], ep0[BA_ILP_W], ep1[BA_ILP_W], sn[BA_ILP_W], dd[BA_ILP_W][4];
-      _Pragma("unroll") for (int u = 0; u < BA_ILP_W; u++) {
-        const int i = i0 + u * BA_THREADS, ic = i < nm ? i : nm - 1;   // unconditional loads: no branch between them
-        stt[u] = v.ms_state[ic];
-        e2[u] = v.ms_err2[ic]; ep0[u] = MS(ms_eps, 0, ic); ep1[u] = MS(ms_eps, 1, ic); sn[u] = v.ms_sin[ic];
-        _Pragma("unroll") for (int k = 0; k < 4; k++) dd[u][k] = MS(ms_derivs, k, ic);
-        if (i >= nm) stt[u] = MS_ERASED;
-      }
-      _Pragma("unroll") for (int u = 0; u < BA_ILP_W; u++) {
-        const int i = i0 + u * BA_THREADS;
-        if (stt[u] == MS_ERASED) continue;
-        if (stt[u] == MS_BAD) { cur += 1.0; continue; }
-        const double dWeight = tukey_sqrt_weight(e2[u], sigma2);
-        MS(ms_eps, 0, i) = ep0[u] * dWeight; MS(ms_eps, 1, i) = ep1[u] * dWeight;
-        if (dWeight == 0) { v.ms_state[i] = MS_BAD; cur += 1.0; continue; }
-        cur += tukey_objective(e2[u], sigma2);
-        _Pragma("unroll") for (int k = 0; k < 4; k++) MS(ms_derivs, k, i) = sn[u] * (dWeight * dd[u][k]);   // weighted from here on
+    // passes 1 + 2 (:209-321) in one sweep: weights, objective, V / epsilon_b, U / epsilon_a; A, B, W are re-derived by their consumers
+    double* stg = lds_buf; double* ured = lds_buf + BA_WAVES * 64 * 9;
+    double cur = ba_step_sweep(v_, cfg, 0, sigma2, nfree, stg, ured);
+    __syncthreads();
+    if (nfree <= BA_MFMA_FREE) {
+      for (int t = threadIdx.x; t < nfree * 27; t += BA_THREADS) {     // wave partials in wave order
+        const int f = t / 27, q = t - 27 * f, j = v.free_cams[f];
+        double x = 0.0;
+        for (int w = 0; w < BA_WAVES; w++) x += ured[(w * BA_MFMA_FREE + f) * 32 + q];
+        if (q < 21) { int r = 0, qq = q; while (qq > r) { qq -= r + 1; r++; } v.cam_U[36 * j + r * 6 + qq] = x; }
+        else v.cam_ea[6 * j + (q - 21)] = x;
       }
     }
+    BA_STAMP(3);
+    cur += ba_step_sweep(v_, cfg, 1, sigma2, nfree, stg, ured);
     cur = ba_block_sum(cur, red);
     if (threadIdx.x == 0) sh_cur_err = cur;
     __syncthreads();
-    BA_STAMP(3);
-    ba_accum_V(v_, nc, np);
     BA_STAMP(4);
-    ba_accum_U(v_, nfree, np);
-    __syncthreads();
+    if (nfree > BA_MFMA_FREE) { ba_accum_U_generic(v_, nfree, np); __syncthreads(); }
     BA_STAMP(5);
     // ---- inner loop over lambda (:326-501) ----
     if (threadIdx.x == 0) sh_new_err = sh_cur_err + 9999;
     __syncthreads();
     while (sh_new_err > sh_cur_err && !sh_converged && !sh_hitmax && !sh_error) {
       const double lambda = sh_lambda;
-      for (int p = threadIdx.x; p < np; p += BA_THREADS) {           // V*^-1 (:329-347)
-        const double v00 = PT(pt_V, 0, p), v10 = PT(pt_V, 1, p), v11 = PT(pt_V, 2, p), v20 = PT(pt_V, 3, p), v21 = PT(pt_V, 4, p), v22 = PT(pt_V, 5, p);
-        double Vi[9];
-        if (v00 * v11 * v22 == 0) { _Pragma("unroll") for (int k = 0; k < 9; k++) Vi[k] = 0.0; }
-        else {
-          const double Vs[9] = {v00 * (1.0 + lambda), v10, v20, v10, v11 * (1.0 + lambda), v21, v20, v21, v22 * (1.0 + lambda)};
-          inv3(Vs, Vi);
-        }
-        _Pragma("unroll") for (int k = 0; k < 9; k++) PT(pt_Vinv, k, p) = Vi[k];
-      }
-      for (int t = threadIdx.x; t < nS * nS; t += BA_THREADS) v.S[t] = 0.0;
-      __syncthreads();
       BA_STAMP(6);
-      // S: diagonal blocks + E (:362-396) and off-diagonal blocks (:400-426); one wavefront per block
-      if (nfree <= BA_MFMA_FREE) ba_schur_mfma(v_, nfree, np, nS, lambda, lds_buf);
+      // S: diagonal blocks + E (:362-396) and off-diagonal blocks (:400-426); V*^-1 (:329-347) is formed where it is used
+      if (nfree == 0) { }                                              // only fixed cameras: no camera unknowns, the points move alone
+      else if (nfree <= BA_MFMA_FREE) ba_schur_mfma(v_, nfree, np, nS, lambda, lds_buf);
       else {
+        for (int t = threadIdx.x; t < nS * nS; t += BA_THREADS) v.S[t] = 0.0;
+        __syncthreads();
         const int ntask = nfree + nfree * (nfree - 1) / 2;
         for (int task = wave; task < ntask; task += BA_WAVES) {
           if (task < nfree) ba_task_diag(v_, task, np, nS, lambda);
-          else ba_task_pair(v_, task - nfree, np, nS);
+          else ba_task_pair(v_, task - nfree, np, nS, lambda);
         }
       }
       __syncthreads();
@@ -879,7 +1045,7 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
       __syncthreads();
       BA_STAMP(8);
       // map updates (:440-462)
-      double ssq = ba_map_update(v_, nfree, np);
+      double ssq = ba_map_update(v_, nfree, np, lambda);
       for (int t = threadIdx.x; t < nS; t += BA_THREADS) ssq += v.cam_up[t] * v.cam_up[t];
       ssq = ba_block_sum(ssq, red);                                    // :467-470
       for (int j = threadIdx.x; j < nc; j += BA_THREADS) {             // :476-482
@@ -894,7 +1060,7 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
       __syncthreads();
       BA_STAMP(9);
       // FindNewError (:537-561)
-      const BaNewError fne = ba_find_new_error(v_, cfg, nm, sigma2);
+      const BaNewError fne = ba_find_new_error(v_, cfg, M, sigma2, 1);
       const double ne = ba_block_sum(fne.ne, red);
       const int nv_next = ba_block_sum_i(fne.nvalid, ired);
       BA_STAMP(10);
@@ -916,36 +1082,10 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
     } else if (threadIdx.x == 0) sh_cache_valid = 0;
     __syncthreads();
     BA_STAMP(11);
-    // erase the outliers in list order (:517-528): ordered compaction of the (p, c) pairs, BA_ERASE_B chunks of the list
-    // per barrier pair (all their states are loaded first; one LDS table of per-chunk, per-wavefront counts)
-    {
-      constexpr int BA_ERASE_B = 8;
-      __shared__ int ecnt[BA_ERASE_B * BA_WAVES];
-      int base = sh_nout;
-      for (int i0 = 0; i0 < nm; i0 += BA_ERASE_B * BA_THREADS) {
-        bool bad[BA_ERASE_B]; unsigned long long bm[BA_ERASE_B];
-        _Pragma("unroll") for (int u = 0; u < BA_ERASE_B; u++) {
-          const int i = i0 + u * BA_THREADS + threadIdx.x;
-          bad[u] = v.ms_state[i < nm ? i : nm - 1] == MS_BAD && i < nm;
-        }
-        _Pragma("unroll") for (int u = 0; u < BA_ERASE_B; u++) { bm[u] = __ballot(bad[u]); if (lane == 0) ecnt[u * BA_WAVES + wave] = __popcll(bm[u]); }
-        __syncthreads();
-        _Pragma("unroll") for (int u = 0; u < BA_ERASE_B; u++) {
-          int off = base;
-          for (int w = 0; w < BA_WAVES; w++) { const int c = ecnt[u * BA_WAVES + w]; if (w < wave) off += c; base += c; }
-          if (bad[u]) {
-            const int i = i0 + u * BA_THREADS + threadIdx.x;
-            off += __popcll(bm[u] & ((1ull << lane) - 1ull));
-            const int pp = v.ms_p[i], cc = v.ms_c[i];
-            v.outl[2 * off] = pp; v.outl[2 * off + 1] = cc;
-            v.ms_state[i] = MS_ERASED;
-            v.lut[(size_t)cc * v.max_pts + pp] = -1;
-            atomicAdd((int*)&v.pt_nout[pp], 1);
-          }
-        }
-        __syncthreads();
-      }
-      if (threadIdx.x == 0) sh_nout = base;
+    {                                                                  // erase the outliers in list order (:517-528)
+      const int no = ba_erase_outliers(v_, M, nm, sh_nout, (unsigned*)lds_buf, ired);
+      __syncthreads();
+      if (threadIdx.x == 0) sh_nout = no;
       __syncthreads();
     }
     BA_STAMP(12);

@@ -2,6 +2,7 @@
 // Tukey M-estimator (jni/MEstimator.h), small dense solves.  Pure functions, no state.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "vslam_libm.h"
 
 #define DEVFN __device__ __forceinline__
 #define HDFN __host__ __device__ __forceinline__
@@ -60,7 +61,7 @@ HDFN void so3_exp(const double w[3], double R[9]) {                      // jni/
   double A, B;
   if (theta_sq < 1e-8) { A = 1.0 - one_6th * theta_sq; B = 0.5; }
   else if (theta_sq < 1e-6) { B = 0.5 - 0.25 * one_6th * theta_sq; A = 1.0 - theta_sq * one_6th * (1.0 - one_20th * theta_sq); }
-  else { const double inv_theta = 1.0 / theta; A = sin(theta) * inv_theta; B = (1 - cos(theta)) * (inv_theta * inv_theta); }
+  else { const double inv_theta = 1.0 / theta; A = vlm::vsin(theta) * inv_theta; B = (1 - vlm::vcos(theta)) * (inv_theta * inv_theta); }
   rodrigues(w, A, B, R);
 }
 
@@ -70,12 +71,12 @@ HDFN void so3_ln(const double M[9], double result[3]) {                  // jni/
   result[0] = (M[7] - M[5]) / 2; result[1] = (M[2] - M[6]) / 2; result[2] = (M[3] - M[1]) / 2;
   const double sin_angle_abs = sqrt(result[0] * result[0] + result[1] * result[1] + result[2] * result[2]);
   if (cos_angle > kSqrt1_2) {
-    if (sin_angle_abs > 0) { const double f = asin(sin_angle_abs) / sin_angle_abs; result[0] *= f; result[1] *= f; result[2] *= f; }
+    if (sin_angle_abs > 0) { const double f = vlm::vasin(sin_angle_abs) / sin_angle_abs; result[0] *= f; result[1] *= f; result[2] *= f; }
   } else if (cos_angle > -kSqrt1_2) {
-    const double f = acos(cos_angle) / sin_angle_abs;
+    const double f = vlm::vacos(cos_angle) / sin_angle_abs;
     result[0] *= f; result[1] *= f; result[2] *= f;
   } else {
-    const double angle = kPi - asin(sin_angle_abs);
+    const double angle = kPi - vlm::vasin(sin_angle_abs);
     const double d0 = M[0] - cos_angle, d1 = M[4] - cos_angle, d2 = M[8] - cos_angle;
     double r2[3];
     if (d0 * d0 > d1 * d1 && d0 * d0 > d2 * d2) { r2[0] = d0; r2[1] = (M[3] + M[1]) / 2; r2[2] = (M[2] + M[6]) / 2; }
@@ -101,7 +102,7 @@ HDFN Pose se3_exp(const double mu[6]) {                                  // jni/
   } else {
     double C;
     if (theta_sq < 1e-6) { C = one_6th * (1.0 - one_20th * theta_sq); A = 1.0 - theta_sq * C; B = 0.5 - 0.25 * one_6th * theta_sq; }
-    else { const double inv_theta = 1.0 / theta; A = sin(theta) * inv_theta; B = (1 - cos(theta)) * (inv_theta * inv_theta); C = (1 - A) * (inv_theta * inv_theta); }
+    else { const double inv_theta = 1.0 / theta; A = vlm::vsin(theta) * inv_theta; B = (1 - vlm::vcos(theta)) * (inv_theta * inv_theta); C = (1 - A) * (inv_theta * inv_theta); }
     const double wc[3] = {w[1] * cr[2] - w[2] * cr[1], w[2] * cr[0] - w[0] * cr[2], w[0] * cr[1] - w[1] * cr[0]};
     for (int i = 0; i < 3; i++) result.t[i] = mu[i] + B * cr[i] + C * wc[i];
   }
@@ -115,7 +116,7 @@ HDFN void se3_ln(const Pose& T, double out[6]) {                         // jni/
   const double rr = rotv[0] * rotv[0] + rotv[1] * rotv[1] + rotv[2] * rotv[2];
   const double theta = sqrt(rr);
   double shtot = 0.5;
-  if (theta > 0.00001) shtot = sin(theta / 2) / theta;
+  if (theta > 0.00001) shtot = vlm::vsin(theta / 2) / theta;
   const double half[3] = {rotv[0] * -0.5, rotv[1] * -0.5, rotv[2] * -0.5};
   Pose hr;
   so3_exp(half, hr.R);
@@ -157,7 +158,7 @@ HDFN void se3_generator_motion(int k, const double c[3], double ooz, double& f0,
 // ---- camera -------------------------------------------------------------------------------------------------
 HDFN double cam_rtrans_factor(const CamModel& c, double r) {              // jni/ATANCamera.h:136-142
   if (r < 0.001 || c.w == 0.0) return 1.0;
-  return c.winv * atan(r * c.two_tan) / r;
+  return c.winv * vlm::vatan(r * c.two_tan) / r;
 }
 HDFN CamProj cam_project(const CamModel& c, double cx, double cy) {        // jni/ATANCamera.cc:133-145
   CamProj p;
@@ -188,7 +189,7 @@ HDFN void cam_derivs(const CamModel& c, const CamProj& p, double d[4]) {   // jn
 HDFN void cam_unproject(const CamModel& c, double ix, double iy, double out[2]) {
   const double dx = (ix - c.center[0]) * (1.0 / c.focal[0]), dy = (iy - c.center[1]) * (1.0 / c.focal[1]);
   const double dist_r = sqrt(dx * dx + dy * dy);
-  const double r = c.w == 0.0 ? dist_r : tan(dist_r * c.w) * (1.0 / c.two_tan);
+  const double r = c.w == 0.0 ? dist_r : vlm::vtan(dist_r * c.w) * (1.0 / c.two_tan);
   const double f = dist_r > 0.01 ? r / dist_r : 1.0;
   out[0] = dx * f; out[1] = dy * f;
 }

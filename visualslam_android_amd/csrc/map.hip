@@ -201,6 +201,18 @@ extern "C" int vslam_set_velocity(vslam_system* sys, int s, const double v6[6]) 
   return put_state(sys, s, &st);
 }
 
+// Tracker::mnLastKeyFrameDropped (jni/Tracker.h:118; Reset sets -20, :59): the frame number of the stream's last keyframe.
+// A benchmark spreads the keyframe phases of its independent sequences with it (they would otherwise all ask for their first
+// keyframe in frame 1 and stay in step, one burst of bundle adjustments every ~21 frames).
+extern "C" int vslam_set_last_keyframe_dropped(vslam_system* sys, int s, int frame) {
+  CHK_STREAM(sys, s);
+  TrackerState st;
+  int r = get_state(sys, s, &st); if (r) return r;
+  reset_tracker_fields(st);
+  st.last_kf_dropped = frame;
+  return put_state(sys, s, &st);
+}
+
 int map_init_states(vslam_system* sys) {
   std::vector<TrackerState> v(sys->S);
   memset(v.data(), 0, sizeof(TrackerState) * sys->S);
@@ -210,25 +222,82 @@ int map_init_states(vslam_system* sys) {
 }
 
 // ---- per-frame entry points -------------------------------------------------------------------------------------
-extern "C" int vslam_track_frame(vslam_system* sys, const uint8_t* gray, size_t row_stride, size_t stream_stride, int on_device) {
+// VSLAM_PROFILE_SERIAL=1 (diagnostic): no overlap between the front-end, tracking and map-maker streams, so the
+// per-stage HIP-event times are those of each kernel running alone on the device.
+static bool profile_serial() { static const bool serial = getenv("VSLAM_PROFILE_SERIAL") != nullptr; return serial; }
+
+// TrackFrame in its pieces; vslam_track_frame is exactly vslam_make_keyframe_lite, vslam_patch_search(0), vslam_pose_update(0),
+// vslam_patch_search(1), vslam_pose_update(1), vslam_finish_frame.
+extern "C" int vslam_patch_search(vslam_system* sys, int stage) {
+  if (!sys || stage < 0 || stage > 1) { vslam_set_error("patch_search: bad argument"); return VSLAM_E_INVALID; }
+  if (!sys->have_frame) { vslam_set_error("patch_search: no current frame (vslam_make_keyframe_lite first)"); return VSLAM_E_STATE; }
+  if (stage == 0) {
+    if (sys->frame_open) { vslam_set_error("patch_search: the previous frame was not finished (vslam_finish_frame)"); return VSLAM_E_STATE; }
+    int r = ba_frame_start(sys);                                                       // deferred map-maker results that are due now
+    if (r) return r;
+    sys->frame_open = true;
+  } else if (!sys->frame_open) { vslam_set_error("patch_search: stage 1 before stage 0"); return VSLAM_E_STATE; }
+  return trk_search_stage(sys, stage);
+}
+
+extern "C" int vslam_pose_update(vslam_system* sys, int stage) {
+  if (!sys || stage < 0 || stage > 1) { vslam_set_error("pose_update: bad argument"); return VSLAM_E_INVALID; }
+  if (!sys->frame_open) { vslam_set_error("pose_update: no search stage has run on this frame"); return VSLAM_E_STATE; }
+  return trk_pose_stage(sys, stage);
+}
+
+extern "C" int vslam_finish_frame(vslam_system* sys) {
   if (!sys) return VSLAM_E_INVALID;
-  // VSLAM_PROFILE_SERIAL=1 (diagnostic): no overlap between the front-end, tracking and map-maker streams, so the
-  // per-stage HIP-event times are those of each kernel running alone on the device.
-  static const bool serial = getenv("VSLAM_PROFILE_SERIAL") != nullptr;
-  int r = fe_make_keyframe_lite(sys, gray, row_stride, stream_stride, on_device);   // jni/Tracker.cc:85
-  if (r) return r;
-  if (serial) HIPCHK(hipStreamSynchronize(sys->fe_stream));
-  r = ba_frame_start(sys);                                                           // deferred map-maker results that are due now
-  if (r) return r;
-  r = trk_track_map(sys);                                                            // :103-124
-  if (r) return r;
-  r = ba_add_keyframe_and_adjust(sys);                                               // :128-132 -> MapMaker::AddKeyFrame
+  if (!sys->frame_open) { vslam_set_error("finish_frame: no frame in progress"); return VSLAM_E_STATE; }
+  sys->frame_open = false;
+  const int r = ba_add_keyframe_and_adjust(sys);                                       // :128-132 -> MapMaker::AddKeyFrame
   prof_mark(sys, VSLAM_N_STAGES);
   if (sys->prof_on && sys->prof_frame < sys->prof_cap) sys->prof_frame++;
-  if (!r) HIPCHK(hipEventRecord(sys->ev_track_done[sys->fr_idx], sys->stream));   // the front-end may now reuse this buffer
+  if (!r) HIPCHK(hipEventRecord(sys->ev_track_done[sys->fr_idx], sys->stream));       // the front-end may now reuse this buffer
   sys->frame_no++;
-  if (serial && !r) { HIPCHK(hipStreamSynchronize(sys->stream)); if (sys->ba_stream) HIPCHK(hipStreamSynchronize(sys->ba_stream)); }
+  if (profile_serial() && !r) { HIPCHK(hipStreamSynchronize(sys->stream)); int rs = ba_sync_streams(sys); if (rs) return rs; }
   return r;
+}
+
+extern "C" int vslam_track_frame(vslam_system* sys, const uint8_t* gray, size_t row_stride, size_t stream_stride, int on_device) {
+  if (!sys) return VSLAM_E_INVALID;
+  int r = fe_make_keyframe_lite(sys, gray, row_stride, stream_stride, on_device);   // jni/Tracker.cc:85
+  if (r) return r;
+  if (profile_serial()) HIPCHK(hipStreamSynchronize(sys->fe_stream));
+  r = vslam_patch_search(sys, 0);                                                    // :103-124 TrackMap
+  if (!r) r = vslam_pose_update(sys, 0);
+  if (!r) r = vslam_patch_search(sys, 1);
+  if (!r) r = vslam_pose_update(sys, 1);
+  if (r) { sys->frame_open = false; return r; }
+  return vslam_finish_frame(sys);
+}
+
+// Map editing after the upload (a host-side map-maker, map loading, tests that re-synchronise the map to a reference):
+// MapPoint::v3WorldPos of points [first, first + n) and KeyFrame::se3CfromW of one keyframe.
+extern "C" int vslam_map_set_point_positions(vslam_system* sys, int s, int first, int n, const double* pos3) {
+  CHK_STREAM(sys, s);
+  TrackerState st;
+  int r = get_state(sys, s, &st); if (r) return r;
+  if (!pos3 || first < 0 || n < 0 || first + n > st.n_points) { vslam_set_error("map_set_point_positions: bad range"); return VSLAM_E_INVALID; }
+  if (n == 0) return VSLAM_OK;
+  const int P = sys->p.max_points;
+  std::vector<MapPointDev> mp(n);
+  HIPCHK(hipMemcpy(mp.data(), sys->map.pts + (size_t)s * P + first, sizeof(MapPointDev) * n, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; i++) for (int q = 0; q < 3; q++) mp[i].pos[q] = pos3[3 * i + q];
+  HIPCHK(hipMemcpy(sys->map.pts + (size_t)s * P + first, mp.data(), sizeof(MapPointDev) * n, hipMemcpyHostToDevice));
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_map_set_keyframe_pose(vslam_system* sys, int s, int keyframe, const double pose12[12]) {
+  CHK_STREAM(sys, s);
+  TrackerState st;
+  int r = get_state(sys, s, &st); if (r) return r;
+  if (!pose12 || keyframe < 0 || keyframe >= st.n_kf) { vslam_set_error("map_set_keyframe_pose: bad argument"); return VSLAM_E_INVALID; }
+  Pose p;
+  for (int i = 0; i < 9; i++) p.R[i] = pose12[i];
+  for (int i = 0; i < 3; i++) p.t[i] = pose12[9 + i];
+  HIPCHK(hipMemcpy(sys->map.kf_pose + (size_t)s * sys->p.max_keyframes + keyframe, &p, sizeof(Pose), hipMemcpyHostToDevice));
+  return VSLAM_OK;
 }
 
 static const char* kStageNames[VSLAM_N_STAGES] = {"pyr_fast0", "fast_lvl", "compact", "pvs", "plan_coarse", "search_coarse", "pose_coarse",
@@ -240,6 +309,7 @@ extern "C" int vslam_profile_begin(vslam_system* sys, int max_frames) {
   HIPCHK(hipStreamSynchronize(sys->stream));
   while ((int)sys->prof_ev.size() < max_frames * PROF_MARKS) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); sys->prof_ev.push_back(e); }
   sys->prof_cap = max_frames; sys->prof_frame = 0; sys->prof_on = true;
+  sys->prof_ba_launched.assign((size_t)max_frames, 0);
   return VSLAM_OK;
 }
 
@@ -247,7 +317,7 @@ extern "C" int vslam_profile_end(vslam_system* sys, double* stage_ms, int* n_fra
   if (!sys || !stage_ms) return VSLAM_E_INVALID;
   HIPCHK(hipStreamSynchronize(sys->fe_stream));
   HIPCHK(hipStreamSynchronize(sys->stream));
-  if (sys->ba_stream) HIPCHK(hipStreamSynchronize(sys->ba_stream));
+  { int rs = ba_sync_streams(sys); if (rs) return rs; }
   sys->prof_on = false;
   for (int k = 0; k < VSLAM_N_STAGES; k++) stage_ms[k] = 0.0;
   for (int f = 0; f < sys->prof_frame; f++)
@@ -255,10 +325,22 @@ extern "C" int vslam_profile_end(vslam_system* sys, double* stage_ms, int* n_fra
       float ms = 0.f;
       int end = k == 2 ? PROF_FE_END : k + 1;   // stages 0..2 run on the front-end stream
       if (sys->tp.ba_delay > 0) { if (k == 11) end = VSLAM_N_STAGES; else if (k == 12) end = PROF_BA_END; else if (k == 13) end = 3; }
+      if (sys->tp.ba_delay > 0 && k == 12 && !(f < (int)sys->prof_ba_launched.size() && sys->prof_ba_launched[f])) continue;   // no launch in this frame
       HIPCHK(hipEventElapsedTime(&ms, sys->prof_ev[(size_t)f * PROF_MARKS + k], sys->prof_ev[(size_t)f * PROF_MARKS + end]));
       stage_ms[k] += ms;
     }
   if (n_frames) *n_frames = sys->prof_frame;
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_profile_launches(vslam_system* sys, int* launches) {
+  if (!sys || !launches) return VSLAM_E_INVALID;
+  for (int k = 0; k < VSLAM_N_STAGES; k++) launches[k] = sys->prof_frame;
+  if (sys->tp.ba_delay > 0) {
+    int n = 0;
+    for (int f = 0; f < sys->prof_frame && f < (int)sys->prof_ba_launched.size(); f++) n += sys->prof_ba_launched[f] ? 1 : 0;
+    launches[12] = n;
+  }
   return VSLAM_OK;
 }
 
@@ -281,8 +363,9 @@ extern "C" int vslam_get_state(vslam_system* sys, int s, vslam_track_state* o) {
   if (!o) return VSLAM_E_INVALID;
   TrackerState st;
   int r = get_state(sys, s, &st); if (r) return r;
-  for (int i = 0; i < 9; i++) o->pose[i] = st.pose_final.R[i];
-  for (int i = 0; i < 3; i++) o->pose[9 + i] = st.pose_final.t[i];
+  const Pose& T = sys->frame_open ? st.pose_cur : st.pose_final;   // between the stages of a frame: the tracker's current estimate
+  for (int i = 0; i < 9; i++) o->pose[i] = T.R[i];
+  for (int i = 0; i < 3; i++) o->pose[9 + i] = T.t[i];
   for (int i = 0; i < 6; i++) o->velocity[i] = st.velocity[i];
   o->msd_velocity = st.msd_vel; o->depth_mean = st.depth_mean; o->depth_sigma = st.depth_sigma;
   for (int i = 0; i < NLEV; i++) { o->attempted[i] = st.attempted[i]; o->found[i] = st.found[i]; }
@@ -353,6 +436,44 @@ extern "C" int vslam_get_keyframe_pose(vslam_system* sys, int s, int k, double p
   HIPCHK(hipMemcpy(&p, sys->map.kf_pose + (size_t)s * sys->p.max_keyframes + k, sizeof(p), hipMemcpyDeviceToHost));
   for (int i = 0; i < 9; i++) pose12[i] = p.R[i];
   for (int i = 0; i < 3; i++) pose12[9 + i] = p.t[i];
+  return VSLAM_OK;
+}
+
+// MapMaker::NeedNewKeyFrame (jni/MapMaker.cc:761-773) and IsDistanceToNearestKeyFrameExcessive (:1098-1101) for the stream's current
+// pose, on the host from the keyframe poses (the tracker takes both decisions on device, k_pose; these are the public members)
+static int nearest_keyframe_dist(vslam_system* sys, int s, TrackerState* st, double* dist) {
+  int r = get_state(sys, s, st); if (r) return r;
+  if (st->n_kf < 1) { vslam_set_error("no keyframes"); return VSLAM_E_STATE; }
+  std::vector<Pose> kp(st->n_kf);
+  HIPCHK(hipMemcpy(kp.data(), sys->map.kf_pose + (size_t)s * sys->p.max_keyframes, sizeof(Pose) * st->n_kf, hipMemcpyDeviceToHost));
+  const Pose ic = pose_inverse(st->pose_final);
+  double best = 9999999999.9;                                      // ClosestKeyFrame :737-758 with KeyFrameLinearDist :705-712
+  for (int k = 0; k < st->n_kf; k++) {
+    const Pose ik = pose_inverse(kp[k]);
+    const double d0 = ik.t[0] - ic.t[0], d1 = ik.t[1] - ic.t[1], d2 = ik.t[2] - ic.t[2];
+    const double d = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+    if (d < best) best = d;
+  }
+  *dist = best;
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_need_new_keyframe(vslam_system* sys, int s, int* need) {
+  CHK_STREAM(sys, s);
+  if (!need) return VSLAM_E_INVALID;
+  TrackerState st; double d;
+  int r = nearest_keyframe_dist(sys, s, &st, &d); if (r) return r;
+  d *= (1.0 / st.depth_mean);
+  *need = d > sys->p.max_kf_dist_wiggle_mult * st.wiggle_depth_norm ? 1 : 0;
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_distance_to_nearest_keyframe_excessive(vslam_system* sys, int s, int* excessive) {
+  CHK_STREAM(sys, s);
+  if (!excessive) return VSLAM_E_INVALID;
+  TrackerState st; double d;
+  int r = nearest_keyframe_dist(sys, s, &st, &d); if (r) return r;
+  *excessive = d > sys->p.wiggle_scale * 10.0 ? 1 : 0;
   return VSLAM_OK;
 }
 
@@ -428,4 +549,27 @@ extern "C" int vslam_get_template(vslam_system* sys, int s, int point, uint8_t* 
   HIPCHK(hipMemcpy(&fl, sys->map.pt_flags + (size_t)s * P + point, sizeof(int), hipMemcpyDeviceToHost));
   if (bad) *bad = (fl & TDF_TMPL_BAD) ? 1 : 0;
   return (fl & TDF_HAVE_LAST) ? 1 : 0;
+}
+
+// the same for the points [first, first + n) at once: tmpl n * P * P bytes, the other arrays n ints (any may be NULL)
+extern "C" int vslam_get_templates(vslam_system* sys, int s, int first, int n, uint8_t* tmpl, int* sum, int* sumsq, int* bad, int* have) {
+  CHK_STREAM(sys, s);
+  const int P = sys->p.max_points, PS = sys->p.patch_size;
+  if (first < 0 || n < 0 || first + n > P) return VSLAM_E_INVALID;
+  if (n == 0) return VSLAM_OK;
+  HIPCHK(hipStreamSynchronize(sys->stream));
+  std::vector<TrackData> td(n);
+  std::vector<uint8_t> raw((size_t)n * TMPL_PITCH);
+  std::vector<int> fl(n);
+  HIPCHK(hipMemcpy(td.data(), sys->map.td + (size_t)s * P + first, sizeof(TrackData) * n, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(raw.data(), sys->map.tmpl + ((size_t)s * P + first) * TMPL_PITCH, raw.size(), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(fl.data(), sys->map.pt_flags + (size_t)s * P + first, sizeof(int) * n, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; i++) {
+    if (tmpl) memcpy(tmpl + (size_t)i * PS * PS, raw.data() + (size_t)i * TMPL_PITCH, (size_t)PS * PS);
+    if (sum) sum[i] = td[i].tsum;
+    if (sumsq) sumsq[i] = td[i].tsumsq;
+    if (bad) bad[i] = (fl[i] & TDF_TMPL_BAD) ? 1 : 0;
+    if (have) have[i] = (fl[i] & TDF_HAVE_LAST) ? 1 : 0;
+  }
+  return VSLAM_OK;
 }

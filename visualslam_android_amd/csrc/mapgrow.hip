@@ -8,7 +8,7 @@
 //       :242-350, MapMaker::ReprojectPoint :174-200, MapPoint::RefreshPixelVectors jni/MapPoint.cc:4-29
 // One wavefront per candidate; the candidates of a level are independent of each other, new points are appended in
 // candidate order by an ordered commit (the reference's push_back order).  Not built: ReFind* (see DESIGN.md).
-// Eigen::JacobiSVD of the 4x4 triangulation matrix is third-party arithmetic, restated as in oracle/mapgrow.cpp (parity unpinned).
+// Eigen::JacobiSVD of the 4x4 triangulation matrix is third-party arithmetic, restated as a two-sided Jacobi SVD (parity unpinned).
 #include "vslam_internal.h"
 
 #define GROW_THREADS 256
@@ -75,7 +75,7 @@ template <int G> DEVFN int grow_grp_sum(int v) { for (int d = 1; d < G; d <<= 1)
 // MakeSubPixTemplate (jni/PatchFinder.cc:242-271) + IterateSubPixToConvergence (:273-350) by one wavefront, starting from
 // the level-zero position in sub0/sub1; these are left wherever the iteration stopped (ReFind_Common reads them regardless)
 template <int PS>
-DEVFN bool wave_subpix(const uint8_t* tmpl, const uint8_t* img, int ip, int wl, int hl, int nLevel, int max_its, int lane, double& sub0, double& sub1) {
+DEVFN bool wave_subpix(const uint8_t* tmpl, const uint8_t* img, int ip, int wl, int hl, int nLevel, int max_its, int lane, double& sub0, double& sub1, double* slab /* LDS [3][Q*Q] of this wavefront */) {
   constexpr int HALF = PS / 2, Q = PS - 2, NQL = (Q * Q + 63) / 64;
   const int nLevelScale = 1 << nLevel;
   double gx[NQL], gy[NQL];
@@ -104,7 +104,8 @@ DEVFN bool wave_subpix(const uint8_t* tmpl, const uint8_t* img, int ip, int wl, 
     const double dX = bx - floor(bx), dY = by - floor(by);
     const float fTL = (float)((1.0 - dX) * (1.0 - dY)), fTR = (float)((dX) * (1.0 - dY));
     const float fBL = (float)((1.0 - dX) * (dY)), fBR = (float)((dX) * (dY));
-    double a0 = 0, a1 = 0, a2 = 0;
+    // v3Accum in the reference's pixel order, y outer / x inner (:316-340): the per-pixel products go to LDS in that order
+    // and lanes 0..2 walk one sum each (a butterfly over the lanes would round differently)
     for (int q = 0; q < NQL; q++) {
       const int k = q * 64 + lane;
       if (k < Q * Q) {
@@ -112,10 +113,19 @@ DEVFN bool wave_subpix(const uint8_t* tmpl, const uint8_t* img, int ip, int wl, 
         const uint8_t* tl = img + (size_t)((int)by + y) * ip + (int)bx + x;
         const float fPixel = fTL * tl[0] + fTR * tl[1] + fBL * tl[ip] + fBR * tl[ip + 1];
         const double dDiff = (fPixel - (float)tmpl[y * PS + x]) + meanDiff;
-        a0 += dDiff * gx[q]; a1 += dDiff * gy[q]; a2 += dDiff;
+        const int o = (y - 1) * Q + (x - 1);
+        slab[o] = dDiff * gx[q]; slab[Q * Q + o] = dDiff * gy[q]; slab[2 * Q * Q + o] = dDiff;
       }
     }
-    a0 = wsum_d(a0); a1 = wsum_d(a1); a2 = wsum_d(a2);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    double acc = 0.0;
+    if (lane < 3) {
+      const double* sp = slab + lane * Q * Q;
+      _Pragma("unroll") for (int o = 0; o < Q * Q; o++) acc += sp[o];
+    }
+    const double a0 = __shfl(acc, 0), a1 = __shfl(acc, 1), a2 = __shfl(acc, 2);
+    __builtin_amdgcn_wave_barrier();
     const double u0 = Hinv[0] * a0 + Hinv[1] * a1 + Hinv[2] * a2;
     const double u1 = Hinv[3] * a0 + Hinv[4] * a1 + Hinv[5] * a2;
     const double u2 = Hinv[6] * a0 + Hinv[7] * a1 + Hinv[8] * a2;
@@ -125,31 +135,52 @@ DEVFN bool wave_subpix(const uint8_t* tmpl, const uint8_t* img, int ip, int wl, 
   return false;
 }
 
-// smallest-eigenvalue eigenvector of a symmetric 4x4 matrix: cyclic Jacobi, the same rotation sequence and the same stopping
-// rule as the oracle (at most 16 sweeps; stop once the off-diagonal sum is zero or below 1e-22 of the diagonal sum: further
-// rotations change no bit -- the fixed 16 sweeps on one lane were 60 % of k_epipolar)
-DEVFN void smallest_eigvec4(const double Sin[16], double out[4]) {
-  double S[16], V[16];
-  for (int i = 0; i < 16; i++) { S[i] = Sin[i]; V[i] = (i % 5 == 0) ? 1.0 : 0.0; }
-  _Pragma("unroll 1") for (int sweep = 0; sweep < 16; sweep++) {
-    _Pragma("unroll") for (int p = 0; p < 3; p++)
-      _Pragma("unroll") for (int q = p + 1; q < 4; q++) {
-        const double apq = S[p * 4 + q];
-        if (apq == 0.0) continue;
-        const double theta = (S[q * 4 + q] - S[p * 4 + p]) / (2.0 * apq);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < 4; k++) { const double a = S[k * 4 + p], b = S[k * 4 + q]; S[k * 4 + p] = c * a - s * b; S[k * 4 + q] = s * a + c * b; }
-        for (int k = 0; k < 4; k++) { const double a = S[p * 4 + k], b = S[q * 4 + k]; S[p * 4 + k] = c * a - s * b; S[q * 4 + k] = s * a + c * b; }
-        for (int k = 0; k < 4; k++) { const double a = V[k * 4 + p], b = V[k * 4 + q]; V[k * 4 + p] = c * a - s * b; V[k * 4 + q] = s * a + c * b; }
+// Eigen::JacobiSVD of the square 4x4 triangulation matrix (jni/MapMaker.cc:191-192): two-sided Jacobi on A itself as
+// published for Eigen 3.0-3.1 -- sweeps over the pairs (p, q), q < p; a pair is rotated while max(|m_pq|, |m_qp|) >
+// 2 eps max(|m_pp|, |m_qq|); the 2x2 step symmetrises the block with a left rotation, then diagonalises it with the Jacobi
+// rotation of the symmetric block; V collects the right rotations; the column of V of the smallest |m_ii| is
+// matrixV().col(3).  Statement for statement what oracle/mapgrow.cpp evaluates on the host (one lane, same order: same
+// bits).  Third-party arithmetic, version unpinned: parity unpinned against the reference.
+DEVFN void svd4_smallest_right_vector(const double Ain[16], double out[4]) {
+  double M[16], V[16];
+  for (int i = 0; i < 16; i++) { M[i] = Ain[i]; V[i] = (i % 5 == 0) ? 1.0 : 0.0; }
+  const double precision = 2.0 * 2.220446049250313e-16;
+  _Pragma("unroll 1") for (int sweep = 0; sweep < 64; sweep++) {
+    bool finished = true;
+    _Pragma("unroll") for (int p = 1; p < 4; p++)
+      _Pragma("unroll") for (int q = 0; q < p; q++) {
+        const double apq = fabs(M[p * 4 + q]), aqp = fabs(M[q * 4 + p]), off = apq > aqp ? apq : aqp;
+        const double app = fabs(M[p * 4 + p]), aqq = fabs(M[q * 4 + q]), dia = app > aqq ? app : aqq;
+        if (!(off > dia * precision)) continue;
+        finished = false;
+        const double m00 = M[p * 4 + p], m01 = M[p * 4 + q], m10 = M[q * 4 + p], m11 = M[q * 4 + q];
+        double c1, s1;
+        const double t = m00 + m11, d = m10 - m01;
+        if (t == 0.0) { c1 = 0.0; s1 = d > 0.0 ? 1.0 : -1.0; }
+        else { const double u = d / t; c1 = 1.0 / sqrt(1.0 + u * u); s1 = c1 * u; }
+        const double x = c1 * m00 + s1 * m10, y = c1 * m01 + s1 * m11, z = -s1 * m01 + c1 * m11;
+        double c2, s2;
+        if (y == 0.0) { c2 = 1.0; s2 = 0.0; }
+        else {
+          const double tau = (x - z) / (2.0 * fabs(y)), w = sqrt(tau * tau + 1.0);
+          const double tt = tau > 0.0 ? 1.0 / (tau + w) : 1.0 / (tau - w);
+          const double sign_t = tt > 0.0 ? 1.0 : -1.0, n = 1.0 / sqrt(tt * tt + 1.0);
+          s2 = -sign_t * (y / fabs(y)) * fabs(tt) * n; c2 = n;
+        }
+        const double cl = c1 * c2 + s1 * s2, sl = s1 * c2 - c1 * s2;
+        _Pragma("unroll") for (int k = 0; k < 4; k++) { const double a = M[p * 4 + k], b = M[q * 4 + k]; M[p * 4 + k] = cl * a + sl * b; M[q * 4 + k] = -sl * a + cl * b; }
+        _Pragma("unroll") for (int k = 0; k < 4; k++) { const double a = M[k * 4 + p], b = M[k * 4 + q]; M[k * 4 + p] = c2 * a - s2 * b; M[k * 4 + q] = s2 * a + c2 * b; }
+        _Pragma("unroll") for (int k = 0; k < 4; k++) { const double a = V[k * 4 + p], b = V[k * 4 + q]; V[k * 4 + p] = c2 * a - s2 * b; V[k * 4 + q] = s2 * a + c2 * b; }
       }
-    const double off = fabs(S[1]) + fabs(S[2]) + fabs(S[3]) + fabs(S[6]) + fabs(S[7]) + fabs(S[11]);
-    const double dia = fabs(S[0]) + fabs(S[5]) + fabs(S[10]) + fabs(S[15]);
-    if (off == 0.0 || off <= 1e-22 * dia) break;
+    if (finished) break;
   }
-  int best = 0;
-  for (int i = 1; i < 4; i++) if (S[i * 4 + i] < S[best * 4 + best]) best = i;
-  for (int k = 0; k < 4; k++) out[k] = V[k * 4 + best];
+  // the column of the smallest |m_ii| without a dynamically indexed register array (selects)
+  double bestv = fabs(M[0]);
+  out[0] = V[0]; out[1] = V[4]; out[2] = V[8]; out[3] = V[12];
+  _Pragma("unroll") for (int i = 1; i < 4; i++) {
+    const double a = fabs(M[i * 4 + i]);
+    if (a < bestv) { bestv = a; out[0] = V[i]; out[1] = V[4 + i]; out[2] = V[8 + i]; out[3] = V[12 + i]; }
+  }
 }
 
 // MapMaker::ReprojectPoint, jni/MapMaker.cc:174-200
@@ -158,10 +189,8 @@ DEVFN void reproject_point(const Pose& AfromB, const double v2A[2], const double
   for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) PD[r * 4 + c] = AfromB.R[r * 3 + c]; PD[r * 4 + 3] = AfromB.t[r]; }
   double A[16] = {-1.0, 0.0, v2B[0], 0.0, 0.0, -1.0, v2B[1], 0.0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int c = 0; c < 4; c++) { A[8 + c] = v2A[0] * PD[8 + c] - PD[0 + c]; A[12 + c] = v2A[1] * PD[8 + c] - PD[4 + c]; }
-  double S[16];
-  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { double s = 0; for (int k = 0; k < 4; k++) s += A[k * 4 + i] * A[k * 4 + j]; S[i * 4 + j] = s; }
   double v[4];
-  smallest_eigvec4(S, v);
+  svd4_smallest_right_vector(A, v);
   if (v[3] == 0.0) v[3] = 0.00001;
   out[0] = v[0] / v[3]; out[1] = v[1] / v[3]; out[2] = v[2] / v[3];
 }
@@ -241,6 +270,7 @@ __global__ __launch_bounds__(GROW_THREADS) __attribute__((amdgpu_waves_per_eu(2,
   __shared__ int sh_tgt;
   __shared__ EpiResult res[GROW_WAVES];
   __shared__ uint8_t sh_tmpl[GROW_WAVES][128];
+  __shared__ double sh_slab[GROW_WAVES][3 * (PS - 2) * (PS - 2)];
   constexpr int G = PS <= 8 ? 8 : 16, NPW = 64 / G;                 // lanes per patch, patches scored per wavefront step
   __shared__ int2 sh_sel[GROW_WAVES][NPW];
   int2* sel = sh_sel[wave];
@@ -386,7 +416,7 @@ __global__ __launch_bounds__(GROW_THREADS) __attribute__((amdgpu_waves_per_eu(2,
     if (alive) {
       const uint32_t bc = tcorners[nBest];
       sub0 = level_zero_pos((double)(bc & 0xFFFF), nLevel); sub1 = level_zero_pos((double)(bc >> 16), nLevel);
-      const bool converged = wave_subpix<PS>(tmpl, img_tgt, ip, wl, hl, nLevel, 10, lane, sub0, sub1);
+      const bool converged = wave_subpix<PS>(tmpl, img_tgt, ip, wl, hl, nLevel, 10, lane, sub0, sub1, sh_slab[wave]);
       if (!converged) { alive = false; why = 6; }
     }
     GROW_STAMP(3);   // sub-pixel
@@ -469,6 +499,7 @@ __global__ __launch_bounds__(GROW_THREADS) void k_refind(MapDev m, TrackParams t
   const int K = tp.max_keyframes, P = tp.max_points;
   const int ksrc = st->n_kf;
   __shared__ uint8_t sh_tmpl[GROW_WAVES][128];
+  __shared__ double sh_slab[GROW_WAVES][3 * (PS - 2) * (PS - 2)];
   uint8_t* tmpl = sh_tmpl[wave];
   const Pose Tk = m.kf_pose[(size_t)s * K + ksrc];
   const int npts = st->n_points;
@@ -588,7 +619,7 @@ __global__ __launch_bounds__(GROW_THREADS) void k_refind(MapDev m, TrackParams t
     REFIND_STAMP(12);  // corner search + ZMSSD
     if (!(nBest < tp.max_ssd)) continue;                             // :1010
     double sub0 = level_zero_pos((double)bestx, level), sub1 = level_zero_pos((double)besty, level);
-    if (level > 0) wave_subpix<PS>(tmpl, img, ip, wl, hl, level, 8, lane, sub0, sub1);   // :1020-1024, convergence not looked at
+    if (level > 0) wave_subpix<PS>(tmpl, img, ip, wl, hl, level, 8, lane, sub0, sub1, sh_slab[wave]);   // :1020-1024, convergence not looked at
     __builtin_amdgcn_wave_barrier();
     REFIND_STAMP(13);  // sub-pixel
     if (lane == 0) {                                                 // :1016-1034

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(SBI_THREADS) void k_sbi(SbiArgs a) {
       Se2 U;
       U.t[0] = -upd[0]; U.t[1] = -upd[1];
       const double ang = -upd[2];
-      U.R[0] = U.R[3] = cos(ang); U.R[2] = sin(ang); U.R[1] = -U.R[2];   // mySO2::exp, jni/RT.h:459-465
+      U.R[0] = U.R[3] = vlm::vcos(ang); U.R[2] = vlm::vsin(ang); U.R[1] = -U.R[2];   // mySO2::exp, jni/RT.h:459-465
       CtoC = se2_mul(CtoC, U);
       sh_mean_off -= upd[3];
       final_score = v[14];

@@ -47,6 +47,7 @@ extern "C" int vslam_default_params(vslam_params* p, int width, int height, int 
   p->device = 0;
   p->ba_delay_frames = 0;
   p->grow_map = 0;
+  p->ba_batch_frames = 1;
   return VSLAM_OK;
 }
 
@@ -65,8 +66,10 @@ extern "C" int vslam_create(const vslam_params* p, vslam_system** out) {
   if (!p || !out) { vslam_set_error("create: null argument"); return VSLAM_E_INVALID; }
   if (p->width < 48 || p->height < 48 || p->width > 4096 || p->height > 4096 || p->n_streams < 1 ||
       (p->patch_size != 8 && p->patch_size != 11) || p->ba_delay_frames < 0 || p->ba_delay_frames >= 20 ||
-      (p->ba_delay_frames > 0 && p->ba_delay_frames >= p->min_frames_between_kf)) {
-    vslam_set_error("create: unsupported size %dx%d streams %d patch %d", p->width, p->height, p->n_streams, p->patch_size);
+      (p->ba_delay_frames > 0 && p->ba_delay_frames >= p->min_frames_between_kf) || p->ba_batch_frames < 0 ||
+      (p->ba_batch_frames > 1 && p->ba_batch_frames > p->ba_delay_frames)) {
+    vslam_set_error("create: unsupported parameters: size %dx%d (48..4096), streams %d (>= 1), patch %d (8 or 11), ba_delay_frames %d (0..19 and below min_frames_between_kf %d), ba_batch_frames %d (0..ba_delay_frames)",
+                    p->width, p->height, p->n_streams, p->patch_size, p->ba_delay_frames, p->min_frames_between_kf, p->ba_batch_frames);
     return VSLAM_E_INVALID;
   }
   int ndev = 0;
@@ -125,7 +128,14 @@ extern "C" int vslam_create(const vslam_params* p, vslam_system** out) {
   sys->have_candidates = false;
   sys->have_sbi = false;
   if (p->ba_delay_frames > 0) {
-    if (hipStreamCreateWithFlags(&sys->ba_stream, hipStreamNonBlocking) != hipSuccess) { vslam_set_error("create: hipStreamCreate failed"); vslam_destroy(sys); return VSLAM_E_HIP; }
+    const int nb = p->ba_delay_frames < 8 ? p->ba_delay_frames : 8;
+    for (int i = 0; i < nb; i++) {
+      hipStream_t st = nullptr;
+      if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { vslam_set_error("create: hipStreamCreate failed"); vslam_destroy(sys); return VSLAM_E_HIP; }
+      sys->ba_streams.push_back(st);
+    }
+    sys->ba_stream = sys->ba_streams[0];
+    sys->frame_batch.assign((size_t)p->ba_delay_frames + 2, -1L);
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->device) == hipSuccess && ncu > 0) sys->n_cu = ncu;
     for (int i = 0; i < p->ba_delay_frames + 2; i++) {
@@ -154,11 +164,11 @@ extern "C" int vslam_create(const vslam_params* p, vslam_system** out) {
 extern "C" int vslam_destroy(vslam_system* sys) {
   if (!sys) return VSLAM_OK;
   if (sys->fe_stream) (void)hipStreamSynchronize(sys->fe_stream);
-  if (sys->ba_stream) (void)hipStreamSynchronize(sys->ba_stream);
+  for (hipStream_t st : sys->ba_streams) (void)hipStreamSynchronize(st);
   if (sys->stream) (void)hipStreamSynchronize(sys->stream);
   for (hipEvent_t e : sys->ev_asm) (void)hipEventDestroy(e);
   for (hipEvent_t e : sys->ev_ba) (void)hipEventDestroy(e);
-  if (sys->ba_stream) (void)hipStreamDestroy(sys->ba_stream);
+  for (hipStream_t st : sys->ba_streams) (void)hipStreamDestroy(st);
   for (void* p : sys->allocs) (void)hipFree(p);
   for (hipEvent_t e : sys->prof_ev) (void)hipEventDestroy(e);
   for (int b = 0; b < 2; b++) { if (sys->ev_fe_done[b]) (void)hipEventDestroy(sys->ev_fe_done[b]); if (sys->ev_track_done[b]) (void)hipEventDestroy(sys->ev_track_done[b]); }
@@ -171,8 +181,7 @@ extern "C" int vslam_destroy(vslam_system* sys) {
 extern "C" int vslam_synchronize(vslam_system* sys) {
   if (!sys) return VSLAM_E_INVALID;
   HIPCHK(hipStreamSynchronize(sys->stream));
-  if (sys->ba_stream) HIPCHK(hipStreamSynchronize(sys->ba_stream));
-  return VSLAM_OK;
+  return ba_sync_streams(sys);
 }
 
 extern "C" int vslam_make_keyframe_lite(vslam_system* sys, const uint8_t* gray, size_t row_stride, size_t stream_stride,
@@ -283,5 +292,48 @@ extern "C" int vslam_read_max_corners(vslam_system* sys, int stream, int level, 
   if (scores && nc > 0)  // scores of ALL corners of the level (same order as vslam_read_corners)
     HIPCHK(hipMemcpyAsync(scores, sys->fr.scores[level] + off, (size_t)(nc < cap ? nc : cap) * 4, hipMemcpyDeviceToHost, sys->stream));
   HIPCHK(hipStreamSynchronize(sys->stream));
+  return VSLAM_OK;
+}
+
+// ---- self-test hook: the transcendentals of vslam_libm.h evaluated on the device ---------------------------------------
+__global__ void k_eval_transcendental(int fn, int n, const double* x, double* y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double v = x[i];
+  double r;
+  switch (fn) {
+    case 0: r = vlm::vsin(v); break;
+    case 1: r = vlm::vcos(v); break;
+    case 2: r = vlm::vtan(v); break;
+    case 3: r = vlm::vatan(v); break;
+    case 4: r = vlm::vasin(v); break;
+    case 5: r = vlm::vacos(v); break;
+    case 6: r = sqrt(v); break;
+    default: r = 1.0 / v; break;
+  }
+  y[i] = r;
+}
+
+extern "C" int vslam_eval_transcendental(int fn, int n, const double* x, double* y, int on_host) {
+  if (fn < 0 || fn > 7 || n < 0 || !x || !y) { vslam_set_error("eval_transcendental: bad argument"); return VSLAM_E_INVALID; }
+  if (on_host) {                                      // the same source compiled for the host (what cam_fill and the oracle evaluate)
+    for (int i = 0; i < n; i++) {
+      const double v = x[i];
+      y[i] = fn == 0 ? vlm::vsin(v) : fn == 1 ? vlm::vcos(v) : fn == 2 ? vlm::vtan(v) : fn == 3 ? vlm::vatan(v) : fn == 4 ? vlm::vasin(v)
+           : fn == 5 ? vlm::vacos(v) : fn == 6 ? sqrt(v) : 1.0 / v;
+    }
+    return VSLAM_OK;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { vslam_set_error("eval_transcendental: no HIP device visible"); return VSLAM_E_HIP; }
+  if (n == 0) return VSLAM_OK;
+  double *dx = nullptr, *dy = nullptr;
+  HIPCHK(hipMalloc((void**)&dx, sizeof(double) * n));
+  HIPCHK(hipMalloc((void**)&dy, sizeof(double) * n));
+  HIPCHK(hipMemcpy(dx, x, sizeof(double) * n, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_eval_transcendental, dim3((n + 255) / 256), dim3(256), 0, 0, fn, n, dx, dy);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(y, dy, sizeof(double) * n, hipMemcpyDeviceToHost));
+  (void)hipFree(dx); (void)hipFree(dy);
   return VSLAM_OK;
 }

@@ -531,22 +531,35 @@ DEVFN void subpix_block(const MapDev& m, const TrackParams& tp, const SearchArgs
       const int b = HALF + 1;
       if (!(xb >= b && yb >= b && xb < cols - b && yb < rows - b)) running = false;   // went off edge -> fail
     }
-    double a0 = 0, a1 = 0, a2 = 0;
+    // v3Accum over the interior pixels in the reference's order, row by row (:316-340): the lane of row y adds its Q pixels
+    // to the running sums it takes over from the lane of row y - 1 (a tree over the rows would round differently)
+    double p0[Q], p1[Q], p2[Q];
+#pragma unroll
+    for (int x = 0; x < Q; x++) { p0[x] = 0; p1[x] = 0; p2[x] = 0; }
     if (running && rowok) {
       const double bx = cx - HALF, by = cy - HALF;
       const double dX = bx - floor(bx), dY = by - floor(by);
       const float fTL = (float)((1.0 - dX) * (1.0 - dY)), fTR = (float)((dX) * (1.0 - dY));
       const float fBL = (float)((1.0 - dX) * (dY)), fBR = (float)((dX) * (dY));
       const uint8_t* r0 = img + (size_t)((int)by + sub) * ip + (int)bx + 1;
-      const PRow<PS> p0 = load_row<PS>(r0), p1 = load_row<PS>(r0 + ip);
+      const PRow<PS> q0 = load_row<PS>(r0), q1 = load_row<PS>(r0 + ip);
 #pragma unroll
       for (int x = 1; x <= Q; x++) {
-        const float fPixel = fTL * row_byte(p0, x - 1) + fTR * row_byte(p0, x) + fBL * row_byte(p1, x - 1) + fBR * row_byte(p1, x);
+        const float fPixel = fTL * row_byte(q0, x - 1) + fTR * row_byte(q0, x) + fBL * row_byte(q1, x - 1) + fBR * row_byte(q1, x);
         const double dDiff = (fPixel - (float)row_byte(trow, x)) + meanDiff;
-        a0 += dDiff * gx[x - 1]; a1 += dDiff * gy[x - 1]; a2 += dDiff;
+        p0[x - 1] = dDiff * gx[x - 1]; p1[x - 1] = dDiff * gy[x - 1]; p2[x - 1] = dDiff;
       }
     }
-    a0 = grp_sum_d<G>(a0); a1 = grp_sum_d<G>(a1); a2 = grp_sum_d<G>(a2);
+    double a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll 1
+    for (int y = 1; y <= Q; y++) {
+      if (sub == y) {
+#pragma unroll
+        for (int x = 0; x < Q; x++) { a0 += p0[x]; a1 += p1[x]; a2 += p2[x]; }
+      }
+      const int src = grp * G + y;
+      a0 = __shfl(a0, src); a1 = __shfl(a1, src); a2 = __shfl(a2, src);
+    }
     if (running) {
       const double u0 = Hinv[0] * a0 + Hinv[1] * a1 + Hinv[2] * a2;
       const double u1 = Hinv[3] * a0 + Hinv[4] * a1 + Hinv[5] * a2;
@@ -620,12 +633,20 @@ DEVFN void item_store(const PoseItem& it, const PoseWs& w, int e, bool all) {   
 }
 
 // CalcPoseUpdate, jni/Tracker.cc:683-774 (Tukey).  All threads of the workgroup call it; result in up[6] (LDS).
-DEVFN void calc_pose_update(const PoseWs& ws, MapPointDev* pts, int n, int nvalid, const TrackParams& tp,
-                            double dOverrideSigma, bool bMarkOutliers, double* sortbuf, double* red /* [waves][28] */,
-                            double* up /* [6] */, int* icnt, int* hist /* [768] */, unsigned long long* sel /* [1] */) {
+// The working set holds the nf FOUND entries of the iteration set in iteration-set order (k_pose compacts them once).
+//
+// The weighted normal equations are accumulated in the reference's ORDER: wls.add_mJ row 0, row 1 of every measurement in
+// turn (:736-768, jni/myWLS.h:39-50), every one of the 27 sums (21 of the upper triangle of C, 6 of v) a chain of
+// 2 nf dependent additions that starts from add_prior's value (:734).  fp addition does not associate, and PTAM's
+// templates are trunc(bilinear): a pose that differs in the last bit flips template pixels on flat image regions, so a
+// tree reduction would not do.  The products are formed in parallel -- four threads per measurement, 64 measurements at
+// a time, into LDS (the median's sort buffer is free by then) -- and lane q of wavefront 0 walks sum q through the chunk.
+#define POSE_CHUNK 64
+DEVFN void calc_pose_update(const PoseWs& ws, MapPointDev* pts, int nf, const TrackParams& tp,
+                            double dOverrideSigma, bool bMarkOutliers, double* sortbuf, double* red /* [28] */,
+                            double* up /* [6] */, int* hist /* [768] */, unsigned long long* sel /* [1] */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // nvalid = number of found entries: fixed for the whole launch, counted once by k_pose; residuals are in sortbuf
-  if (nvalid == 0) {                                                // :712-716
+  if (nf == 0) {                                                    // :712-716
     if (threadIdx.x < 6) up[threadIdx.x] = 0.0;
     __syncthreads();
     return;
@@ -634,76 +655,77 @@ DEVFN void calc_pose_update(const PoseWs& ws, MapPointDev* pts, int n, int nvali
   double sigma2;
   if (dOverrideSigma > 0) sigma2 = dOverrideSigma;                  // :720-721
   else {                                                            // Tukey::FindSigmaSquared, jni/MEstimator.h:67-77
-    const double med = block_radix_select(sortbuf, n, nvalid / 2, hist, sel);   // same order statistic as sort + [n/2]
-    sigma2 = tukey_sigma_squared(med, (unsigned long)nvalid);
+    const double med = block_radix_select(sortbuf, nf, nf / 2, hist, sel);   // same order statistic as sort + [n/2]
+    sigma2 = tukey_sigma_squared(med, (unsigned long)nf);
   }
   POSE_STAMP(3);
   const bool qint = (tp.quirks & VSLAM_Q_POSE_INT_RESIDUAL) != 0;
-  double acc[27];
+  double* prod = sortbuf;                                           // [POSE_CHUNK][2 rows][27]
+  const int le = threadIdx.x >> 2, part = threadIdx.x & 3, row = part >> 1, half = part & 1;
+  // sum q of the chain: upper triangle of C row by row (0..20), then v (21..26); the diagonal starts at the prior
+  double acc = 0.0;
+  if (lane == 0 || lane == 6 || lane == 11 || lane == 15 || lane == 18 || lane == 20) acc = 0.0 + tp.wls_prior;   // add_prior, :734
+  PoseItem nx;
+  item_load(nx, ws, le < nf ? le : nf - 1);
+  for (int c0 = 0; c0 < nf; c0 += POSE_CHUNK) {
+    const PoseItem t = nx;
+    const int e = c0 + le;
+    { const int en = e + POSE_CHUNK; item_load(nx, ws, en < nf ? en : nf - 1); }   // the next chunk's operands travel during this chunk's chain
+    __syncthreads();                                                // the chain of the previous chunk has left `prod` (first trip: the median has left sortbuf)
+    if (e < nf) {
+      const double err[2] = {(t.vfound[0] - t.image[0]) * t.sqrt_inv_noise, (t.vfound[1] - t.image[1]) * t.sqrt_inv_noise};
+      const double es = err[0] * err[0] + err[1] * err[1];
+      const double w = tukey_weight(es, sigma2);
+      if (bMarkOutliers && part == 0) { if (w == 0.0) pts[t.idx].n_out++; else pts[t.idx].n_in++; }   // :749-756
+      double pr[27];
+      if (w == 0.0) {
 #pragma unroll
-  for (int i = 0; i < 27; i++) acc[i] = 0.0;
-  for (int e0 = threadIdx.x; e0 < n; e0 += POSE_ILP * POSE_THREADS) {
-    PoseItem tt[POSE_ILP];
+        for (int q = 0; q < 27; q++) pr[q] = 0.0;                   // the reference skips the measurement: x + 0 = x
+      } else {
+        double jac[12];
+        td_calc_jacobian(t, jac);                                    // CalcJacobian, jni/TrackerData.h:107-122
+        const double mm = qint ? (double)(int)err[row] : err[row];  // wls.add_mJ(v2(row), J.row(row), w), :766-767
+        double J[6];
 #pragma unroll
-    for (int u = 0; u < POSE_ILP; u++) {
-      const int e = e0 + u * POSE_THREADS;
-      item_load(tt[u], ws, e < n ? e : n - 1);
-      if (e >= n) tt[u].flags = 0;
-    }
+        for (int k = 0; k < 6; k++) J[k] = t.sqrt_inv_noise * (row ? jac[6 + k] : jac[k]);
+        int q = 0;
 #pragma unroll
-    for (int u = 0; u < POSE_ILP; u++) {
-    const PoseItem& t = tt[u];
-    if (!(t.flags & TDF_FOUND)) continue;
-    const double err[2] = {(t.vfound[0] - t.image[0]) * t.sqrt_inv_noise, (t.vfound[1] - t.image[1]) * t.sqrt_inv_noise};
-    const double es = err[0] * err[0] + err[1] * err[1];
-    const double w = tukey_weight(es, sigma2);
-    if (w == 0.0) { if (bMarkOutliers) pts[t.idx].n_out++; continue; }   // :749-756
-    else if (bMarkOutliers) pts[t.idx].n_in++;
-    double jac[12];
-    td_calc_jacobian(t, jac);                                        // CalcJacobian, jni/TrackerData.h:107-122
+        for (int r = 0; r < 6; r++) {
+          const double Jw = w * J[r];
+          pr[21 + r] = mm * Jw;
 #pragma unroll
-    for (int row = 0; row < 2; row++) {                              // wls.add_mJ x2 (:766-767), jni/myWLS.h:39-50
-      const double mm = qint ? (double)(int)err[row] : err[row];
-      double J[6];
-#pragma unroll
-      for (int k = 0; k < 6; k++) J[k] = t.sqrt_inv_noise * jac[row * 6 + k];
-      int q = 0;
-#pragma unroll
-      for (int r = 0; r < 6; r++) {
-        const double Jw = w * J[r];
-        acc[21 + r] += mm * Jw;
-#pragma unroll
-        for (int c = r; c < 6; c++) acc[q++] += Jw * J[c];
+          for (int c = r; c < 6; c++) pr[q++] = Jw * J[c];
+        }
       }
+      double* dst = prod + (le * 2 + row) * 27;
+#pragma unroll
+      for (int q = 0; q < 27; q++) if ((q < 14) == (half == 0)) dst[q] = pr[q];
     }
+    __syncthreads();
+    if (wave == 0 && lane < 27) {
+      const int cnt2 = 2 * (nf - c0 < POSE_CHUNK ? nf - c0 : POSE_CHUNK);      // rows of this chunk
+      const double* pp = prod + lane;
+      int k = 0;
+      for (; k + 8 <= cnt2; k += 8) {                               // the LDS reads of 8 rows are in flight ahead of the dependent additions
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = pp[(k + u) * 27];
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += v[u];
+      }
+      for (; k < cnt2; k++) acc += pp[k * 27];
     }
   }
   POSE_STAMP(4);
-  {
-    double a32[32];
-#pragma unroll
-    for (int i = 0; i < 32; i++) a32[i] = i < 27 ? acc[i] : 0.0;
-    const double tot = wave_multi_sum<32>(a32);
-    const int vi = wave_multi_index<32>(lane);
-    if (!(lane & 1) && vi < 27) red[wave * 28 + vi] = tot;
-  }
+  if (wave == 0 && lane < 27) red[lane] = acc;
   __syncthreads();
   POSE_STAMP(5);
   if (threadIdx.x == 0) {
     double C[36], v[6];
     int q = 0;
     for (int r = 0; r < 6; r++)
-      for (int c = r; c < 6; c++) {
-        double x = 0.0;
-        for (int w = 0; w < POSE_WAVES; w++) x += red[w * 28 + q];          // fixed order: deterministic
-        C[r * 6 + c] = x; C[c * 6 + r] = x; q++;
-      }
-    for (int r = 0; r < 6; r++) {
-      C[r * 6 + r] += tp.wls_prior;                                        // add_prior(100), :734
-      double x = 0.0;
-      for (int w = 0; w < POSE_WAVES; w++) x += red[w * 28 + 21 + r];
-      v[r] = x;
-    }
+      for (int c = r; c < 6; c++) { const double x = red[q++]; C[r * 6 + c] = x; C[c * 6 + r] = x; }   // myWLS::compute mirrors the triangle, :54-58
+    for (int r = 0; r < 6; r++) v[r] = red[21 + r];
     if (!lu_solve6(C, v)) for (int r = 0; r < 6; r++) v[r] = 0.0;
     for (int r = 0; r < 6; r++) up[r] = v[r];
   }
@@ -731,9 +753,9 @@ __global__ __launch_bounds__(POSE_THREADS) __attribute__((amdgpu_waves_per_eu(VS
   MapPointDev* pts = m.pts + (size_t)s * P;
   const int* ilist = m.iter_list + (size_t)s * P;
   __shared__ double sortbuf[SORT_CAP];
-  __shared__ double red[POSE_WAVES * 28 + 2];
+  __shared__ double red[28];
   __shared__ double up[6], last_up[6];
-  __shared__ int icnt[POSE_WAVES];
+  __shared__ int gcnt[4 * POSE_WAVES];
   __shared__ int hist[768];
   __shared__ unsigned long long sel[1];
   __shared__ Pose pose;
@@ -749,49 +771,57 @@ __global__ __launch_bounds__(POSE_THREADS) __attribute__((amdgpu_waves_per_eu(VS
   if (blockIdx.x == 0 && threadIdx.x == 0) g_pose_prof[15] = clock64();
 #endif
   const PoseWs ws = {m.pose_ws + (size_t)s * POSE_WS_COMPS * P, m.pose_wsi + (size_t)s * 2 * P, P};
-  int nfound_thread = 0;
-  // gather, POSE_GB entries per thread at a time: the entry indices, then every operand of the batch are loaded before
-  // anything is stored, so the dependent pair of round trips (list -> tracker data) is paid once per batch, not per entry
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // Gather: the FOUND entries of the iteration set, in iteration-set order, into the working set (every loop of the pose
+  // iterations skips the others: TrackerData::bFound is fixed for the stage).  Ordered compaction by ballots, four blocks
+  // of POSE_THREADS entries per barrier pair; the entry indices, the flags, then every operand of the batch are loaded
+  // before anything is stored, so the dependent round trips (list -> flags -> tracker data) are paid once per batch.
   constexpr int POSE_GB = 4;
-  for (int e0 = threadIdx.x; e0 < n; e0 += POSE_GB * POSE_THREADS) {
-    int idx[POSE_GB], fl[POSE_GB]; double v[POSE_GB][12];
+  int nf = 0;
+  for (int e0 = 0; e0 < n; e0 += POSE_GB * POSE_THREADS) {
+    int idx[POSE_GB], fl[POSE_GB]; bool fnd[POSE_GB]; unsigned long long bm[POSE_GB]; double v[POSE_GB][12];
 #pragma unroll
-    for (int u = 0; u < POSE_GB; u++) { const int e = e0 + u * POSE_THREADS; idx[u] = ilist[e < n ? e : n - 1]; }
+    for (int u = 0; u < POSE_GB; u++) { const int e = e0 + u * POSE_THREADS + threadIdx.x; idx[u] = ilist[e < n ? e : n - 1]; }
+#pragma unroll
+    for (int u = 0; u < POSE_GB; u++) {
+      const int e = e0 + u * POSE_THREADS + threadIdx.x;
+      fl[u] = m.pt_flags[(size_t)s * P + idx[u]];
+      fnd[u] = e < n && (fl[u] & TDF_FOUND);
+    }
 #pragma unroll
     for (int u = 0; u < POSE_GB; u++) {
       const TrackData& t = td[idx[u]];
-      fl[u] = m.pt_flags[(size_t)s * P + idx[u]];
       for (int i = 0; i < 3; i++) v[u][i] = t.cam[i];
       for (int i = 0; i < 2; i++) { v[u][3 + i] = t.image[i]; v[u][9 + i] = t.vfound[i]; }
       for (int i = 0; i < 4; i++) v[u][5 + i] = t.derivs[i];
       v[u][11] = t.sqrt_inv_noise;
     }
 #pragma unroll
-    for (int u = 0; u < POSE_GB; u++) {
-      const int e = e0 + u * POSE_THREADS;
-      if (e >= n) continue;
-      ws.i[e] = fl[u]; ws.i[P + e] = idx[u];
+    for (int u = 0; u < POSE_GB; u++) { bm[u] = __ballot(fnd[u]); if (lane == 0) gcnt[u * POSE_WAVES + wave] = __popcll(bm[u]); }
+    __syncthreads();
 #pragma unroll
-      for (int c = 0; c < 12; c++) ws.d[c * P + e] = v[u][c];
-      if (fl[u] & TDF_FOUND) nfound_thread++;
+    for (int u = 0; u < POSE_GB; u++) {
+      int off = nf;
+      for (int w = 0; w < POSE_WAVES; w++) { const int c = gcnt[u * POSE_WAVES + w]; if (w < wave) off += c; nf += c; }
+      if (!fnd[u]) continue;
+      const int f = off + __popcll(bm[u] & ((1ull << lane) - 1ull));
+      ws.i[f] = fl[u]; ws.i[P + f] = idx[u];
+#pragma unroll
+      for (int c = 0; c < 12; c++) ws.d[c * P + f] = v[u][c];
     }
+    __syncthreads();
   }
-  nfound_thread = wave_sum_i(nfound_thread);
-  if ((threadIdx.x & 63) == 0) icnt[threadIdx.x >> 6] = nfound_thread;
-  __syncthreads();
-  int nvalid_total = 0;
-  for (int w = 0; w < POSE_WAVES; w++) nvalid_total += icnt[w];
   POSE_STAMP(0);
   for (int iter = 0; iter < 10; iter++) {                            // coarse :466-488, fine :543-577
     const bool nonlinear = stage == 0 || iter == 0 || iter == 4 || iter == 9;
     // POSE_ILP entries per thread in flight: all their loads are issued (index clamped, no branch in between) before any
     // of them is advanced -- the loop is latency-bound at one workgroup of four waves per stream
-    for (int e0 = threadIdx.x; e0 < n; e0 += POSE_ILP * POSE_THREADS) {
+    for (int e0 = threadIdx.x; e0 < nf; e0 += POSE_ILP * POSE_THREADS) {
       PoseItem t[POSE_ILP]; double pos[POSE_ILP][3];
 #pragma unroll
       for (int u = 0; u < POSE_ILP; u++) {
         const int e = e0 + u * POSE_THREADS;
-        item_load(t[u], ws, e < n ? e : n - 1);
+        item_load(t[u], ws, e < nf ? e : nf - 1);
       }
       if (nonlinear && iter != 0) {
 #pragma unroll
@@ -802,30 +832,27 @@ __global__ __launch_bounds__(POSE_THREADS) __attribute__((amdgpu_waves_per_eu(VS
 #pragma unroll
       for (int u = 0; u < POSE_ILP; u++) {
         const int e = e0 + u * POSE_THREADS;
-        if (e >= n) continue;
-        double e2 = __builtin_huge_val();
-        if (t[u].flags & TDF_FOUND) {
-          if (iter != 0) {
-            if (nonlinear) td_project_and_derivs(t[u], t[u].flags, pos[u], pose, tp.cam);
-            else {                                                   // LinearUpdate, jni/TrackerData.h:125-131
-              double jac[12], a = 0, b = 0;
-              td_calc_jacobian(t[u], jac);                           // m26Jacobian of the last non-linear iteration
+        if (e >= nf) continue;
+        if (iter != 0) {
+          if (nonlinear) td_project_and_derivs(t[u], t[u].flags, pos[u], pose, tp.cam);
+          else {                                                   // LinearUpdate, jni/TrackerData.h:125-131
+            double jac[12], a = 0, b = 0;
+            td_calc_jacobian(t[u], jac);                           // m26Jacobian of the last non-linear iteration
 #pragma unroll
-              for (int k = 0; k < 6; k++) { a += jac[k] * last_up[k]; b += jac[6 + k] * last_up[k]; }
-              t[u].image[0] += a; t[u].image[1] += b;
-            }
-            item_store(t[u], ws, e, nonlinear);
+            for (int k = 0; k < 6; k++) { a += jac[k] * last_up[k]; b += jac[6 + k] * last_up[k]; }
+            t[u].image[0] += a; t[u].image[1] += b;
           }
-          const double r0 = (t[u].vfound[0] - t[u].image[0]) * t[u].sqrt_inv_noise;   // v2Error_CovScaled, :707
-          const double r1 = (t[u].vfound[1] - t[u].image[1]) * t[u].sqrt_inv_noise;
-          e2 = r0 * r0 + r1 * r1;
+          item_store(t[u], ws, e, nonlinear);
         }
-        sortbuf[e] = e2;
+        const double r0 = (t[u].vfound[0] - t[u].image[0]) * t[u].sqrt_inv_noise;   // v2Error_CovScaled, :707
+        const double r1 = (t[u].vfound[1] - t[u].image[1]) * t[u].sqrt_inv_noise;
+        sortbuf[e] = r0 * r0 + r1 * r1;
       }
     }
+    __syncthreads();
     POSE_STAMP(1);
     const double override_sigma = iter > 5 ? (stage == 0 ? 1.0 : 16.0) : 0.0;
-    calc_pose_update(ws, pts, n, nvalid_total, tp, override_sigma, stage == 1 && iter == 9, sortbuf, red, up, icnt, hist, sel);
+    calc_pose_update(ws, pts, nf, tp, override_sigma, stage == 1 && iter == 9, sortbuf, red, up, hist, sel);
     if (threadIdx.x == 0) pose = pose_mul(se3_exp(up), pose);        // :487 / :573
     if (threadIdx.x < 6) last_up[threadIdx.x] = up[threadIdx.x];
     __syncthreads();
@@ -833,18 +860,17 @@ __global__ __launch_bounds__(POSE_THREADS) __attribute__((amdgpu_waves_per_eu(VS
   }
   POSE_STAMP(8);
   // scatter what the iterations changed, batched like the gather; the fine stage exports the measurements of the found
-  // patches (:594-607) and sums the scene depth (:610-625) from the same registers
+  // patches (:594-607) and leaves their depths in LDS for the scene-depth sums (:610-625)
   MeasDev* cm = m.cur_meas + (size_t)s * P;
   if (stage != 0) {
     for (int i = threadIdx.x; i < st->n_points; i += POSE_THREADS) cm[i].valid = 0;
     __syncthreads();
   }
-  double dSum = 0, dSumSq = 0; int nNum = 0;
-  for (int e0 = threadIdx.x; e0 < n; e0 += POSE_GB * POSE_THREADS) {
+  for (int e0 = threadIdx.x; e0 < nf; e0 += POSE_GB * POSE_THREADS) {
     int idx[POSE_GB], fl[POSE_GB], lv[POSE_GB]; double v[POSE_GB][11];
 #pragma unroll
     for (int u = 0; u < POSE_GB; u++) {
-      const int e = e0 + u * POSE_THREADS, ec = e < n ? e : n - 1;
+      const int e = e0 + u * POSE_THREADS, ec = e < nf ? e : nf - 1;
       idx[u] = ws.i[P + ec]; fl[u] = ws.i[ec];
 #pragma unroll
       for (int c = 0; c < 11; c++) v[u][c] = ws.d[c * P + ec];
@@ -856,19 +882,18 @@ __global__ __launch_bounds__(POSE_THREADS) __attribute__((amdgpu_waves_per_eu(VS
 #pragma unroll
     for (int u = 0; u < POSE_GB; u++) {
       const int e = e0 + u * POSE_THREADS;
-      if (e >= n) continue;
+      if (e >= nf) continue;
       TrackData& t = td[idx[u]];
       m.pt_flags[(size_t)s * P + idx[u]] = fl[u];
       for (int i = 0; i < 3; i++) t.cam[i] = v[u][i];
       for (int i = 0; i < 2; i++) t.image[i] = v[u][3 + i];
       for (int i = 0; i < 4; i++) t.derivs[i] = v[u][5 + i];
-      if (stage != 0 && (fl[u] & TDF_FOUND)) {
+      if (stage != 0) {
         MeasDev mm;
         mm.root[0] = v[u][9]; mm.root[1] = v[u][10];
         mm.valid = 1; mm.level = (signed char)lv[u]; mm.subpix = (fl[u] & TDF_SUBPIX) ? 1 : 0; mm.source = 0 /* SRC_TRACKER */; mm.pad = 0;
         cm[idx[u]] = mm;
-        const double z = v[u][2];
-        dSum += z; dSumSq += z * z; nNum++;
+        sortbuf[e] = v[u][2];
       }
     }
   }
@@ -876,14 +901,26 @@ __global__ __launch_bounds__(POSE_THREADS) __attribute__((amdgpu_waves_per_eu(VS
     if (threadIdx.x == 0) { st->pose_cur = pose; st->did_coarse = 1; }
     return;
   }
-  // ---- scene depth (:610-625) ----
-  dSum = wave_sum_d(dSum); dSumSq = wave_sum_d(dSumSq); nNum = wave_sum_i(nNum);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) { red[wave * 28] = dSum; red[wave * 28 + 1] = dSumSq; icnt[wave] = nNum; }
+  // ---- scene depth (:610-625): dSum += z, dSumSq += z * z over the found points in iteration-set order ----
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    double a = 0.0;
+    const bool sq = threadIdx.x == 1;
+    int k = 0;
+    for (; k + 8 <= nf; k += 8) {
+      double z[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) z[u] = sortbuf[k + u];
+#pragma unroll
+      for (int u = 0; u < 8; u++) a += sq ? z[u] * z[u] : z[u];
+    }
+    for (; k < nf; k++) { const double z = sortbuf[k]; a += sq ? z * z : z; }
+    red[threadIdx.x] = a;
+  }
   __syncthreads();
   if (threadIdx.x != 0) return;
-  dSum = 0; dSumSq = 0; nNum = 0;
-  for (int w = 0; w < POSE_WAVES; w++) { dSum += red[w * 28]; dSumSq += red[w * 28 + 1]; nNum += icnt[w]; }
+  const double dSum = red[0], dSumSq = red[1];
+  const int nNum = nf;
   if (nNum > 20) {
     st->depth_mean = dSum / nNum;
     st->depth_sigma = sqrt((dSumSq / nNum) - (st->depth_mean) * (st->depth_mean));
@@ -974,7 +1011,7 @@ void cam_fill(CamModel& c, const double cam5[5], double width, double height, in
   c.center[0] = c.size[0] * cam5[2] - 0.5; c.center[1] = c.size[1] * cam5[3] - 0.5;
   c.w = cam5[4];
   double one_over_2tan = 0;
-  if (c.w != 0.0) { c.two_tan = 2.0 * tan(c.w / 2.0); one_over_2tan = 1.0 / c.two_tan; c.winv = 1.0 / c.w; c.distortion_enabled = 1.0; }
+  if (c.w != 0.0) { c.two_tan = 2.0 * vlm::vtan(c.w / 2.0); one_over_2tan = 1.0 / c.two_tan; c.winv = 1.0 / c.w; c.distortion_enabled = 1.0; }
   else { c.winv = 0; c.two_tan = 0; c.distortion_enabled = 0; }
   double v2[2];
   if (quirks & VSLAM_Q_CAM_INT_RADIUS) {   // :70-78 int-typed operands (quirk #5)
@@ -987,7 +1024,7 @@ void cam_fill(CamModel& c, const double cam5[5], double width, double height, in
     v2[1] = (cam5[3] > 1.0 - cam5[3] ? cam5[3] : 1.0 - cam5[3]) / cam5[1];
   }
   const double rr = sqrt(v2[0] * v2[0] + v2[1] * v2[1]);
-  c.largest_radius = c.w == 0.0 ? rr : tan(rr * c.w) * one_over_2tan;   // invrtrans, jni/ATANCamera.h:145-150
+  c.largest_radius = c.w == 0.0 ? rr : vlm::vtan(rr * c.w) * one_over_2tan;   // invrtrans, jni/ATANCamera.h:145-150
   c.max_r = 1.5 * c.largest_radius;
 }
 
@@ -1002,6 +1039,7 @@ void trk_fill_params(const vslam_params& p, TrackParams& t) {
   t.ba_max_iterations = p.ba_max_iterations; t.ba_convergence_limit = p.ba_convergence_limit;
   t.ba_min_sigma2 = p.ba_min_tukey_sigma * p.ba_min_tukey_sigma; t.ba_window = p.ba_window; t.ba_min_keyframes = p.ba_min_keyframes;
   t.quirks = p.quirks; t.max_points = p.max_points; t.max_keyframes = p.max_keyframes; t.ba_delay = p.ba_delay_frames;
+  t.ba_batch = p.ba_batch_frames > 1 ? p.ba_batch_frames : 1;
   t.grow_map = p.grow_map;
   {                                                                  // ATANCamera::OnePixelDist, jni/ATANCamera.cc:86-91
     double a[2], b[2];
@@ -1015,11 +1053,7 @@ void trk_fill_params(const vslam_params& p, TrackParams& t) {
 
 }
 
-int trk_track_map(vslam_system* sys) {
-  const int S = sys->S, P = sys->p.max_points;
-  MapDev& m = sys->map;
-  const TrackParams& tp = sys->tp;
-  SearchArgs a;
+static void trk_search_args(vslam_system* sys, SearchArgs& a) {
   for (int l = 0; l < NLEV; l++) {
     a.img[l] = sys->fr.img[l]; a.img_sstride[l] = sys->fr.img_sstride[l]; a.img_pitch[l] = sys->fr.img_pitch[l];
     a.corners[l] = sys->fr.corners[l]; a.rowlut[l] = sys->fr.rowlut[l];
@@ -1027,37 +1061,66 @@ int trk_track_map(vslam_system* sys) {
     a.kf_pitch[l] = sys->geom[l].pitch; a.kf_stride[l] = (size_t)sys->geom[l].pitch * sys->geom[l].h;
   }
   a.ncorners = sys->fr.ncorners;
-  const int maxSearch = tp.max_patches + 2 * tp.coarse_max < P ? tp.max_patches + 2 * tp.coarse_max : P;
-  prof_mark(sys, 3);
-  hipLaunchKernelGGL(k_pvs, dim3((P + TRK_THREADS - 1) / TRK_THREADS, S), dim3(TRK_THREADS), 0, sys->stream, m, tp,
-                     sys->p.use_sbi ? (const double*)sys->fr.sbi_rot : (const double*)nullptr);
-  prof_mark(sys, 4);
-  hipLaunchKernelGGL(k_plan, dim3(S), dim3(TRK_THREADS), 0, sys->stream, m, tp, 0);
-  prof_mark(sys, 5);
-  if (!tp.coarse_disabled) {
-    const int nc = 2 * tp.coarse_max;
-    if (tp.P == 8) {
-      hipLaunchKernelGGL((k_searchN<8, 8>), dim3((nc + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 0);
-      if (tp.coarse_subpix_its > 0) hipLaunchKernelGGL((k_subpixN<8, 8>), dim3(SUBPIX_GRID, S), dim3(64), 0, sys->stream, m, tp, a, 0);
-    } else {
-      hipLaunchKernelGGL((k_searchN<11, 16>), dim3((nc + 3) / 4, S), dim3(64), 0, sys->stream, m, tp, a, 0);
-      if (tp.coarse_subpix_its > 0) hipLaunchKernelGGL((k_subpixN<11, 16>), dim3(SUBPIX_GRID, S), dim3(64), 0, sys->stream, m, tp, a, 0);
+}
+
+// One search stage of TrackMap on the current frame.  stage 0: ApplyMotionModel + the potentially visible set (:369-392),
+// coarse selection (:399-461) and SearchForPoints of the coarse set; stage 1: fine selection (:493-535) and SearchForPoints of
+// the level-3 points (with sub-pixel refinement) and of the rest.
+int trk_search_stage(vslam_system* sys, int stage) {
+  const int S = sys->S, P = sys->p.max_points;
+  MapDev& m = sys->map;
+  const TrackParams& tp = sys->tp;
+  SearchArgs a;
+  trk_search_args(sys, a);
+  if (stage == 0) {
+    prof_mark(sys, 3);
+    hipLaunchKernelGGL(k_pvs, dim3((P + TRK_THREADS - 1) / TRK_THREADS, S), dim3(TRK_THREADS), 0, sys->stream, m, tp,
+                       sys->p.use_sbi ? (const double*)sys->fr.sbi_rot : (const double*)nullptr);
+    prof_mark(sys, 4);
+    hipLaunchKernelGGL(k_plan, dim3(S), dim3(TRK_THREADS), 0, sys->stream, m, tp, 0);
+    prof_mark(sys, 5);
+    if (!tp.coarse_disabled) {
+      const int nc = 2 * tp.coarse_max;
+      if (tp.P == 8) {
+        hipLaunchKernelGGL((k_searchN<8, 8>), dim3((nc + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 0);
+        if (tp.coarse_subpix_its > 0) hipLaunchKernelGGL((k_subpixN<8, 8>), dim3(SUBPIX_GRID, S), dim3(64), 0, sys->stream, m, tp, a, 0);
+      } else {
+        hipLaunchKernelGGL((k_searchN<11, 16>), dim3((nc + 3) / 4, S), dim3(64), 0, sys->stream, m, tp, a, 0);
+        if (tp.coarse_subpix_its > 0) hipLaunchKernelGGL((k_subpixN<11, 16>), dim3(SUBPIX_GRID, S), dim3(64), 0, sys->stream, m, tp, a, 0);
+      }
     }
     prof_mark(sys, 6);
-    hipLaunchKernelGGL(k_pose, dim3(S), dim3(POSE_THREADS), 0, sys->stream, m, tp, 0);
-  } else prof_mark(sys, 6);
-  prof_mark(sys, 7);
-  hipLaunchKernelGGL(k_plan, dim3(S), dim3(TRK_THREADS), 0, sys->stream, m, tp, 1);
-  prof_mark(sys, 8);
-  if (tp.P == 8) {
-    hipLaunchKernelGGL((k_searchN<8, 8>), dim3((maxSearch + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 1);
-    if (tp.fine_subpix_its > 0) hipLaunchKernelGGL((k_subpixN<8, 8>), dim3(SUBPIX_GRID, S), dim3(64), 0, sys->stream, m, tp, a, 1);
   } else {
-    hipLaunchKernelGGL((k_searchN<11, 16>), dim3((maxSearch + 3) / 4, S), dim3(64), 0, sys->stream, m, tp, a, 1);
-    if (tp.fine_subpix_its > 0) hipLaunchKernelGGL((k_subpixN<11, 16>), dim3(SUBPIX_GRID, S), dim3(64), 0, sys->stream, m, tp, a, 1);
+    const int maxSearch = tp.max_patches + 2 * tp.coarse_max < P ? tp.max_patches + 2 * tp.coarse_max : P;
+    prof_mark(sys, 7);
+    hipLaunchKernelGGL(k_plan, dim3(S), dim3(TRK_THREADS), 0, sys->stream, m, tp, 1);
+    prof_mark(sys, 8);
+    if (tp.P == 8) {
+      hipLaunchKernelGGL((k_searchN<8, 8>), dim3((maxSearch + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 1);
+      if (tp.fine_subpix_its > 0) hipLaunchKernelGGL((k_subpixN<8, 8>), dim3(SUBPIX_GRID, S), dim3(64), 0, sys->stream, m, tp, a, 1);
+    } else {
+      hipLaunchKernelGGL((k_searchN<11, 16>), dim3((maxSearch + 3) / 4, S), dim3(64), 0, sys->stream, m, tp, a, 1);
+      if (tp.fine_subpix_its > 0) hipLaunchKernelGGL((k_subpixN<11, 16>), dim3(SUBPIX_GRID, S), dim3(64), 0, sys->stream, m, tp, a, 1);
+    }
+    prof_mark(sys, 9);
   }
-  prof_mark(sys, 9);
-  hipLaunchKernelGGL(k_pose, dim3(S), dim3(POSE_THREADS), 0, sys->stream, m, tp, 1);
   HIPCHK(hipGetLastError());
   return VSLAM_OK;
+}
+
+// The ten Gauss-Newton iterations of a stage (:466-488 / :543-577); stage 1 also ends TrackMap and TrackFrame on device
+// (measurement export, scene depth, UpdateMotionModel, AssessTrackingQuality, the keyframe decision).
+int trk_pose_stage(vslam_system* sys, int stage) {
+  if (stage == 0 && sys->tp.coarse_disabled) return VSLAM_OK;
+  hipLaunchKernelGGL(k_pose, dim3(sys->S), dim3(POSE_THREADS), 0, sys->stream, sys->map, sys->tp, stage);
+  HIPCHK(hipGetLastError());
+  return VSLAM_OK;
+}
+
+int trk_track_map(vslam_system* sys) {
+  int r = trk_search_stage(sys, 0);
+  if (!r) r = trk_pose_stage(sys, 0);
+  if (!r) r = trk_search_stage(sys, 1);
+  if (!r) r = trk_pose_stage(sys, 1);
+  return r;
 }

@@ -111,6 +111,7 @@ struct TrackParams {        // device copy of the tunables the kernels read
   int quirks;
   int max_points, max_keyframes;
   int ba_delay;             // vslam_params.ba_delay_frames
+  int ba_batch;             // vslam_params.ba_batch_frames (>= 1)
   int grow_map;             // vslam_params.grow_map
   double one_pixel_dist;    // ATANCamera::OnePixelDist, jni/ATANCamera.cc:86-91
   int kcap[NLEV];           // capacity of a keyframe's stored corner list per level (grow_map)
@@ -153,13 +154,20 @@ struct vslam_system {
   hipStream_t fe_stream = nullptr;
   hipEvent_t ev_fe_done[2] = {nullptr, nullptr}, ev_track_done[2] = {nullptr, nullptr};
   // asynchronous map-maker (ba_delay_frames > 0): Bundle::Compute runs on ba_stream beside the following frames
-  hipStream_t ba_stream = nullptr;
+  hipStream_t ba_stream = nullptr;   // the map-maker stream of the frame being enqueued (= ba_streams[frame_no % ba_streams.size()])
+  std::vector<hipStream_t> ba_streams;   // a bundle adjustment outlasts a frame: successive keyframe frames' launches overlap on a ring of streams
   double* grow_implane = nullptr;   // [S][kcap_0][2]: the epipolar search's target corners on the image plane (mapgrow.hip)
   int n_cu = 0;             // compute units of the device (asynchronous map-maker: size of the background BA grid)
-  std::vector<hipEvent_t> ev_asm, ev_ba;   // rings of ba_delay + 2 events, indexed by frame number
+  std::vector<hipEvent_t> ev_asm, ev_ba;   // rings of ba_delay + 2 events, indexed by batch number
   long frame_no = 0;
+  // batches of the asynchronous map-maker: the problems assembled in ba_batch consecutive frames share one work list and one launch
+  long ba_batch_id = 0;        // the open batch
+  int ba_batch_fill = 0;       // frames assembled into it so far
+  std::vector<long> frame_batch;   // ring [ba_delay + 2]: the batch a frame's keyframes were assembled into
+  std::vector<char> prof_ba_launched;   // per profiled frame: did it launch k_ba_compute
   std::vector<void*> allocs;   // everything to hipFree
   bool have_frame;
+  bool frame_open = false;  // stage-wise TrackFrame (vslam_patch_search ... vslam_finish_frame) in progress
   bool have_sbi;            // a SmallBlurryImage of a previous frame exists (mpSBILastFrame)
   // KeyFrame::Level::vCandidates of the current frame (jni/KeyFrame.h:62-70), filled by vslam_make_keyframe_rest
   uint32_t* cand[NLEV]; double* cand_score[NLEV]; int* ncand; bool have_candidates;
@@ -200,11 +208,14 @@ int fe_thin_candidates(vslam_system* sys, int keyframe);
 void trk_fill_params(const vslam_params& p, TrackParams& t);
 int trk_alloc(vslam_system* sys);
 int trk_track_map(vslam_system* sys);
+int trk_search_stage(vslam_system* sys, int stage);
+int trk_pose_stage(vslam_system* sys, int stage);
 // ba.hip
 int ba_alloc(vslam_system* sys);
 int ba_add_keyframe_and_adjust(vslam_system* sys);
 int ba_run(vslam_system* sys, int mode);
-int ba_frame_start(vslam_system* sys);   // asynchronous map-maker: apply the results that are due at this frame
+int ba_frame_start(vslam_system* sys);
+int ba_sync_streams(vslam_system* sys);   // launches an open batch first, then   // host wait for every map-maker stream   // asynchronous map-maker: apply the results that are due at this frame
 // map.hip
 int map_init_states(vslam_system* sys);
 
