@@ -86,6 +86,11 @@ typedef struct vslam_params {
                                       frames is launched together (1 .. ba_delay_frames; 0 = 1).  Independent sequences ask for keyframes in
                                       different frames; one launch per frame would carry only a few problems.  Does not change any result: a
                                       keyframe's adjustment is still applied ba_delay_frames frames after the keyframe */
+  int idle_iterations;             /* MapMaker::run's idle jobs (jni/MapMaker.cc:94-117) after every frame, this many passes: BundleAdjustRecent until it
+                                      has converged, ReFindNewlyMade (:1061-1081), BundleAdjustAll until it has converged (:776-798), every 20th pass
+                                      ReFindFromFailureQueue (:1083-1096; the reference draws rand() % 20), HandleBadPoints.  0 (default): one
+                                      BundleAdjustRecent per keyframe only.  -1: none after a frame, but the failure queue and never-retry sets are kept so that
+                                      vslam_mapmaker_idle_job can run the jobs on request.  Needs the synchronous map-maker (ba_delay_frames = 0) */
 } vslam_params;
 
 const char* vslam_last_error(void);
@@ -250,6 +255,14 @@ int vslam_get_templates(vslam_system* sys, int stream, int first, int n, uint8_t
 /* Size of the last bundle-adjustment problem MapMaker::BundleAdjust (jni/MapMaker.cc:854-960) assembled for the stream:
  * out[0..5] = cameras, adjustable cameras, points, measurements added, LM trials (mnCounter), accepted steps. */
 int vslam_get_bundle_stats(vslam_system* sys, int stream, int out[6]);
+/* Counters of the map-maker's idle jobs (vslam_params.idle_iterations, MapMaker::run jni/MapMaker.cc:94-117): out[0..5] = measurements
+ * added by ReFindNewlyMade, by ReFindFromFailureQueue, BundleAdjustAll calls, idle BundleAdjustRecent calls, failure-queue length,
+ * new-queue length. */
+int vslam_get_idle_stats(vslam_system* sys, int stream, int out[6]);
+/* One idle job of MapMaker::run (jni/MapMaker.cc:94-117) for every stream, between frames: 0 BundleAdjustRecent if not converged
+ * (:97-98), 1 ReFindNewlyMade (:102-103), 2 BundleAdjustAll if not converged (:107-108), 3 every 20th call
+ * ReFindFromFailureQueue (:112-113); each followed by HandleBadPoints (:117).  Needs idle_iterations != 0 at creation. */
+int vslam_mapmaker_idle_job(vslam_system* sys, int job);
 
 /* ---- measurement: HIP-event time per stage of vslam_track_frame, on the system's own stream ---- */
 #define VSLAM_N_STAGES 14

@@ -24,6 +24,7 @@ void* orc_sys_create(const orc_params* q) {
   p.ba_delay_frames = q->ba_delay_frames;
   p.use_sbi = q->use_sbi;
   p.grow_map = q->grow_map;
+  p.idle_iterations = q->idle_iterations;
   return new System(p);
 }
 void orc_sys_destroy(void* s) { delete (System*)s; }
@@ -50,6 +51,12 @@ void orc_sys_frame_begin(void* s, const uint8_t* gray, int stride) { ((System*)s
 void orc_sys_search_stage(void* s, int stage) { System* S = (System*)s; if (S->tracked_this_frame) S->SearchStage(stage); }
 void orc_sys_pose_stage(void* s, int stage) { System* S = (System*)s; if (S->tracked_this_frame) S->PoseStage(stage); }
 void orc_sys_frame_end(void* s) { ((System*)s)->FrameEnd(); }
+void orc_sys_idle_iteration(void* s) { ((System*)s)->IdleIteration(); }
+void orc_sys_idle_job(void* s, int job) { ((System*)s)->IdleJob(job); }
+void orc_sys_get_idle_stats(void* sv, int out[6]) {
+  System* s = (System*)sv;
+  out[0] = s->n_refound_new; out[1] = s->n_refound_failed; out[2] = s->n_ba_all; out[3] = s->n_ba_recent_idle; out[4] = (int)s->failure_queue.size(); out[5] = (int)s->new_queue.size();
+}
 
 void orc_sys_get_state(void* sv, orc_track_state* o) {
   System* s = (System*)sv;

@@ -165,7 +165,7 @@ class OrcParams(C.Structure):
                 ("min_frames_between_kf", C.c_int), ("max_kf_dist_wiggle_mult", C.c_double), ("wiggle_scale", C.c_double),
                 ("ba_max_iterations", C.c_int), ("ba_convergence_limit", C.c_double), ("ba_min_tukey_sigma", C.c_double),
                 ("ba_window", C.c_int), ("ba_min_keyframes", C.c_int), ("cam", C.c_double * 5), ("quirks", C.c_int),
-                ("ba_delay_frames", C.c_int), ("use_sbi", C.c_int), ("grow_map", C.c_int)]
+                ("ba_delay_frames", C.c_int), ("use_sbi", C.c_int), ("grow_map", C.c_int), ("idle_iterations", C.c_int)]
 
 
 class TrackState(C.Structure):
@@ -187,7 +187,7 @@ def params_from_vslam(vp):
     for f in ("coarse_min", "coarse_max", "coarse_range", "coarse_subpix_its", "coarse_disabled", "coarse_min_vel",
               "fine_subpix_its", "wls_prior", "min_frames_between_kf", "max_kf_dist_wiggle_mult", "wiggle_scale",
               "ba_max_iterations", "ba_convergence_limit", "ba_min_tukey_sigma", "ba_window", "ba_min_keyframes", "quirks",
-              "ba_delay_frames", "use_sbi", "grow_map"):
+              "ba_delay_frames", "use_sbi", "grow_map", "idle_iterations"):
         setattr(p, f, getattr(vp, f))
     for i in range(5):
         p.cam[i] = vp.cam[i]
@@ -206,7 +206,7 @@ class OracleSystem:
         L.orc_sys_create.restype = C.c_void_p
         for f in ("orc_sys_destroy", "orc_sys_add_meas", "orc_sys_set_map_good", "orc_sys_set_pose", "orc_sys_set_velocity",
                   "orc_sys_track_frame", "orc_sys_get_state", "orc_sys_get_keyframe_pose", "orc_sys_frame_begin", "orc_sys_search_stage",
-                  "orc_sys_pose_stage", "orc_sys_frame_end"):
+                  "orc_sys_pose_stage", "orc_sys_frame_end", "orc_sys_idle_iteration", "orc_sys_idle_job", "orc_sys_get_idle_stats"):
             getattr(L, f).restype = None
         self.L = L
         self.p = params
@@ -259,6 +259,17 @@ class OracleSystem:
 
     def frame_end(self):
         self.L.orc_sys_frame_end(self.h)
+
+    def idle_iteration(self):
+        self.L.orc_sys_idle_iteration(self.h)
+
+    def idle_job(self, job):
+        self.L.orc_sys_idle_job(self.h, job)
+
+    def idle_stats(self):
+        o = np.zeros(6, np.int32)
+        self.L.orc_sys_get_idle_stats(self.h, _p(o))
+        return dict(zip(("refound_new", "refound_failed", "ba_all", "ba_recent_idle", "failure_queue", "new_queue"), (int(x) for x in o)))
 
     def state(self):
         s = TrackState()

@@ -234,6 +234,7 @@ bool System::AddPointEpipolar(int ksrc, int ktgt, int nLevel, int nCandidate) {
   m.source = SRC_EPIPOLAR; m.root[0] = f.subpix[0]; m.root[1] = f.subpix[1];
   kTarget.meas[pid] = m;
   pNew->meas_kfs.insert(ksrc); pNew->meas_kfs.insert(ktgt);
+  new_queue.push_back(pid);                                       // mqNewQueue.push(pNew), :689
   return true;
 }
 
@@ -276,6 +277,38 @@ int System::ReFindInSingleKeyFrame(int kidx) {
   int n = 0;
   for (int i = 0; i < (int)pts.size(); i++) if (!pts[i]->bad && ReFind_Common(kidx, i)) n++;
   return n;
+}
+
+// MapMaker::ReFindNewlyMade, jni/MapMaker.cc:1061-1081: every point of the new queue against every keyframe
+void System::ReFindNewlyMade() {
+  for (int pi : new_queue) {
+    if (pts[pi]->bad) continue;
+    for (int k = 0; k < (int)kfs.size(); k++) if (ReFind_Common(k, pi)) n_refound_new++;
+  }
+  new_queue.clear();
+}
+
+// MapMaker::ReFindFromFailureQueue, jni/MapMaker.cc:1083-1096.  The reference sorts the (KeyFrame*, MapPoint*) pairs by address;
+// here by (keyframe index, point index), the build's stand-in for address order.
+void System::ReFindFromFailureQueue() {
+  if (failure_queue.empty()) return;
+  std::sort(failure_queue.begin(), failure_queue.end());
+  for (auto& e : failure_queue) if (ReFind_Common(e.first, e.second)) n_refound_failed++;
+  failure_queue.clear();
+}
+
+// One pass through the idle jobs of MapMaker::run (jni/MapMaker.cc:94-117) with an empty keyframe queue
+void System::IdleIteration() { for (int job = 0; job < 4; job++) IdleJob(job); }
+
+// One of the four jobs, so that a test can compare (and re-synchronise) after each.  HandleBadPoints (:117) runs after every job
+// here instead of once per pass: it only acts on bBad flags, which nothing between the jobs reads differently.
+void System::IdleJob(int job) {
+  if (!map_good) return;
+  if (job == 0 && !ba_converged_recent) { BundleAdjustRecent(); n_ba_recent_idle++; }                         // :97-98
+  if (job == 1 && ba_converged_recent) ReFindNewlyMade();                                                    // :102-103
+  if (job == 2 && ba_converged_recent && !ba_converged_full) { BundleAdjustAll(); n_ba_all++; }                // :107-108
+  if (job == 3 && ba_converged_recent && ba_converged_full) { if (idle_count++ % 20 == 0) ReFindFromFailureQueue(); }   // :112-113, rand() % 20 == 0 made deterministic
+  HandleBadPoints();                                                                                         // :117
 }
 
 int System::AddSomeMapPoints(int nLevel) {

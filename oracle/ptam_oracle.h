@@ -95,6 +95,7 @@ typedef struct orc_params {           /* mirrors the hot-path fields of vslam_pa
   int ba_delay_frames;
   int use_sbi;                        /* gvnUseSBI, jni/Tracker.cc:88 */
   int grow_map;                       /* AddSomeMapPoints on every new keyframe, jni/MapMaker.cc:498-501 */
+  int idle_iterations;                /* iterations of MapMaker::run's idle jobs per frame (jni/MapMaker.cc:94-117) */
 } orc_params;
 
 typedef struct orc_track_state {      /* same fields as vslam_track_state */
@@ -123,6 +124,9 @@ void orc_sys_frame_begin(void* sys, const uint8_t* gray, int stride);
 void orc_sys_search_stage(void* sys, int stage);
 void orc_sys_pose_stage(void* sys, int stage);
 void orc_sys_frame_end(void* sys);
+void orc_sys_idle_job(void* sys, int job);   /* one of them: 0 idle BundleAdjustRecent, 1 ReFindNewlyMade, 2 BundleAdjustAll, 3 ReFindFromFailureQueue */
+void orc_sys_idle_iteration(void* sys);        /* one pass through the idle jobs of MapMaker::run, jni/MapMaker.cc:94-117 */
+void orc_sys_get_idle_stats(void* sys, int out[6]);   /* points re-found by ReFindNewlyMade / ReFindFromFailureQueue, BundleAdjustAll / idle BundleAdjustRecent calls, queue lengths */
 void orc_sys_get_state(void* sys, orc_track_state* out);
 /* per map point: found flag, searched flag, search level, did-subpix, found position (L0), projected position */
 int orc_sys_get_point_tracks(void* sys, int* found, int* searched, int* level, int* subpix, double* vfound, double* image, int cap);

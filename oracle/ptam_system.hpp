@@ -74,6 +74,7 @@ struct Params {
   double cam[5]; int quirks;
   int ba_delay_frames = 0;   // 0: results applied at once; D > 0: applied at the start of the D-th following frame
   int use_sbi = 0;           // gvnUseSBI, jni/Tracker.cc:88 (reference: 1)
+  int idle_iterations = 0;   // iterations of MapMaker::run's idle jobs (jni/MapMaker.cc:94-117) after every frame; 0: one BundleAdjustRecent per keyframe only
   int grow_map = 0;          // bit 0: AddSomeMapPoints (jni/MapMaker.cc:498-501), bit 1: ReFindInSingleKeyFrame (:497); 0: only the tracker's measurements
 };
 
@@ -139,7 +140,7 @@ struct System {
   void TrackFrame(const uint8_t* gray, int stride);
   void TrackMap();
   // TrackFrame in stages (same statements, same order): FrameBegin; SearchStage(0); PoseStage(0); SearchStage(1); PoseStage(1); FrameEnd
-  void FrameBegin(const uint8_t* gray, int stride); void FrameEnd(); void SearchStage(int stage); void PoseStage(int stage);
+  void FrameBegin(const uint8_t* gray, int stride); void FrameEnd(); void TrackerFrameEnd(); void SearchStage(int stage); void PoseStage(int stage);
   bool Tracking() const { return map_good && lost_frames < 3; }
   std::vector<int> tm_pvs[4], tm_next, tm_iter; bool tm_coarse_tried = false; unsigned tm_coarse_found = 0; bool tracked_this_frame = false;
   int SearchForPoints(std::vector<int>& v, int range, int subpix_its);
@@ -154,6 +155,11 @@ struct System {
   void ThinCandidates(KeyFrame& k, int level); int ClosestKeyFrame(int kidx);
   bool AddPointEpipolar(int ksrc, int ktgt, int level, int candidate); int AddSomeMapPoints(int level);
   bool ReFind_Common(int kidx, int pi); int ReFindInSingleKeyFrame(int kidx);
+  // the idle jobs of MapMaker::run (jni/MapMaker.cc:94-117)
+  std::vector<int> new_queue;      // mqNewQueue: points AddPointEpipolar made, waiting for ReFindNewlyMade
+  long idle_count = 0;             // evaluations of the lowest-priority job's condition (stands in for rand() % 20 == 0, :112)
+  int n_refound_new = 0, n_refound_failed = 0, n_ba_all = 0, n_ba_recent_idle = 0;
+  void ReFindNewlyMade(); void ReFindFromFailureQueue(); void IdleIteration(); void IdleJob(int job);
   Finder refinder; int refind_last_point = -1;     // ReFind_Common's static PatchFinder and its mpLastTemplateMapPoint
   int n_points_added = 0, n_refound = 0;
   std::vector<int> grow_log;   // per AddPointEpipolar call: level, packed candidate position, stage at which it gave up (0 = point added)

@@ -158,7 +158,11 @@ void System::FrameBegin(const uint8_t* gray, int stride) {
 }
 
 void System::FrameEnd() {
-  if (!tracked_this_frame) return;           // no map, or lost: AttemptRecovery (relocaliser) is out of scope
+  if (tracked_this_frame) TrackerFrameEnd();
+  for (int i = 0; i < p.idle_iterations; i++) IdleIteration();   // the map-maker's idle jobs, a fixed number of run() iterations per frame
+}
+
+void System::TrackerFrameEnd() {
   UpdateMotionModel();
   AssessTrackingQuality();
   if (quality == 2 && NeedNewKeyFrame() && frame - last_kf_dropped > p.min_frames_between_kf) {   // :128-132

@@ -4,6 +4,11 @@ import sys
 import numpy as np
 import pytest
 
+try:                                   # torch bundles its own HIP runtime: it must initialise before libvslam_hip.so's does,
+    import torch  # noqa: F401         # or a later torch.cuda call in the same process finds no device (bench.py imports it first too)
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

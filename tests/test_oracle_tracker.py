@@ -118,3 +118,29 @@ def test_refind_in_single_keyframe_adds_measurements():
     assert refound > 0
     assert o.state().n_points == o_plain.state().n_points == len(m["points"])
     assert pose_err(o.state().pose, f.pose(45)) < 6e-3
+
+
+def test_idle_jobs_of_the_map_maker():
+    """MapMaker::run's idle jobs (jni/MapMaker.cc:94-117) in the oracle: ReFindNewlyMade consumes the new queue, BundleAdjustAll runs
+    once per new keyframe until it has converged, the outliers of the adjustments wait in the failure queue until the 20th pass
+    re-finds most of them; one pass = the four jobs one by one (the split the device test uses)."""
+    w, h = 320, 240
+    f, m, frames = make_scene(w, h, seed=77, n_frames=32, per_level=(120, 50, 20, 8))
+    kw = dict(patch_size=8, grow_map=3)
+    a = make_oracle(capi.default_params(w, h, 1, idle_iterations=2, **kw), m, f.pose(-1))
+    b = make_oracle(capi.default_params(w, h, 1, idle_iterations=0, **kw), m, f.pose(-1))
+    seen_queue = 0
+    for t in range(32):
+        a.track_frame(frames[t]); b.track_frame(frames[t])
+        for _ in range(2):
+            for job in range(4):
+                b.idle_job(job)
+        sa, sb = a.idle_stats(), b.idle_stats()
+        assert sa == sb, (t, sa, sb)                                   # a pass = its four jobs
+        assert pose_err(a.state().pose, b.state().pose) == 0.0
+        assert sa["new_queue"] == 0                                    # ReFindNewlyMade ran behind every AddKeyFrame
+        seen_queue = max(seen_queue, sa["failure_queue"])
+        assert pose_err(a.state().pose, f.pose(t)) < 5e-3
+    assert sa["ba_all"] == a.state().n_keyframes - len(m["keyframes"])
+    assert seen_queue > 100 and sa["failure_queue"] == 0 and sa["refound_failed"] > seen_queue // 2
+    assert sa["refound_new"] > 0

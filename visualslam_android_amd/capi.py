@@ -32,7 +32,7 @@ class Params(C.Structure):
         ("wiggle_scale", C.c_double), ("ba_max_iterations", C.c_int), ("ba_convergence_limit", C.c_double),
         ("ba_min_tukey_sigma", C.c_double), ("ba_window", C.c_int), ("ba_min_keyframes", C.c_int),
         ("cam", C.c_double * 5), ("quirks", C.c_int), ("device", C.c_int), ("ba_delay_frames", C.c_int),
-        ("grow_map", C.c_int), ("ba_batch_frames", C.c_int),
+        ("grow_map", C.c_int), ("ba_batch_frames", C.c_int), ("idle_iterations", C.c_int),
     ]
 
 
@@ -99,6 +99,8 @@ SYMBOLS = {
     "vslam_get_keyframe_pose": (_i, [_sys, _i, _i, _vp]),
     "vslam_save_map": (_i, [_sys, _i, C.c_char_p]),
     "vslam_get_bundle_stats": (_i, [_sys, _i, _vp]),
+    "vslam_get_idle_stats": (_i, [_sys, _i, _vp]),
+    "vslam_mapmaker_idle_job": (_i, [_sys, _i]),
     "vslam_get_keyframe_measurements": (_i, [_sys, _i, _i, _vp, _vp, _vp, _vp, _i]),
     "vslam_get_template": (_i, [_sys, _i, _i, _vp, _ip, _ip, _ip]),
     "vslam_get_templates": (_i, [_sys, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -430,6 +432,14 @@ class System:
         o = np.zeros(6, np.int32)
         _check(self.lib.vslam_get_bundle_stats(self.h, stream, o.ctypes.data))
         return dict(zip(("cams", "free_cams", "points", "meas", "trials", "accepted"), (int(x) for x in o)))
+
+    def mapmaker_idle_job(self, job):
+        _check(self.lib.vslam_mapmaker_idle_job(self.h, job))
+
+    def idle_stats(self, stream):
+        o = np.zeros(6, np.int32)
+        _check(self.lib.vslam_get_idle_stats(self.h, stream, o.ctypes.data))
+        return dict(zip(("refound_new", "refound_failed", "ba_all", "ba_recent_idle", "failure_queue", "new_queue"), (int(x) for x in o)))
 
     def keyframe_pose(self, stream, kf):
         p = np.zeros(12)

@@ -7,6 +7,7 @@
 //     start of frame t + D (ba_frame_start), the deterministic stand-in for PTAM's map-maker thread.
 #include "vslam_internal.h"
 #include "ba_device.h"
+#define BA_MAX_KF 128        // keyframes per stream = cameras of a bundle-adjustment problem (8-bit camera field of a slot: < 256)
 #include <string.h>
 
 struct BaPool {            // device arrays for N problems
@@ -24,6 +25,7 @@ struct BaPool {            // device arrays for N problems
   // of that frame walks exactly this list: it never looks at a problem a later frame's assemble (running beside it on the
   // main stream) is still writing.
   int* work; int* work_n; int work_slots;
+  int* view_of_kf;               // [N][BA_MAX_KF] keyframe index -> camera id of the problem being assembled, or -1 (k_ba_select -> k_ba_assemble)
 };
 
 __host__ __device__ inline BaView ba_view(const BaPool& b, int n) {
@@ -86,7 +88,7 @@ static int pool_create(BaPool& b, std::vector<void*>& allocs, hipStream_t st, in
   PALLOC(S, n * F * F); PALLOC(E, n * F); PALLOC(cam_up, n * F);
   PALLOC(scratch, n * M); PALLOC(outl, n * M * 2); PALLOC(free_cams, n * C); PALLOC(id_view, n * C); PALLOC(id_point, n * P);
   b.work_slots = work_slots > 0 ? work_slots : 1;
-  PALLOC(work, n * b.work_slots); PALLOC(work_n, (size_t)b.work_slots);
+  PALLOC(work, n * b.work_slots); PALLOC(work_n, (size_t)b.work_slots); PALLOC(view_of_kf, n * BA_MAX_KF);
   return VSLAM_OK;
 }
 
@@ -108,8 +110,8 @@ struct vslam_bundle {
 
 
 extern "C" int vslam_bundle_create(const vslam_params* p, int n_problems, int max_cameras, int max_points, int max_meas, vslam_bundle** out) {
-  if (!p || !out || n_problems < 1 || max_cameras < 1 || max_cameras > 64 || max_points < 1 || max_points > 4096 || max_meas < 1 || max_meas > 65536) {
-    vslam_set_error("bundle_create: bad argument (1..64 cameras, 1..4096 points, 1..65536 measurements per problem)"); return VSLAM_E_INVALID;
+  if (!p || !out || n_problems < 1 || max_cameras < 1 || max_cameras > BA_MAX_KF || max_points < 1 || max_points > 4096 || max_meas < 1 || max_meas > 65536) {
+    vslam_set_error("bundle_create: bad argument (1..128 cameras of which at most 64 adjustable, 1..4096 points, 1..65536 measurements per problem)"); return VSLAM_E_INVALID;
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { vslam_set_error("bundle_create: no HIP device visible (no CPU fallback)"); return VSLAM_E_HIP; }
@@ -304,67 +306,88 @@ DEVFN double kfdist(const Pose& a, const Pose& b) {   // KeyFrameLinearDist :705
 }
 
 // mode 0: after AddKeyFrame (only streams with kf_pending) -> BundleAdjustRecent; 1: BundleAdjustRecent on every
-// stream; 2: BundleAdjustAll on every stream.  Builds the Bundle problem of BundleAdjust (:854-902) in the pool.
+// stream; 2: BundleAdjustAll on every stream.  Two kernels build the Bundle problem of BundleAdjust (:854-902) in the pool:
+// k_ba_select (one lane per stream, on the tracker's stream) takes the decisions that the next frame's tracking must see --
+// the keyframe joins the map (n_kf), which cameras are adjusted (:803-820), the countdown of the asynchronous map-maker --
+// and k_ba_assemble does the long part (point set, fixed set, measurement list), which with the asynchronous map-maker runs
+// on the map-maker's stream beside the following frames: nothing it reads changes while the stream's adjustment is pending.
+__global__ __launch_bounds__(64) void k_ba_select(MapDev m, TrackParams tp, BaPool pool, int mode) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= pool.N) return;
+  TrackerState* st = &m.st[s];
+  const BaView v = ba_view(pool, s);
+  BaResult* R = v.res;
+  const int K = tp.max_keyframes;
+  const Pose* kfp = m.kf_pose + (size_t)s * K;
+  const int* kff = m.kf_fixed + (size_t)s * K;
+  int* view_of_kf = pool.view_of_kf + (size_t)s * BA_MAX_KF;
+  int go = 0, nadj_out = 0;
+  const bool in_flight = st->ba_countdown > 0;     // asynchronous map-maker: the pool still belongs to the last keyframe
+  if (!in_flight) R->active = 0;
+  if (mode == 0 && st->kf_pending) {
+    st->n_kf++;                                                       // mMap.vpKeyFrames.push_back (:489)
+    st->kf_added = 1;
+    st->ba_converged_full = 0; st->ba_converged_recent = 0;           // :504-505
+  }
+  bool want = st->map_good && (mode != 0 || st->kf_pending) && !in_flight;
+  if (mode == 3) want = want && !st->ba_converged_recent;                                   // MapMaker::run :97-98
+  if (mode == 4) want = want && st->ba_converged_recent && !st->ba_converged_full;          // :107-108
+  const bool all = mode == 2 || mode == 4;
+  if (want && mode == 3) st->n_ba_recent_idle++;
+  if (want && mode == 4) st->n_ba_all++;
+  const int nk = st->n_kf;
+  if (want) for (int k = 0; k < BA_MAX_KF; k++) view_of_kf[k] = -1;
+  if (want && !all) {
+    if (nk < tp.ba_min_keyframes) { st->ba_converged_recent = 1; st->ba_accepted = -2; }   // :803-807
+    else {
+      // adjust set: newest + (window-1) nearest non-fixed (:812-820), camera ids in keyframe order
+      const int newest = nk - 1;
+      int N = tp.ba_window - 1; if (N > nk - 1) N = nk - 1;
+      unsigned long long chosen[2] = {0ull, 0ull}, taken[2] = {0ull, 0ull};      // bit sets over up to 128 keyframes
+      chosen[newest >> 6] |= 1ull << (newest & 63);
+      for (int n = 0; n < N; n++) {                                   // partial_sort by (distance, index)
+        int best = -1; double bd = 0;
+        for (int k = 0; k < nk; k++) {
+          if (k == newest || ((taken[k >> 6] >> (k & 63)) & 1ull)) continue;
+          const double d = kfdist(kfp[newest], kfp[k]);
+          if (best < 0 || d < bd) { best = k; bd = d; }
+        }
+        if (best < 0) break;
+        taken[best >> 6] |= 1ull << (best & 63);
+        if (!kff[best]) chosen[best >> 6] |= 1ull << (best & 63);
+      }
+      int c = 0;
+      for (int k = 0; k < nk; k++) if ((chosen[k >> 6] >> (k & 63)) & 1ull) { view_of_kf[k] = c; v.cam_fixed[c] = kff[k]; v.cam_pose[c] = kfp[k]; pool.id_view[(size_t)s * pool.max_cams + c] = k; c++; }
+      nadj_out = c; go = 1;
+    }
+  } else if (want && all) {                                           // BundleAdjustAll :776-798
+    int c = 0;
+    for (int k = 0; k < nk; k++) if (!kff[k]) { view_of_kf[k] = c; v.cam_fixed[c] = 0; v.cam_pose[c] = kfp[k]; pool.id_view[(size_t)s * pool.max_cams + c] = k; c++; }
+    nadj_out = c; go = c > 0 && c <= 64;                            // the slot layout holds the adjustable cameras of a point in one 64-bit set
+    if (c > 64) st->ba_accepted = -3;
+  }
+  R->go = go; R->nadj = nadj_out;
+  if (go && mode == 0 && tp.ba_delay > 0) st->ba_countdown = tp.ba_delay;   // results are applied ba_delay frames from now
+}
+
 __global__ __launch_bounds__(BA_THREADS) void k_ba_assemble(MapDev m, TrackParams tp, BaPool pool, int mode, int slot /* work list to enter, or -1 */) {
   const int s = blockIdx.x;
   TrackerState* st = &m.st[s];
   const BaView v = ba_view(pool, s);
   BaResult* R = v.res;
-  __shared__ int sh_go, sh_nc, sh_nadj, sh_nm;
-  __shared__ int view_of_kf[64];      // kf index -> camera id or -1
+  if (!R->go) return;
+  __shared__ int sh_nc, sh_nm;
+  __shared__ int view_of_kf[BA_MAX_KF];      // kf index -> camera id or -1
   __shared__ int ired[BA_WAVES];
-  __shared__ int kf_cnt[64], kf_off[64];
+  __shared__ int kf_cnt[BA_MAX_KF], kf_off[BA_MAX_KF];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int P = tp.max_points, K = tp.max_keyframes;
   const Pose* kfp = m.kf_pose + (size_t)s * K;
   const int* kff = m.kf_fixed + (size_t)s * K;
   const MeasDev* kfm = m.kf_meas + (size_t)s * K * P;
-  if (threadIdx.x == 0) {
-    sh_go = 0;
-    const bool in_flight = st->ba_countdown > 0;     // asynchronous map-maker: the pool still belongs to the last keyframe
-    if (!in_flight) R->active = 0;
-    if (mode == 0 && st->kf_pending) {
-      st->n_kf++;                                                       // mMap.vpKeyFrames.push_back (:489)
-      st->kf_added = 1;
-      st->ba_converged_full = 0; st->ba_converged_recent = 0;           // :504-505
-    }
-    const bool want = st->map_good && (mode != 0 || st->kf_pending) && !in_flight;
-    const int nk = st->n_kf;
-    for (int k = 0; k < 64; k++) view_of_kf[k] = -1;
-    if (want && mode != 2) {
-      if (nk < tp.ba_min_keyframes) { st->ba_converged_recent = 1; st->ba_accepted = -2; }   // :803-807
-      else {
-        // adjust set: newest + (window-1) nearest non-fixed (:812-820), camera ids in keyframe order
-        const int newest = nk - 1;
-        int N = tp.ba_window - 1; if (N > nk - 1) N = nk - 1;
-        bool chosen[64];
-        for (int k = 0; k < nk; k++) chosen[k] = false;
-        chosen[newest] = true;
-        bool taken[64];
-        for (int k = 0; k < nk; k++) taken[k] = false;
-        for (int n = 0; n < N; n++) {                                   // partial_sort by (distance, index)
-          int best = -1; double bd = 0;
-          for (int k = 0; k < nk; k++) {
-            if (k == newest || taken[k]) continue;
-            const double d = kfdist(kfp[newest], kfp[k]);
-            if (best < 0 || d < bd) { best = k; bd = d; }
-          }
-          if (best < 0) break;
-          taken[best] = true;
-          if (!kff[best]) chosen[best] = true;
-        }
-        int c = 0;
-        for (int k = 0; k < nk; k++) if (chosen[k]) { view_of_kf[k] = c; v.cam_fixed[c] = kff[k]; v.cam_pose[c] = kfp[k]; pool.id_view[(size_t)s * pool.max_cams + c] = k; c++; }
-        sh_nadj = c; sh_go = 1;
-      }
-    } else if (want && mode == 2) {                                     // BundleAdjustAll :776-798
-      int c = 0;
-      for (int k = 0; k < nk; k++) if (!kff[k]) { view_of_kf[k] = c; v.cam_fixed[c] = 0; v.cam_pose[c] = kfp[k]; pool.id_view[(size_t)s * pool.max_cams + c] = k; c++; }
-      sh_nadj = c; sh_go = c > 0;
-    }
-  }
+  if (threadIdx.x < BA_MAX_KF) view_of_kf[threadIdx.x] = pool.view_of_kf[(size_t)s * BA_MAX_KF + threadIdx.x];
+  const int sh_nadj = R->nadj;
   __syncthreads();
-  if (!sh_go) return;
   const int nk = st->n_kf, npts = st->n_points, nadj = sh_nadj;
   MapPointDev* pts = m.pts + (size_t)s * P;
   // ---- point set (:823-831 / :791-795), ids in map order; id_point translation ----
@@ -426,7 +449,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_assemble(MapDev m, TrackParam
   if (threadIdx.x == 0) { int o = 0; for (int k = 0; k < nk; k++) { kf_off[k] = o; o += kf_cnt[k]; } sh_nm = o; }
   __syncthreads();
   const int nm = sh_nm;
-  if (np > pool.max_pts || nm > pool.max_meas || ncam > pool.max_cams) { if (threadIdx.x == 0) { R->active = 0; st->ba_accepted = -3; } return; }
+  if (np > pool.max_pts || nm > pool.max_meas || ncam > pool.max_cams) { if (threadIdx.x == 0) { R->active = 0; R->go = 0; st->ba_accepted = -3; } return; }
   for (int k = 0; k < nk; k++) {
     if (view_of_kf[k] < 0) continue;
     const int cam = view_of_kf[k];
@@ -457,7 +480,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_assemble(MapDev m, TrackParam
   __syncthreads();
   if (threadIdx.x == 0) {
     R->n_cams = ncam; R->n_pts = np; R->n_meas = nm; R->active = (ncam > 0 && np > 0 && nm > 0); R->accepted = 0; R->n_outlier_meas = 0; R->computed = 0;
-    if (mode == 0 && tp.ba_delay > 0) st->ba_countdown = tp.ba_delay;   // results are applied ba_delay frames from now
+    R->go = 0;
     if (slot >= 0 && R->active) pool.work[(size_t)slot * pool.N + atomicAdd(&pool.work_n[slot], 1)] = s;   // list order is immaterial: the problems are independent
   }
 }
@@ -491,18 +514,49 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_writeback(MapDev m, TrackPara
       for (int c = threadIdx.x; c < R->n_cams; c += BA_THREADS) m.kf_pose[(size_t)s * K + idv[c]] = v.cam_pose[c];
     }
     __syncthreads();
+    // Outlier measurements (:941-959).  The reference walks the list in order; entries of different points do not interact (a
+    // point's bBad flag and its sMeasurementKFs size are touched by its own entries only), so the first entry of every point
+    // takes that point's entries in list order and the points proceed in parallel (a bundle adjustment reports hundreds of
+    // outliers: one lane walking them through dependent global accesses was most of this kernel's time).
+    if (acc >= 0) {
+      const int no = R->n_outlier_meas;
+      __shared__ int sh_op[2048];                                        // the outliers' point ids (the scans below read them n^2 / 2 times)
+      const bool in_lds = no <= 2048;
+      if (in_lds) for (int o = threadIdx.x; o < no; o += BA_THREADS) sh_op[o] = v.outl[2 * o];
+      __syncthreads();
+      auto op = [&](int q) -> int { return in_lds ? sh_op[q] : v.outl[2 * q]; };
+      for (int o = threadIdx.x; o < no; o += BA_THREADS) {
+        const int bp = op(o);
+        bool first = true;
+        for (int q = 0; q < o && first; q++) if (op(q) == bp) first = false;
+        if (!first) continue;
+        const int pp = idp[bp];
+        int nkfs = pts[pp].n_meas_kfs; int bad = pts[pp].bad;
+        for (int q = o; q < no; q++) {
+          if (op(q) != bp) continue;
+          const int pk = idv[v.outl[2 * q + 1]];
+          MeasDev& mm = kfm[(size_t)pk * P + pp];
+          if (nkfs <= 2 || mm.source == 2 /* SRC_ROOT */) bad = 1;
+          else {
+            if (tp.idle > 0) {                                             // :951-956: a second chance later, or never again
+              if (mm.source == 0 /* SRC_TRACKER */ || mm.source == 4 /* SRC_EPIPOLAR */) {
+                const int e = atomicAdd(&st->fq_n, 1);                     // (the queue is sorted / order-free when it is read)
+                if (e < tp.fq_cap) m.fq[(size_t)s * tp.fq_cap + e] = make_int2(pk, pp);
+              } else atomicOr(&m.never_retry[((size_t)s * P + pp) * 2 + (pk >> 6)], 1ull << (pk & 63));
+            }
+            mm.valid = 0; nkfs--;
+          }
+        }
+        pts[pp].n_meas_kfs = nkfs; pts[pp].bad = bad;
+      }
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
       st->ba_accepted = acc;
       st->n_ba_trials += (unsigned long long)R->trials;
       if (acc >= 0) {
         if (acc > 0) { if (mode != 2) st->ba_converged_recent = 0; st->ba_converged_full = 0; }
         if (R->converged) { st->ba_converged_recent = 1; if (mode == 2) st->ba_converged_full = 1; }   // :931-935
-        for (int o = 0; o < R->n_outlier_meas; o++) {                    // :941-959, sequential like the reference
-          const int pp = idp[v.outl[2 * o]], pk = idv[v.outl[2 * o + 1]];
-          MeasDev& mm = kfm[(size_t)pk * P + pp];
-          if (pts[pp].n_meas_kfs <= 2 || mm.source == 2 /* SRC_ROOT */) pts[pp].bad = 1;
-          else { mm.valid = 0; pts[pp].n_meas_kfs--; }                   // failure queue / never-retry sets feed "next" rows only
-        }
       }
       R->active = 0;
     }
@@ -518,6 +572,20 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_writeback(MapDev m, TrackPara
   }
 }
 
+// HandleBadPoints (:140-164) on its own: MapMaker::run :117 calls it after every pass through the idle jobs
+__global__ __launch_bounds__(BA_THREADS) void k_handle_bad_points(MapDev m, TrackParams tp) {
+  const int s = blockIdx.x;
+  const TrackerState* st = &m.st[s];
+  if (!st->map_good) return;
+  const int P = tp.max_points, K = tp.max_keyframes, nk = st->n_kf;
+  MapPointDev* pts = m.pts + (size_t)s * P;
+  MeasDev* kfm = m.kf_meas + (size_t)s * K * P;
+  for (int i = threadIdx.x; i < st->n_points; i += BA_THREADS) {
+    if (pts[i].n_out > 20 && pts[i].n_out > pts[i].n_in) pts[i].bad = 1;
+    if (pts[i].bad) for (int k = 0; k < nk; k++) kfm[(size_t)k * P + i].valid = 0;
+  }
+}
+
 // ---- host ---------------------------------------------------------------------------------------------------------
 struct BaSystemWs { BaPool pool; };
 
@@ -525,7 +593,7 @@ int ba_alloc(vslam_system* sys) {
   BaSystemWs* ws = new BaSystemWs();
   sys->ba_ws = ws;
   const int K = sys->p.max_keyframes, P = sys->p.max_points;
-  if (K > 64) { vslam_set_error("max_keyframes > 64"); return VSLAM_E_INVALID; }
+  if (K > BA_MAX_KF) { vslam_set_error("max_keyframes %d exceeds %d", K, BA_MAX_KF); return VSLAM_E_INVALID; }
   // worst case of BundleAdjust: every keyframe a camera, every point, every (kf, point) slot a measurement
   size_t M = (size_t)K * P;
   if (M > 65536) M = 65536;
@@ -548,9 +616,7 @@ static int ba_launch_batch(vslam_system* sys) {
   const BaConfig cfg = make_cfg(sys->tp);
   const int R = (int)sys->ev_ba.size(), slot = (int)(sys->ba_batch_id % R);
   sys->ba_stream = sys->ba_streams[(size_t)(sys->ba_batch_id % (long)sys->ba_streams.size())];
-  HIPCHK(hipEventRecord(sys->ev_asm[slot], sys->stream));
-  HIPCHK(hipStreamWaitEvent(sys->ba_stream, sys->ev_asm[slot], 0));
-  prof_mark(sys, 12);
+  prof_mark(sys, 12);                                  // the batch's assemblies precede on this very stream
   // one workgroup per problem up to two per compute unit; the grid walks the batch's work list
   const int cap = 2 * (sys->n_cu > 0 ? sys->n_cu : 256);
   const int ba_grid = sys->S < cap ? sys->S : cap;
@@ -600,12 +666,14 @@ static int ba_drain(vslam_system* sys) {
   return VSLAM_OK;
 }
 
-// mode 0: tracker-driven AddKeyFrame + BundleAdjustRecent; 1: BundleAdjustRecent; 2: BundleAdjustAll
+// mode 0: tracker-driven AddKeyFrame + BundleAdjustRecent; 1: BundleAdjustRecent; 2: BundleAdjustAll; 3 / 4: the same two as idle jobs of
+// MapMaker::run, for the streams whose adjustment has not converged (gated on device)
 int ba_run(vslam_system* sys, int mode) {
+  const int base = mode == 3 ? 1 : (mode == 4 ? 2 : mode);          // what the assembly and the write-back do
   BaSystemWs* ws = (BaSystemWs*)sys->ba_ws;
   const BaConfig cfg = make_cfg(sys->tp);
   const bool async = mode == 0 && sys->tp.ba_delay > 0;
-  if (mode != 0) { int r = ba_drain(sys); if (r) return r; }
+  if (mode == 1 || mode == 2) { int r = ba_drain(sys); if (r) return r; }
   if (mode == 0) {
     KfCopyArgs a; fill_kfcopy(sys, a);
     prof_mark(sys, 10);
@@ -621,9 +689,16 @@ int ba_run(vslam_system* sys, int mode) {
     // collected in one work list and launched together; successive launches go to a ring of streams and may overlap.
     // A launch walks exactly its batch's list -- never a problem a later frame's k_ba_assemble is writing beside it.
     const int R = (int)sys->ev_ba.size(), slot = (int)(sys->ba_batch_id % R);
+    hipStream_t bs = sys->ba_streams[(size_t)(sys->ba_batch_id % (long)sys->ba_streams.size())];
+    hipLaunchKernelGGL(k_ba_select, dim3((sys->S + 63) / 64), dim3(64), 0, sys->stream, sys->map, sys->tp, ws->pool, mode);
+    // the long part of the assembly leaves the tracker's stream: behind this frame's keyframe copy / map growth, on the batch's
+    // map-maker stream (every frame of a batch uses the same stream, so the batch's launch follows all its assemblies)
+    const int FBn = (int)sys->frame_batch.size(), es = (int)(sys->frame_no % FBn);
+    HIPCHK(hipEventRecord(sys->ev_asm[es], sys->stream));
+    HIPCHK(hipStreamWaitEvent(bs, sys->ev_asm[es], 0));
     if (sys->ba_batch_fill == 0)
-      HIPCHK(hipMemsetAsync(ws->pool.work_n + slot, 0, sizeof(int), sys->stream));   // the launch that read this slot R batches ago was waited for (ba_frame_start)
-    hipLaunchKernelGGL(k_ba_assemble, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, mode, slot);
+      HIPCHK(hipMemsetAsync(ws->pool.work_n + slot, 0, sizeof(int), bs));   // the launch that read this slot R batches ago was waited for (ba_frame_start)
+    hipLaunchKernelGGL(k_ba_assemble, dim3(sys->S), dim3(BA_THREADS), 0, bs, sys->map, sys->tp, ws->pool, mode, slot);
     sys->frame_batch[(size_t)(sys->frame_no % (long)sys->frame_batch.size())] = sys->ba_batch_id;
     sys->ba_batch_fill++;
     if (sys->ba_batch_fill >= sys->tp.ba_batch) { int rl = ba_launch_batch(sys); if (rl) return rl; }
@@ -631,16 +706,36 @@ int ba_run(vslam_system* sys, int mode) {
     HIPCHK(hipGetLastError());
     return VSLAM_OK;
   }
-  hipLaunchKernelGGL(k_ba_assemble, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, mode, -1);
+  hipLaunchKernelGGL(k_ba_select, dim3((sys->S + 63) / 64), dim3(64), 0, sys->stream, sys->map, sys->tp, ws->pool, mode);
+  hipLaunchKernelGGL(k_ba_assemble, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, base, -1);
   if (mode == 0) prof_mark(sys, 12);
   hipLaunchKernelGGL(k_ba_compute, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, ws->pool, cfg, -1);
   if (mode == 0) prof_mark(sys, 13);
-  hipLaunchKernelGGL(k_ba_writeback, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, mode);
+  hipLaunchKernelGGL(k_ba_writeback, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, base);
   HIPCHK(hipGetLastError());
   return VSLAM_OK;
 }
 
 int ba_add_keyframe_and_adjust(vslam_system* sys) { return ba_run(sys, 0); }
+
+// vslam_params.idle_iterations passes through the idle jobs of MapMaker::run (jni/MapMaker.cc:94-117), every stream deciding on
+// device which of them it runs: BundleAdjustRecent until converged, ReFindNewlyMade, BundleAdjustAll until converged, every 20th
+// time ReFindFromFailureQueue, HandleBadPoints (the tail of the write-back kernels).  Synchronous map-maker only.
+int mm_idle_job(vslam_system* sys, int job) {
+  if (job < 0 || job > 3) { vslam_set_error("mapmaker_idle_job: job must be 0..3"); return VSLAM_E_INVALID; }
+  if (job == 0) return ba_run(sys, 3);                 // the write-back ends with HandleBadPoints
+  if (job == 2) return ba_run(sys, 4);
+  const int r = grow_idle_refind(sys, job == 1 ? 0 : 1);
+  if (r) return r;
+  hipLaunchKernelGGL(k_handle_bad_points, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp);   // :117
+  HIPCHK(hipGetLastError());
+  return VSLAM_OK;
+}
+int mm_idle(vslam_system* sys) {
+  for (int it = 0; it < sys->p.idle_iterations; it++)
+    for (int job = 0; job < 4; job++) { const int r = mm_idle_job(sys, job); if (r) return r; }
+  return VSLAM_OK;
+}
 
 extern "C" int vslam_get_bundle_stats(vslam_system* sys, int s, int out[6]) {
   if (!sys || !out || s < 0 || s >= sys->S || !sys->ba_ws) { vslam_set_error("get_bundle_stats: bad argument"); return VSLAM_E_INVALID; }

@@ -40,6 +40,7 @@
 struct BaResult {
   int active;           // 0: nothing to do for this problem
   int computed;         // set by Bundle::Compute: an assembled problem is solved exactly once (the gated kernel is launched every frame)
+  int go, nadj;         // k_ba_select -> k_ba_assemble: a problem is to be assembled for this stream; its number of adjustable cameras
   int n_cams, n_pts, n_meas, n_free;
   int accepted;         // Compute() return value (negative on error)
   int converged, hit_max;
@@ -434,7 +435,7 @@ __device__ __attribute__((noinline)) void ba_build_layout(const BaView& v_, int 
     int k = 0, start = 0;
     if (np > 0) ch[0] = 0;
     for (int p = 0; p < np; p++) {
-      if (o[p + 1] - o[start] > 64) { ch[++k] = p; start = p; }
+      if (o[p + 1] - o[start] > 64 && p > start) { ch[++k] = p; start = p; }   // a point with more than 64 slots stands alone
     }
     if (np > 0) ch[++k] = np;
     v.ch_n[threadIdx.x == 0 ? 0 : 1] = k;
@@ -517,7 +518,12 @@ __device__ __attribute__((noinline)) double ba_step_sweep(const BaView& v_, cons
   _Pragma("unroll") for (int f = 0; f < BA_MFMA_FREE; f++) uacc[f] = 0.0;
   for (int k = wave; k < nch; k += BA_WAVES) {
     const int p0 = ch[k], p1 = ch[k + 1];
-    const int a = base + off[p0], n = base + off[p1] - a;              // n <= 64 slots
+    const int a0 = base + off[p0], ntot = base + off[p1] - a0;         // <= 64 slots, or ONE point with more (a keyframe-rich map: fixed cameras)
+    const int ntrip = (ntot + 63) >> 6;
+    double carry[9];                                                   // lane 0: the running sums of a point that spans several trips
+    _Pragma("unroll") for (int q = 0; q < 9; q++) carry[q] = 0.0;
+    for (int trip = 0; trip < (ntrip > 0 ? ntrip : 1); trip++) {
+    const int a = a0 + 64 * trip, n = min(64, ntot - 64 * trip);
     const bool act = lane < n;
     const int s = a + (act ? lane : 0);
     const int info = v.sl_info[s], pt = v.sl_pt[s];
@@ -566,18 +572,25 @@ __device__ __attribute__((noinline)) double ba_step_sweep(const BaView& v_, cons
       __builtin_amdgcn_s_waitcnt(0xC07F);
       __builtin_amdgcn_wave_barrier();
       const int ptprev = __shfl_up(pt, 1);
-      if (act && (lane == 0 || ptprev != pt)) {                       // first slot of the point in this region
-        const int cnt = off[pt + 1] - off[pt];
+      if (act && (lane == 0 || ptprev != pt)) {                       // first slot of the point in this region (or in this trip of its slots)
+        const int cnt = ntrip > 1 ? n : off[pt + 1] - off[pt];
         double acc[9];
         const bool cont = region == 1 && v.pt_offF[pt + 1] - v.pt_offF[pt] > 0;   // continue the sum the F sweep left
-        _Pragma("unroll") for (int q = 0; q < 6; q++) acc[q] = cont ? PT(pt_V, q, pt) : 0.0;
-        _Pragma("unroll") for (int q = 0; q < 3; q++) acc[6 + q] = cont ? PT(pt_eb, q, pt) : 0.0;
+        if (trip == 0) {
+          _Pragma("unroll") for (int q = 0; q < 6; q++) acc[q] = cont ? PT(pt_V, q, pt) : 0.0;
+          _Pragma("unroll") for (int q = 0; q < 3; q++) acc[6 + q] = cont ? PT(pt_eb, q, pt) : 0.0;
+        } else {
+          _Pragma("unroll") for (int q = 0; q < 9; q++) acc[q] = carry[q];
+        }
         for (int j = 0; j < cnt; j++) {
           _Pragma("unroll") for (int q = 0; q < 9; q++) acc[q] += stg[(lane + j) * 9 + q];
         }
-        // lower triangle of V: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) -> components 0..5
-        _Pragma("unroll") for (int q = 0; q < 6; q++) PT(pt_V, q, pt) = acc[q];
-        _Pragma("unroll") for (int q = 0; q < 3; q++) PT(pt_eb, q, pt) = acc[6 + q];
+        _Pragma("unroll") for (int q = 0; q < 9; q++) carry[q] = acc[q];
+        if (trip == ntrip - 1 || ntrip <= 1) {
+          // lower triangle of V: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) -> components 0..5
+          _Pragma("unroll") for (int q = 0; q < 6; q++) PT(pt_V, q, pt) = acc[q];
+          _Pragma("unroll") for (int q = 0; q < 3; q++) PT(pt_eb, q, pt) = acc[6 + q];
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -598,6 +611,7 @@ __device__ __attribute__((noinline)) double ba_step_sweep(const BaView& v_, cons
           uacc[f] += wave_multi_sum<32>(t32);
         }
       }
+    }
     }
   }
   if (fastU) {
@@ -965,6 +979,7 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
   }
   __syncthreads();
   const int nfree = R->n_free, nS = nfree * 6;
+  if (nfree > 64) { if (threadIdx.x == 0) { R->accepted = -1; R->converged = 0; R->hit_max = 0; R->counter = 0; R->n_outlier_meas = 0; } __syncthreads(); return; }   // pt_maskF holds 64 ordinals
 #ifdef VSLAM_BA_PROF
   unsigned long long ba_t0 = clock64();
 #endif

@@ -15,6 +15,7 @@
 //   k_candidates / k_thin_candidates   MakeKeyFrame_Rest's Shi-Tomasi candidates (jni/KeyFrame.cc:66-95) and
 //                 MapMaker::ThinCandidates (jni/MapMaker.cc:393-422), ordered block compaction.
 #include "vslam_internal.h"
+#include <stdlib.h>
 
 #define BAND 16          // level-0 rows per workgroup (multiple of 8: three halvings stay inside a band)
 #define HALO 3           // FAST ring radius (cvfast.cpp:6094-6111)
@@ -231,43 +232,58 @@ __global__ __launch_bounds__(FE_THREADS) void k_fast_lvl(FeArgs a) {
             a.cmask[l] + (size_t)s * a.h[l] * a.nchunk[l], a.rowcnt[l] + (size_t)s * a.h[l], mask_lds, cand, ncand);
 }
 
-// Raster-ordered corner lists + row LUT from the corner bit-masks: one workgroup per (level, stream).  Every thread owns
-// a contiguous run of mask words (word index = row * nchunk + chunk, i.e. raster order), a block-wide exclusive scan of
-// the popcounts gives its output offset, and it expands its bits in order -> the list is bit-exactly the reference's
-// push_back order (cvfast.cpp:9237-9238) with no ordered atomics; lut[y] is the offset of the first word of row y
-// (jni/KeyFrame.cc:43-49).
-#define COMPACT_THREADS 1024
+// Raster-ordered corner lists + row LUT from the corner bit-masks, one workgroup per (band of 16 rows, level, stream): the
+// workgroup adds the row counts above its band (its list offset = lut of its first row), scans the popcounts of its band's
+// mask words (word index = row * nchunk + chunk, i.e. raster order) and every thread expands its words at its scanned
+// offset -> the list is bit-exactly the reference's push_back order (cvfast.cpp:9237-9238) with no ordered atomics;
+// lut[y] is the offset of the first word of row y (jni/KeyFrame.cc:43-49).  (One workgroup per (level, stream) walking the
+// whole level was the fourth largest kernel of the path: the level-0 workgroup did nearly all the work.)
+#define COMPACT_THREADS 256
 __global__ __launch_bounds__(COMPACT_THREADS) void k_compact(FeArgs a) {
   __shared__ int wsum[COMPACT_THREADS / 64];
-  const int l = blockIdx.x, s = blockIdx.y;
+  __shared__ int sh_above;
+  const int b = blockIdx.x, l = blockIdx.y, s = blockIdx.z;
   const int h = a.h[l], nchunk = a.nchunk[l], cap = a.cap[l];
-  const int nw = h * nchunk;
-  const unsigned long long* cm = a.cmask[l] + (size_t)s * nw;
+  const int y0 = b * BAND;
+  if (y0 >= h) return;
+  const int nrows = min(BAND, h - y0);
+  const int* rc = a.rowcnt[l] + (size_t)s * h;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int above = 0;
+  for (int y = threadIdx.x; y < y0; y += COMPACT_THREADS) above += rc[y];
+  for (int d = 32; d > 0; d >>= 1) above += __shfl_xor(above, d);
+  if (lane == 0) wsum[wave] = above;
+  __syncthreads();
+  if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < COMPACT_THREADS / 64; w++) t += wsum[w]; sh_above = t; }
+  __syncthreads();
+  const int first = sh_above;
+  const int nw = nrows * nchunk;
+  const unsigned long long* cm = a.cmask[l] + ((size_t)s * h + y0) * nchunk;
   uint32_t* out = a.corners[l] + (size_t)s * cap;
   int* lut = a.rowlut[l] + (size_t)s * (h + 1);
   const int per = (nw + COMPACT_THREADS - 1) / COMPACT_THREADS;
   const int lo = min((int)threadIdx.x * per, nw), hi = min(lo + per, nw);
   int cnt = 0;
   for (int i = lo; i < hi; i++) cnt += __popcll(cm[i]);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int inc = cnt;
   for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(inc, d); if (lane >= d) inc += v; }
+  __syncthreads();
   if (lane == 63) wsum[wave] = inc;
   __syncthreads();
-  int base = inc - cnt, total = 0;
+  int base = first + inc - cnt, total = first;
   for (int w = 0; w < COMPACT_THREADS / 64; w++) { if (w < wave) base += wsum[w]; total += wsum[w]; }
   for (int i = lo; i < hi; i++) {
     unsigned long long m = cm[i];
-    const int y = i / nchunk, c = i - y * nchunk;
+    const int rr = i / nchunk, c = i - rr * nchunk, y = y0 + rr;
     if (c == 0) lut[y] = min(base, cap);
     while (m) {
-      const int b = __ffsll((long long)m) - 1;
-      if (base < cap) out[base] = (uint32_t)((c << 6) + b) | ((uint32_t)y << 16);
+      const int bit = __ffsll((long long)m) - 1;
+      if (base < cap) out[base] = (uint32_t)((c << 6) + bit) | ((uint32_t)y << 16);
       base++;
       m &= m - 1;
     }
   }
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && y0 + nrows == h) {                         // the last band of the level closes the list
     lut[h] = min(total, cap);
     a.ncorners[s * NLEV + l] = min(total, cap);
     if (total > cap) *a.overflow = 1;
@@ -553,7 +569,7 @@ int fe_make_keyframe_lite(vslam_system* sys, const uint8_t* gray, size_t row_str
   prof_mark(sys, 1);
   hipLaunchKernelGGL(k_fast_lvl, dim3(nb, sys->S), dim3(FE_THREADS), lds1, fs, a);
   prof_mark(sys, 2);
-  hipLaunchKernelGGL(k_compact, dim3(NLEV, sys->S), dim3(COMPACT_THREADS), 0, fs, a);
+  hipLaunchKernelGGL(k_compact, dim3(nb0, NLEV, sys->S), dim3(COMPACT_THREADS), 0, fs, a);
   if (sys->p.use_sbi) {                                           // jni/Tracker.cc:86-97, 104-105
     int r = fe_sbi(sys, sys->have_sbi ? sys->frbuf[b ^ 1] : sys->fr);
     if (r) return r;
@@ -675,7 +691,7 @@ int fe_keyframe_corners(vslam_system* sys, int s, int kf) {
   for (int l = 1; l < NLEV; l++) { a.band_first[l] = nb; nb += (g[l].h + BAND - 1) / BAND; }
   const size_t lds1 = (size_t)(BAND + 2 * HALO) * lp1 + 16 + (size_t)BAND * g[1].nchunk * 8 + (size_t)FB_ROWS * lp1 * 2 + 16;
   hipLaunchKernelGGL(k_fast_lvl, dim3(nb, 1), dim3(FE_THREADS), lds1, sys->stream, a);
-  hipLaunchKernelGGL(k_compact, dim3(NLEV, 1), dim3(COMPACT_THREADS), 0, sys->stream, a);
+  hipLaunchKernelGGL(k_compact, dim3((g[0].h + BAND - 1) / BAND, NLEV, 1), dim3(COMPACT_THREADS), 0, sys->stream, a);
   uint32_t* d[NLEV];
   for (int l = 0; l < NLEV; l++) d[l] = sys->map.kf_corners[l] + ((size_t)s * K + kf) * sys->tp.kcap[l];
   hipLaunchKernelGGL(k_store_kf_corners, dim3(NLEV), dim3(256), 0, sys->stream, scr.corners[0], scr.corners[1], scr.corners[2], scr.corners[3], scr.ncorners,

@@ -50,7 +50,7 @@ extern "C" int vslam_map_add_keyframe(vslam_system* sys, int s, const double pos
   HIPCHK(hipMemcpyAsync(sys->map.kf_fixed + (size_t)s * K + k, &fx, sizeof(int), hipMemcpyHostToDevice, sys->stream));
   HIPCHK(hipMemcpyAsync(sys->map.kf_depth + ((size_t)s * K + k) * 2, dd, sizeof(dd), hipMemcpyHostToDevice, sys->stream));
   HIPCHK(hipMemsetAsync(sys->map.kf_meas + ((size_t)s * K + k) * sys->p.max_points, 0, sizeof(MeasDev) * sys->p.max_points, sys->stream));
-  if (sys->p.grow_map) { r = fe_keyframe_corners(sys, s, k); if (r) return r; }   // Level::vCorners, needed as an epipolar-search target
+  if (sys->p.grow_map || sys->p.idle_iterations != 0) { r = fe_keyframe_corners(sys, s, k); if (r) return r; }   // Level::vCorners, needed as an epipolar-search target
   st.n_kf = k + 1;
   r = put_state(sys, s, &st); if (r) return r;
   return k;
@@ -76,6 +76,7 @@ extern "C" int vslam_map_add_point(vslam_system* sys, int s, const double pos[3]
   HIPCHK(hipMemcpyAsync(sys->map.pts + (size_t)s * P + i, &mp, sizeof(mp), hipMemcpyHostToDevice, sys->stream));
   HIPCHK(hipMemcpyAsync(sys->map.td + (size_t)s * P + i, &td, sizeof(td), hipMemcpyHostToDevice, sys->stream));
   st.n_points = i + 1;
+  st.newq_head = st.n_points;                 // uploaded points are not "newly made" (mqNewQueue holds AddPointEpipolar's)
   r = put_state(sys, s, &st); if (r) return r;
   return i;
 }
@@ -151,6 +152,7 @@ extern "C" int vslam_map_add_points(vslam_system* sys, int s, int n, const doubl
     HIPCHK(hipMemcpy(sys->map.pt_flags + (size_t)s * P + st.n_points, fl.data(), sizeof(int) * n, hipMemcpyHostToDevice));
   }
   st.n_points += n;
+  st.newq_head = st.n_points;
   r = put_state(sys, s, &st); if (r) return r;
   return st.n_points;
 }
@@ -250,7 +252,8 @@ extern "C" int vslam_finish_frame(vslam_system* sys) {
   if (!sys) return VSLAM_E_INVALID;
   if (!sys->frame_open) { vslam_set_error("finish_frame: no frame in progress"); return VSLAM_E_STATE; }
   sys->frame_open = false;
-  const int r = ba_add_keyframe_and_adjust(sys);                                       // :128-132 -> MapMaker::AddKeyFrame
+  int r = ba_add_keyframe_and_adjust(sys);                                             // :128-132 -> MapMaker::AddKeyFrame
+  if (!r && sys->p.idle_iterations > 0) r = mm_idle(sys);                              // the map-maker's idle jobs
   prof_mark(sys, VSLAM_N_STAGES);
   if (sys->prof_on && sys->prof_frame < sys->prof_cap) sys->prof_frame++;
   if (!r) HIPCHK(hipEventRecord(sys->ev_track_done[sys->fr_idx], sys->stream));       // the front-end may now reuse this buffer
@@ -373,6 +376,25 @@ extern "C" int vslam_get_state(vslam_system* sys, int s, vslam_track_state* o) {
   o->kf_added = st.kf_added; o->n_keyframes = st.n_kf; o->n_points = st.n_points; o->ba_accepted = st.ba_accepted;
   o->n_zmssd = (long long)st.n_zmssd; o->n_ba_trials = (long long)st.n_ba_trials;
   return VSLAM_OK;
+}
+
+// counters of the map-maker's idle jobs (vslam_params.idle_iterations): points re-found by ReFindNewlyMade and by
+// ReFindFromFailureQueue, BundleAdjustAll and idle BundleAdjustRecent calls, failure-queue and new-queue lengths
+extern "C" int vslam_get_idle_stats(vslam_system* sys, int s, int out[6]) {
+  CHK_STREAM(sys, s);
+  if (!out) return VSLAM_E_INVALID;
+  TrackerState st;
+  int r = get_state(sys, s, &st); if (r) return r;
+  out[0] = st.n_refound_new; out[1] = st.n_refound_failed; out[2] = st.n_ba_all; out[3] = st.n_ba_recent_idle; out[4] = st.fq_n; out[5] = st.n_points - st.newq_head;
+  return VSLAM_OK;
+}
+
+// One idle job of MapMaker::run for every stream, outside a frame (the streams decide on device whether it is due)
+extern "C" int vslam_mapmaker_idle_job(vslam_system* sys, int job) {
+  if (!sys) { vslam_set_error("mapmaker_idle_job: null system"); return VSLAM_E_INVALID; }
+  if (sys->frame_open) { vslam_set_error("mapmaker_idle_job: a frame is open (vslam_finish_frame first)"); return VSLAM_E_STATE; }
+  if (sys->p.idle_iterations == 0) { vslam_set_error("mapmaker_idle_job: created with idle_iterations = 0 (no failure queue / never-retry sets are kept); use -1 for idle jobs on request only"); return VSLAM_E_STATE; }
+  return mm_idle_job(sys, job);
 }
 
 extern "C" int vslam_get_message(vslam_system* sys, int s, char* buf, size_t cap) {

@@ -483,157 +483,259 @@ __global__ __launch_bounds__(GROW_THREADS) __attribute__((amdgpu_waves_per_eu(2,
   }
 }
 
-// MapMaker::ReFindInSingleKeyFrame(new keyframe) / ReFind_Common, jni/MapMaker.cc:967-1056 (vslam_params.grow_map bit 1).
+// MapMaker::ReFind_Common (jni/MapMaker.cc:967-1036) by one wavefront: try to measure map point `pid` in keyframe `k`.
+// `rowlut` = the row look-up table of keyframe k's corner lists when k is the current frame (the new keyframe), else null (the
+// rows are found by binary search in the stored list).  RefindCache is the function-static PatchFinder of the reference as far
+// as it can matter: MakeTemplateCoarseCont (jni/PatchFinder.cc:79-125) keeps the template of the previous call when that call
+// was for the same point and the warp moved by less than 0.07, and TemplateBad() then still says what the last generation said.
+struct RefindCache { bool have_last, prev_bad; double last_warp[4]; int tsum, tsumsq; };
+
+DEVFN void never_retry_set(const MapDev& m, const TrackParams& tp, int s, int pid, int k, int lane) {
+  if (m.never_retry && lane == 0) atomicOr(&m.never_retry[((size_t)s * tp.max_points + pid) * 2 + (k >> 6)], 1ull << (k & 63));
+}
+
+template <int PS>
+DEVFN bool refind_common(const MapDev& m, const TrackParams& tp, const GrowArgs& a, int s, int k, int pid, const int* rowlut,
+                         uint8_t* tmpl, double* slab, RefindCache& cache, int lane) {
+  constexpr int HALF = PS / 2;
+  const int K = tp.max_keyframes, P = tp.max_points;
+  MapPointDev& p = m.pts[(size_t)s * P + pid];
+  MeasDev& cell = m.kf_meas[((size_t)s * K + k) * P + pid];
+  if (cell.valid) return false;                                      // sMeasurementKFs.count(&k), :971
+  if (m.never_retry && ((m.never_retry[((size_t)s * P + pid) * 2 + (k >> 6)] >> (k & 63)) & 1ull)) return false;   // sNeverRetryKFs, :972
+  const Pose Tk = m.kf_pose[(size_t)s * K + k];
+  double c[3];
+  pose_xform(Tk, p.pos, c);
+  if (c[2] < 0.001) { never_retry_set(m, tp, s, pid, k, lane); return false; }                                     // :979
+  const double ip0 = c[0] / c[2], ip1 = c[1] / c[2];
+  if (ip0 * ip0 + ip1 * ip1 > tp.cam.largest_radius * tp.cam.largest_radius) { never_retry_set(m, tp, s, pid, k, lane); return false; }   // :985
+  const CamProj pr = cam_project(tp.cam, ip0, ip1);
+  if (pr.invalid) { never_retry_set(m, tp, s, pid, k, lane); return false; }                                       // :991
+  if (pr.im[0] < 0 || pr.im[1] < 0 || pr.im[0] > a.w[0] || pr.im[1] > a.h[0]) { never_retry_set(m, tp, s, pid, k, lane); return false; }   // :996
+  double d[4];
+  cam_derivs(tp.cam, pr, d);
+  // CalcSearchLevelAndWarpMatrix, jni/PatchFinder.cc:31-68
+  const double ooz = 1.0 / c[2];
+  double mr[3], md[3];
+  pose_rot(Tk, p.right, mr);
+  pose_rot(Tk, p.down, md);
+  const double r0 = mr[0] - c[0] * mr[2] * ooz, r1 = mr[1] - c[1] * mr[2] * ooz;
+  const double d0 = md[0] - c[0] * md[2] * ooz, d1 = md[1] - c[1] * md[2] * ooz;
+  const double wi[4] = {(d[0] * r0 + d[1] * r1) * ooz, (d[0] * d0 + d[1] * d1) * ooz, (d[2] * r0 + d[3] * r1) * ooz, (d[2] * d0 + d[3] * d1) * ooz};
+  double det = wi[0] * wi[3] - wi[1] * wi[2];
+  int level = 0;
+  while (det > 3 && level < NLEV - 1) { level++; det *= 0.25; }
+  const bool bad_scale = det > 3 || det < 0.25;                      // mbTemplateBad = true (:62-65); a regenerated template replaces the verdict
+  const int scale = 1 << level;
+  REFIND_STAMP(10);  // projection, derivatives, warp
+  // MakeTemplateCoarseCont, :79-125: transform_image with the accumulated stepping of jni/vision/ImageHandler.cpp:21-113
+  double inv[4];
+  inv2(wi, inv);
+  const double m2[4] = {inv[0] * scale, inv[1] * scale, inv[2] * scale, inv[3] * scale};
+  bool refresh = !cache.have_last;
+  for (int i = 0; !refresh && i < 2; i++) {
+    const double dx = m2[i] - cache.last_warp[i], dy = m2[2 + i] - cache.last_warp[2 + i];
+    if (dx * dx + dy * dy > 0.07 * 0.07) refresh = true;
+  }
+  bool bad;
+  if (refresh) {
+    int nOutside = 0, sum = 0, sumsq = 0;
+    const int sl = p.src_level;
+    const uint8_t* src = m.kf_img[sl] + ((size_t)s * K + p.src_kf) * a.kf_stride[sl];
+    const int sp = a.kf_pitch[sl], iw = a.w[sl], ih = a.h[sl];
+    const double across[2] = {m2[0], m2[2]}, down[2] = {m2[1], m2[3]};
+    const double px0 = (double)p.irx - (m2[0] * HALF + m2[1] * HALF), py0 = (double)p.iry - (m2[2] * HALF + m2[3] * HALF);
+    const double cr[2] = {down[0] - PS * across[0], down[1] - PS * across[1]};
+    // one template pixel per lane (two for 11x11): the lane walks the accumulated sample position to its pixel with exactly
+    // the additions transform_image makes (whole rows with their carriage return, then steps along the row)
+    const float x_bound = (float)(iw - 1), y_bound = (float)(ih - 1);
+    for (int q = lane; q < PS * PS; q += 64) {
+      const int r = q / PS, j = q - r * PS;
+      double x = px0, y = py0;
+#pragma unroll 1
+      for (int i = 0; i < r; i++) {
+#pragma unroll
+        for (int jj = 0; jj < PS; jj++) { x += across[0]; y += across[1]; }
+        x += cr[0]; y += cr[1];
+      }
+#pragma unroll 1
+      for (int jj = 0; jj < j; jj++) { x += across[0]; y += across[1]; }
+      int v = 0;
+      if (0 <= x && 0 <= y && x < x_bound && y < y_bound) {
+        const int lx = (int)x, ly = (int)y;
+        x -= lx; y -= ly;
+        const uint8_t* q0 = src + (size_t)ly * sp + lx;
+        v = (uint8_t)((1 - y) * ((1 - x) * q0[0] + x * q0[1]) + y * ((1 - x) * q0[sp] + x * q0[sp + 1]));
+      } else nOutside++;
+      tmpl[q] = (uint8_t)v;
+      sum += v; sumsq += v * v;
+    }
+    nOutside = wsum_i(nOutside);
+    cache.tsum = wsum_i(sum); cache.tsumsq = wsum_i(sumsq);
+    __builtin_amdgcn_wave_barrier();
+    bad = nOutside != 0;
+    cache.have_last = true;
+    for (int i = 0; i < 4; i++) cache.last_warp[i] = m2[i];
+  } else bad = bad_scale ? true : cache.prev_bad;
+  cache.prev_bad = bad;
+  const int tsum = cache.tsum, tsumsq = cache.tsumsq;
+  REFIND_STAMP(11);  // template
+  if (bad) { never_retry_set(m, tp, s, pid, k, lane); return false; }                                              // TemplateBad, :1004
+  // FindPatchCoarse(v2Image, k, 4), jni/PatchFinder.cc:170-235
+  const int wl = a.w[level], hl = a.h[level], ip = a.kf_pitch[level];
+  const uint8_t* img = m.kf_img[level] + ((size_t)s * K + k) * a.kf_stride[level];
+  const uint32_t* corners = m.kf_corners[level] + ((size_t)s * K + k) * tp.kcap[level];
+  const int nc = m.kf_ncorners[((size_t)s * K + k) * NLEV + level];
+  const double irx = pr.im[0] / scale, iry = pr.im[1] / scale;
+  const unsigned nRange = (4u + scale - 1) / scale;
+  int nTop = (int)(iry - nRange);
+  const int nBottomPlusOne = (int)(iry + nRange + 1);
+  const int nLeft = (int)(irx - nRange), nRight = (int)(irx + nRange);
+  if (nTop < 0) nTop = 0;
+  if (nTop >= hl || nBottomPlusOne <= 0) { never_retry_set(m, tp, s, pid, k, lane); return false; }
+  int i0, i1;
+  if (rowlut) {
+    // the new keyframe's corner list is the current frame's (k_copy_kf_corners), so the frame's row look-up table serves
+    // (two loads instead of two binary searches of dependent global loads; indices clamped to the stored list)
+    const int* lut = a.rowlut[level] + (size_t)s * (hl + 1);
+    i0 = lut[nTop]; i1 = nBottomPlusOne >= hl ? nc : lut[nBottomPlusOne];
+    if (i0 > nc) i0 = nc;
+    if (i1 > nc) i1 = nc;
+  } else {
+    // Level::vCornerRowLUT of a stored keyframe = first corner of a row: lower bound of (row << 16) in the raster-ordered list
+    auto lower = [&](int row) { int lo = 0, hi = nc; const uint32_t key = (uint32_t)row << 16; while (lo < hi) { const int mid = (lo + hi) >> 1; if (corners[mid] < key) lo = mid + 1; else hi = mid; } return lo; };
+    i0 = lower(nTop); i1 = nBottomPlusOne >= hl ? nc : lower(nBottomPlusOne);
+  }
+  int bestx = -1, besty = -1, nBest = tp.max_ssd + 1;
+  for (int base = i0; base < i1; base += 64) {
+    bool ok = false;
+    uint32_t cv = 0;
+    if (base + lane < i1) {
+      cv = corners[base + lane];
+      const int cx = cv & 0xFFFF, cy = cv >> 16;
+      const double dx = irx - cx, dy = iry - cy;
+      ok = !(cx < nLeft || cx > nRight) && !(dx * dx + dy * dy > (double)(nRange * nRange));
+    }
+    unsigned long long bm = __ballot(ok);
+    while (bm) {
+      const int kk = __ffsll((long long)bm) - 1;
+      bm &= bm - 1;
+      const uint32_t cc = __shfl(cv, kk);
+      const int cx = cc & 0xFFFF, cy = cc >> 16;
+      const int ssd = wave_zmssd<PS>(tmpl, img, ip, wl, hl, cx, cy, tsum, tsumsq, tp.max_ssd, lane);
+      if (ssd < nBest) { bestx = cx; besty = cy; nBest = ssd; }
+    }
+  }
+  REFIND_STAMP(12);  // corner search + ZMSSD
+  if (!(nBest < tp.max_ssd)) { never_retry_set(m, tp, s, pid, k, lane); return false; }                            // :1010
+  double sub0 = level_zero_pos((double)bestx, level), sub1 = level_zero_pos((double)besty, level);
+  if (level > 0) wave_subpix<PS>(tmpl, img, ip, wl, hl, level, 8, lane, sub0, sub1, slab);   // :1020-1024, convergence not looked at
+  __builtin_amdgcn_wave_barrier();
+  REFIND_STAMP(13);  // sub-pixel
+  if (lane == 0) {                                                 // :1016-1034
+    MeasDev mm;
+    mm.valid = 1; mm.level = (signed char)level; mm.subpix = level > 0; mm.source = 1 /* SRC_REFIND */; mm.pad = 0;
+    mm.root[0] = sub0; mm.root[1] = sub1;
+    cell = mm;
+    atomicAdd(&p.n_meas_kfs, 1);
+  }
+  return true;
+}
+
+// MapMaker::ReFindInSingleKeyFrame(new keyframe), jni/MapMaker.cc:1040-1056 (vslam_params.grow_map bit 1).
 // One wavefront per map point, the points of a stream strided over the grid; a point writes only its own cell of the new
 // keyframe's measurement row, so no ordering is needed.  ReFind_Common's function-static PatchFinder never sees the same
-// point twice in a row here, so its template cache never hits and every template is warped afresh (MakeTemplateCoarse,
-// jni/PatchFinder.cc:72-125: a regenerated template's own in-bounds verdict replaces the bad-scale flag of :62-65).
-// sNeverRetryKFs is not kept: its only readers are ReFindNewlyMade / ReFindFromFailureQueue, which are not built.
+// point twice in a row here, so its template cache never hits and every template is warped afresh.
 template <int PS>
 __global__ __launch_bounds__(GROW_THREADS) void k_refind(MapDev m, TrackParams tp, GrowArgs a) {
-  constexpr int HALF = PS / 2;
   const int s = blockIdx.y;
   TrackerState* st = &m.st[s];
   if (!st->kf_pending) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int K = tp.max_keyframes, P = tp.max_points;
+  const int P = tp.max_points;
   const int ksrc = st->n_kf;
   __shared__ uint8_t sh_tmpl[GROW_WAVES][128];
   __shared__ double sh_slab[GROW_WAVES][3 * (PS - 2) * (PS - 2)];
-  uint8_t* tmpl = sh_tmpl[wave];
-  const Pose Tk = m.kf_pose[(size_t)s * K + ksrc];
   const int npts = st->n_points;
 #ifdef VSLAM_BA_PROF
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_grow_prof[15] = clock64();
 #endif
   for (int pid = blockIdx.x * GROW_WAVES + wave; pid < npts; pid += gridDim.x * GROW_WAVES) {
     REFIND_STAMP(8);   // previous iteration's tail / skipped points
-    MapPointDev& p = m.pts[(size_t)s * P + pid];
-    MeasDev& cell = m.kf_meas[((size_t)s * K + ksrc) * P + pid];
-    if (p.bad || cell.valid) continue;                               // :971 (and the trash list, jni/Map.cc:16-27)
+    if (m.pts[(size_t)s * P + pid].bad) continue;                    // the trash list, jni/Map.cc:16-27
     REFIND_STAMP(9);   // point and cell loads
-    double c[3];
-    pose_xform(Tk, p.pos, c);
-    if (c[2] < 0.001) continue;                                      // :979
-    const double ip0 = c[0] / c[2], ip1 = c[1] / c[2];
-    if (ip0 * ip0 + ip1 * ip1 > tp.cam.largest_radius * tp.cam.largest_radius) continue;   // :985
-    const CamProj pr = cam_project(tp.cam, ip0, ip1);
-    if (pr.invalid) continue;                                        // :991
-    if (pr.im[0] < 0 || pr.im[1] < 0 || pr.im[0] > a.w[0] || pr.im[1] > a.h[0]) continue;   // :996
-    double d[4];
-    cam_derivs(tp.cam, pr, d);
-    // CalcSearchLevelAndWarpMatrix, jni/PatchFinder.cc:31-68
-    const double ooz = 1.0 / c[2];
-    double mr[3], md[3];
-    pose_rot(Tk, p.right, mr);
-    pose_rot(Tk, p.down, md);
-    const double r0 = mr[0] - c[0] * mr[2] * ooz, r1 = mr[1] - c[1] * mr[2] * ooz;
-    const double d0 = md[0] - c[0] * md[2] * ooz, d1 = md[1] - c[1] * md[2] * ooz;
-    const double wi[4] = {(d[0] * r0 + d[1] * r1) * ooz, (d[0] * d0 + d[1] * d1) * ooz, (d[2] * r0 + d[3] * r1) * ooz, (d[2] * d0 + d[3] * d1) * ooz};
-    double det = wi[0] * wi[3] - wi[1] * wi[2];
-    int level = 0;
-    while (det > 3 && level < NLEV - 1) { level++; det *= 0.25; }
-    const int scale = 1 << level;
-    REFIND_STAMP(10);  // projection, derivatives, warp
-    // MakeTemplateCoarseCont, :79-125: transform_image with the accumulated stepping of jni/vision/ImageHandler.cpp:21-113
-    double inv[4];
-    inv2(wi, inv);
-    const double m2[4] = {inv[0] * scale, inv[1] * scale, inv[2] * scale, inv[3] * scale};
-    int nOutside = 0, sum = 0, sumsq = 0;
-    {
-      const int sl = p.src_level;
-      const uint8_t* src = m.kf_img[sl] + ((size_t)s * K + p.src_kf) * a.kf_stride[sl];
-      const int sp = a.kf_pitch[sl], iw = a.w[sl], ih = a.h[sl];
-      const double across[2] = {m2[0], m2[2]}, down[2] = {m2[1], m2[3]};
-      double px = (double)p.irx - (m2[0] * HALF + m2[1] * HALF), py = (double)p.iry - (m2[2] * HALF + m2[3] * HALF);
-      const double cr[2] = {down[0] - PS * across[0], down[1] - PS * across[1]};
-      // one template pixel per lane (two for 11x11): the lane walks the accumulated sample position to its pixel with exactly
-      // the additions transform_image makes (whole rows with their carriage return, then steps along the row)
-      const float x_bound = (float)(iw - 1), y_bound = (float)(ih - 1);
-      const double px0 = px, py0 = py;
-      for (int q = lane; q < PS * PS; q += 64) {
-        const int r = q / PS, j = q - r * PS;
-        double x = px0, y = py0;
-#pragma unroll 1
-        for (int i = 0; i < r; i++) {
-#pragma unroll
-          for (int jj = 0; jj < PS; jj++) { x += across[0]; y += across[1]; }
-          x += cr[0]; y += cr[1];
-        }
-#pragma unroll 1
-        for (int jj = 0; jj < j; jj++) { x += across[0]; y += across[1]; }
-        int v = 0;
-        if (0 <= x && 0 <= y && x < x_bound && y < y_bound) {
-          const int lx = (int)x, ly = (int)y;
-          x -= lx; y -= ly;
-          const uint8_t* q0 = src + (size_t)ly * sp + lx;
-          v = (uint8_t)((1 - y) * ((1 - x) * q0[0] + x * q0[1]) + y * ((1 - x) * q0[sp] + x * q0[sp + 1]));
-        } else nOutside++;
-        tmpl[q] = (uint8_t)v;
-        sum += v; sumsq += v * v;
-      }
-    }
-    nOutside = wsum_i(nOutside);
-    const int tsum = wsum_i(sum), tsumsq = wsum_i(sumsq);
-    __builtin_amdgcn_wave_barrier();
-    REFIND_STAMP(11);  // template
-    if (nOutside) continue;                                          // TemplateBad, :1004
-    // FindPatchCoarse(v2Image, k, 4), jni/PatchFinder.cc:170-235
-    const int wl = a.w[level], hl = a.h[level], ip = a.kf_pitch[level];
-    const uint8_t* img = m.kf_img[level] + ((size_t)s * K + ksrc) * a.kf_stride[level];
-    const uint32_t* corners = m.kf_corners[level] + ((size_t)s * K + ksrc) * tp.kcap[level];
-    const int nc = m.kf_ncorners[((size_t)s * K + ksrc) * NLEV + level];
-    const double irx = pr.im[0] / scale, iry = pr.im[1] / scale;
-    const unsigned nRange = (4u + scale - 1) / scale;
-    int nTop = (int)(iry - nRange);
-    const int nBottomPlusOne = (int)(iry + nRange + 1);
-    const int nLeft = (int)(irx - nRange), nRight = (int)(irx + nRange);
-    if (nTop < 0) nTop = 0;
-    if (nTop >= hl || nBottomPlusOne <= 0) continue;
-    // the new keyframe's corner list is the current frame's (k_copy_kf_corners), so the frame's row look-up table serves
-    // (two loads instead of two binary searches of dependent global loads; indices clamped to the stored list)
-    const int* lut = a.rowlut[level] + (size_t)s * (hl + 1);
-    int i0 = lut[nTop], i1 = nBottomPlusOne >= hl ? nc : lut[nBottomPlusOne];
-    if (i0 > nc) i0 = nc;
-    if (i1 > nc) i1 = nc;
-    int bestx = -1, besty = -1, nBest = tp.max_ssd + 1;
-    for (int base = i0; base < i1; base += 64) {
-      bool ok = false;
-      uint32_t cv = 0;
-      if (base + lane < i1) {
-        cv = corners[base + lane];
-        const int cx = cv & 0xFFFF, cy = cv >> 16;
-        const double dx = irx - cx, dy = iry - cy;
-        ok = !(cx < nLeft || cx > nRight) && !(dx * dx + dy * dy > (double)(nRange * nRange));
-      }
-      unsigned long long bm = __ballot(ok);
-      while (bm) {
-        const int k = __ffsll((long long)bm) - 1;
-        bm &= bm - 1;
-        const uint32_t cc = __shfl(cv, k);
-        const int cx = cc & 0xFFFF, cy = cc >> 16;
-        const int ssd = wave_zmssd<PS>(tmpl, img, ip, wl, hl, cx, cy, tsum, tsumsq, tp.max_ssd, lane);
-        if (ssd < nBest) { bestx = cx; besty = cy; nBest = ssd; }
-      }
-    }
-    REFIND_STAMP(12);  // corner search + ZMSSD
-    if (!(nBest < tp.max_ssd)) continue;                             // :1010
-    double sub0 = level_zero_pos((double)bestx, level), sub1 = level_zero_pos((double)besty, level);
-    if (level > 0) wave_subpix<PS>(tmpl, img, ip, wl, hl, level, 8, lane, sub0, sub1, sh_slab[wave]);   // :1020-1024, convergence not looked at
-    __builtin_amdgcn_wave_barrier();
-    REFIND_STAMP(13);  // sub-pixel
-    if (lane == 0) {                                                 // :1016-1034
-      MeasDev mm;
-      mm.valid = 1; mm.level = (signed char)level; mm.subpix = level > 0; mm.source = 1 /* SRC_REFIND */; mm.pad = 0;
-      mm.root[0] = sub0; mm.root[1] = sub1;
-      cell = mm;
-      p.n_meas_kfs += 1;
-    }
+    RefindCache cache; cache.have_last = false; cache.prev_bad = false;
+    refind_common<PS>(m, tp, a, s, ksrc, pid, a.rowlut[0] /* non-null: k is the current frame, its row LUTs serve */, sh_tmpl[wave], sh_slab[wave], cache, lane);
   }
 }
 
+// The idle jobs of MapMaker::run that re-find measurements (vslam_params.idle_iterations), gated per stream on device:
+// mode 0  ReFindNewlyMade (jni/MapMaker.cc:1061-1081) once BundleAdjustRecent has converged: every point of the new queue (the
+//         points AddPointEpipolar made since the last pass) against every keyframe, one wavefront per point walking the
+//         keyframes in order (the PatchFinder's template cache lives across the keyframes of one point);
+// mode 1  ReFindFromFailureQueue (:1083-1096) when the gate kernel drew it: one wavefront per queued (keyframe, point).  The
+//         reference sorts the queue by address first; the entries do not interact (different points, or the same point in
+//         different keyframes whose cells and never-retry bits are disjoint), so no order is imposed here.
+template <int PS>
+__global__ __launch_bounds__(GROW_THREADS) void k_refind_idle(MapDev m, TrackParams tp, GrowArgs a, int mode) {
+  const int s = blockIdx.y;
+  TrackerState* st = &m.st[s];
+  if (!st->map_good) return;
+  if (mode == 0 ? !st->ba_converged_recent : !st->idle_do_fail) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int P = tp.max_points;
+  __shared__ uint8_t sh_tmpl[GROW_WAVES][128];
+  __shared__ double sh_slab[GROW_WAVES][3 * (PS - 2) * (PS - 2)];
+  const int nk = st->n_kf;
+  int nfound = 0;
+  if (mode == 0) {
+    for (int pid = st->newq_head + blockIdx.x * GROW_WAVES + wave; pid < st->n_points; pid += gridDim.x * GROW_WAVES) {
+      if (m.pts[(size_t)s * P + pid].bad) continue;                  // :1070-1073
+      RefindCache cache; cache.have_last = false; cache.prev_bad = false;
+      for (int k = 0; k < nk; k++) nfound += refind_common<PS>(m, tp, a, s, k, pid, nullptr, sh_tmpl[wave], sh_slab[wave], cache, lane) ? 1 : 0;
+    }
+  } else {
+    const int2* fq = m.fq + (size_t)s * tp.fq_cap;
+    const int n = st->fq_n < tp.fq_cap ? st->fq_n : tp.fq_cap;
+    for (int e = blockIdx.x * GROW_WAVES + wave; e < n; e += gridDim.x * GROW_WAVES) {
+      RefindCache cache; cache.have_last = false; cache.prev_bad = false;
+      nfound += refind_common<PS>(m, tp, a, s, fq[e].x, fq[e].y, nullptr, sh_tmpl[wave], sh_slab[wave], cache, lane) ? 1 : 0;
+    }
+  }
+  if (lane == 0 && nfound) atomicAdd(mode == 0 ? &st->n_refound_new : &st->n_refound_failed, nfound);
+}
+
+// bookkeeping around the idle re-find jobs, one lane per stream: what 0 before the failure-queue job draws the job (the reference's
+// rand() % 20 == 0, :112, as "every 20th time the condition is evaluated"); 1 after ReFindNewlyMade empties the new queue;
+// 2 after ReFindFromFailureQueue empties the failure queue.
+__global__ void k_idle_gate(MapDev m, int S, int what) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  TrackerState* st = &m.st[s];
+  if (!st->map_good) return;
+  if (what == 0) {
+    int go = 0;
+    if (st->ba_converged_recent && st->ba_converged_full) { go = (st->idle_count % 20) == 0; st->idle_count++; }
+    st->idle_do_fail = go;
+  } else if (what == 1) {
+    if (st->ba_converged_recent) st->newq_head = st->n_points;
+  } else if (st->idle_do_fail) { st->fq_n = 0; st->idle_do_fail = 0; }
+}
+
+static bool keeps_kf_corners(const vslam_system* sys) { return sys->p.grow_map != 0 || sys->p.idle_iterations != 0; }
+
 int grow_alloc(vslam_system* sys) {
-  if (!sys->p.grow_map) return VSLAM_OK;
+  sys->map.never_retry = nullptr; sys->map.fq = nullptr;
+  if (!keeps_kf_corners(sys)) return VSLAM_OK;
+  if (sys->p.idle_iterations != 0) {
+    void* q = nullptr;
+    HIPCHK(hipMalloc(&q, (size_t)sys->S * sys->p.max_points * 2 * sizeof(unsigned long long) + 64));
+    HIPCHK(hipMemsetAsync(q, 0, (size_t)sys->S * sys->p.max_points * 2 * sizeof(unsigned long long) + 64, sys->stream));
+    sys->allocs.push_back(q); sys->map.never_retry = (unsigned long long*)q;
+    q = nullptr;
+    HIPCHK(hipMalloc(&q, (size_t)sys->S * sys->tp.fq_cap * sizeof(int2) + 64));
+    sys->allocs.push_back(q); sys->map.fq = (int2*)q;
+  }
   const size_t S = sys->S, K = sys->p.max_keyframes;
   for (int l = 0; l < NLEV; l++) {
     void* ptr = nullptr;
@@ -654,7 +756,7 @@ int grow_alloc(vslam_system* sys) {
 }
 
 int grow_on_keyframe(vslam_system* sys) {
-  if (!sys->p.grow_map) return VSLAM_OK;
+  if (!keeps_kf_corners(sys)) return VSLAM_OK;
   const LevelGeom* g = sys->geom;
   hipLaunchKernelGGL(k_copy_kf_corners, dim3(NLEV, sys->S), dim3(256), 0, sys->stream, sys->map, sys->tp, sys->fr.corners[0], sys->fr.corners[1],
                      sys->fr.corners[2], sys->fr.corners[3], sys->fr.ncorners, g[0].cap, g[1].cap, g[2].cap, g[3].cap);
@@ -685,9 +787,32 @@ int grow_on_keyframe(vslam_system* sys) {
   return VSLAM_OK;
 }
 
+static void grow_args(vslam_system* sys, GrowArgs& a) {
+  const LevelGeom* g = sys->geom;
+  for (int l = 0; l < NLEV; l++) {
+    a.cand[l] = sys->cand[l]; a.cand_score[l] = sys->cand_score[l]; a.cap[l] = g[l].cap; a.w[l] = g[l].w; a.h[l] = g[l].h; a.kf_pitch[l] = g[l].pitch;
+    a.kf_stride[l] = (size_t)g[l].pitch * g[l].h; a.rowlut[l] = sys->fr.rowlut[l];
+  }
+  a.ncand = sys->ncand;
+  a.tgt_implane = sys->grow_implane; a.tgt_cap = sys->tp.kcap[0];
+}
+
+// ReFindNewlyMade (mode 0) / ReFindFromFailureQueue (mode 1) of the idle pass, with the queue bookkeeping around them
+int grow_idle_refind(vslam_system* sys, int mode) {
+  GrowArgs a;
+  grow_args(sys, a);
+  const dim3 gs((sys->S + 63) / 64), bs(64);
+  if (mode == 1) hipLaunchKernelGGL(k_idle_gate, gs, bs, 0, sys->stream, sys->map, sys->S, 0);
+  if (sys->tp.P == 8) hipLaunchKernelGGL(k_refind_idle<8>, dim3(REFIND_BLOCKS, sys->S), dim3(GROW_THREADS), 0, sys->stream, sys->map, sys->tp, a, mode);
+  else hipLaunchKernelGGL(k_refind_idle<11>, dim3(REFIND_BLOCKS, sys->S), dim3(GROW_THREADS), 0, sys->stream, sys->map, sys->tp, a, mode);
+  hipLaunchKernelGGL(k_idle_gate, gs, bs, 0, sys->stream, sys->map, sys->S, mode == 0 ? 1 : 2);
+  HIPCHK(hipGetLastError());
+  return VSLAM_OK;
+}
+
 extern "C" int vslam_get_keyframe_corners(vslam_system* sys, int stream, int keyframe, int level, uint32_t* corners, int cap, int* n) {
   if (!sys || stream < 0 || stream >= sys->S || keyframe < 0 || keyframe >= sys->p.max_keyframes || level < 0 || level >= NLEV) { vslam_set_error("get_keyframe_corners: bad argument"); return VSLAM_E_INVALID; }
-  if (!sys->p.grow_map) { vslam_set_error("get_keyframe_corners: keyframe corner lists are only kept with grow_map"); return VSLAM_E_STATE; }
+  if (!keeps_kf_corners(sys)) { vslam_set_error("get_keyframe_corners: keyframe corner lists are only kept with grow_map or idle_iterations"); return VSLAM_E_STATE; }
   HIPCHK(hipStreamSynchronize(sys->stream));
   const size_t slot = (size_t)stream * sys->p.max_keyframes + keyframe;
   int cnt = 0;

@@ -48,6 +48,7 @@ extern "C" int vslam_default_params(vslam_params* p, int width, int height, int 
   p->ba_delay_frames = 0;
   p->grow_map = 0;
   p->ba_batch_frames = 1;
+  p->idle_iterations = 0;
   return VSLAM_OK;
 }
 
@@ -67,9 +68,10 @@ extern "C" int vslam_create(const vslam_params* p, vslam_system** out) {
   if (p->width < 48 || p->height < 48 || p->width > 4096 || p->height > 4096 || p->n_streams < 1 ||
       (p->patch_size != 8 && p->patch_size != 11) || p->ba_delay_frames < 0 || p->ba_delay_frames >= 20 ||
       (p->ba_delay_frames > 0 && p->ba_delay_frames >= p->min_frames_between_kf) || p->ba_batch_frames < 0 ||
-      (p->ba_batch_frames > 1 && p->ba_batch_frames > p->ba_delay_frames)) {
-    vslam_set_error("create: unsupported parameters: size %dx%d (48..4096), streams %d (>= 1), patch %d (8 or 11), ba_delay_frames %d (0..19 and below min_frames_between_kf %d), ba_batch_frames %d (0..ba_delay_frames)",
-                    p->width, p->height, p->n_streams, p->patch_size, p->ba_delay_frames, p->min_frames_between_kf, p->ba_batch_frames);
+      (p->ba_batch_frames > 1 && p->ba_batch_frames > p->ba_delay_frames) || p->idle_iterations < -1 ||
+      (p->idle_iterations != 0 && p->ba_delay_frames > 0)) {
+    vslam_set_error("create: unsupported parameters: size %dx%d (48..4096), streams %d (>= 1), patch %d (8 or 11), ba_delay_frames %d (0..19 and below min_frames_between_kf %d), ba_batch_frames %d (0..ba_delay_frames), idle_iterations %d (>= -1, non-zero only with ba_delay_frames = 0)",
+                    p->width, p->height, p->n_streams, p->patch_size, p->ba_delay_frames, p->min_frames_between_kf, p->ba_batch_frames, p->idle_iterations);
     return VSLAM_E_INVALID;
   }
   int ndev = 0;
@@ -87,6 +89,10 @@ extern "C" int vslam_create(const vslam_params* p, vslam_system** out) {
     vslam_set_error("create: hipStreamCreate failed"); delete sys; return VSLAM_E_HIP;
   }
   const int S = sys->S;
+  {
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->device) == hipSuccess && ncu > 0) sys->n_cu = ncu;
+  }
   if (hipStreamCreateWithFlags(&sys->fe_stream, hipStreamNonBlocking) != hipSuccess) { vslam_set_error("create: hipStreamCreate failed"); vslam_destroy(sys); return VSLAM_E_HIP; }
   for (int b = 0; b < 2; b++) {
     if (hipEventCreateWithFlags(&sys->ev_fe_done[b], hipEventDisableTiming) != hipSuccess ||
@@ -136,8 +142,6 @@ extern "C" int vslam_create(const vslam_params* p, vslam_system** out) {
     }
     sys->ba_stream = sys->ba_streams[0];
     sys->frame_batch.assign((size_t)p->ba_delay_frames + 2, -1L);
-    int ncu = 0;
-    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->device) == hipSuccess && ncu > 0) sys->n_cu = ncu;
     for (int i = 0; i < p->ba_delay_frames + 2; i++) {
       hipEvent_t a = nullptr, b = nullptr;
       if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) { vslam_set_error("create: hipEventCreate failed"); vslam_destroy(sys); return VSLAM_E_HIP; }

@@ -592,7 +592,7 @@ __global__ __launch_bounds__(64) void k_subpixN(MapDev m, TrackParams tp, Search
 // k_pose: one workgroup per stream.  The tracker data of the iteration set is gathered once into a component-major
 // working set indexed by iteration-set entry (coalesced, L2 resident) and scattered back after the ten iterations;
 // entry e is always handled by thread e % POSE_THREADS, so the working set needs no synchronisation.
-#define POSE_THREADS 256
+#define POSE_THREADS 128
 // Diagnostic build only (-DVSLAM_BA_PROF, tools/build_baprof.sh): clock64() stamps of block 0 / thread 0 per phase of k_pose.
 #ifdef VSLAM_BA_PROF
 __device__ unsigned long long g_pose_prof[16];
@@ -639,9 +639,26 @@ DEVFN void item_store(const PoseItem& it, const PoseWs& w, int e, bool all) {   
 // turn (:736-768, jni/myWLS.h:39-50), every one of the 27 sums (21 of the upper triangle of C, 6 of v) a chain of
 // 2 nf dependent additions that starts from add_prior's value (:734).  fp addition does not associate, and PTAM's
 // templates are trunc(bilinear): a pose that differs in the last bit flips template pixels on flat image regions, so a
-// tree reduction would not do.  The products are formed in parallel -- four threads per measurement, 64 measurements at
-// a time, into LDS (the median's sort buffer is free by then) -- and lane q of wavefront 0 walks sum q through the chunk.
-#define POSE_CHUNK 64
+// tree reduction would not do.  The workgroup is two wavefronts: wavefront 1 PRODUCES -- one lane per measurement, both
+// add_mJ calls: weight, Jacobian, 13 doubles per call (w J[0..5], J[0..5], m) -- a chunk ahead into LDS (the median's
+// sort buffer is free by then); lane q of wavefront 0 walks sum q through the chunk, per call two LDS reads at immediate
+// offsets, one product, one dependent addition.  Four such workgroups share a CU (one chain per SIMD).
+#define POSE_CHUNK 64                 // measurements per chunk: one per producer lane
+#define POSE_REC 13                   // doubles per add_mJ call
+#define POSE_ENT 27                   // doubles per measurement in LDS: two calls + one of padding (bank spread of the producer's stores)
+#define POSE_GRP 8                    // add_mJ calls per register set of the chain (two sets alternate)
+static_assert(2 * POSE_CHUNK * POSE_ENT + (POSE_GRP / 2) * POSE_ENT <= SORT_CAP, "two record buffers (and the chain's one group of read-ahead) in the sort buffer");
+static_assert(POSE_THREADS == 128 && POSE_CHUNK == 64 && POSE_GRP % 2 == 0, "wavefront 0 chains, wavefront 1 produces");
+
+DEVFN void pose_chain_load(double (&va)[POSE_GRP], double (&vb)[POSE_GRP], const double* pa, const double* pb) {
+#pragma unroll
+  for (int u = 0; u < POSE_GRP; u++) { const int o = (u >> 1) * POSE_ENT + (u & 1) * POSE_REC; va[u] = pa[o]; vb[u] = pb[o]; }
+}
+DEVFN void pose_chain_add(double& acc, const double (&va)[POSE_GRP], const double (&vb)[POSE_GRP]) {
+#pragma unroll
+  for (int u = 0; u < POSE_GRP; u++) acc += va[u] * vb[u];
+}
+
 DEVFN void calc_pose_update(const PoseWs& ws, MapPointDev* pts, int nf, const TrackParams& tp,
                             double dOverrideSigma, bool bMarkOutliers, double* sortbuf, double* red /* [28] */,
                             double* up /* [6] */, int* hist /* [768] */, unsigned long long* sel /* [1] */) {
@@ -660,61 +677,77 @@ DEVFN void calc_pose_update(const PoseWs& ws, MapPointDev* pts, int nf, const Tr
   }
   POSE_STAMP(3);
   const bool qint = (tp.quirks & VSLAM_Q_POSE_INT_RESIDUAL) != 0;
-  double* prod = sortbuf;                                           // [POSE_CHUNK][2 rows][27]
-  const int le = threadIdx.x >> 2, part = threadIdx.x & 3, row = part >> 1, half = part & 1;
+  const int nchunks = (nf + POSE_CHUNK - 1) / POSE_CHUNK;
+  constexpr int BUF = POSE_CHUNK * POSE_ENT;
+  const bool producer = wave == 1;
   // sum q of the chain: upper triangle of C row by row (0..20), then v (21..26); the diagonal starts at the prior
   double acc = 0.0;
-  if (lane == 0 || lane == 6 || lane == 11 || lane == 15 || lane == 18 || lane == 20) acc = 0.0 + tp.wls_prior;   // add_prior, :734
-  PoseItem nx;
-  item_load(nx, ws, le < nf ? le : nf - 1);
-  for (int c0 = 0; c0 < nf; c0 += POSE_CHUNK) {
-    const PoseItem t = nx;
-    const int e = c0 + le;
-    { const int en = e + POSE_CHUNK; item_load(nx, ws, en < nf ? en : nf - 1); }   // the next chunk's operands travel during this chunk's chain
-    __syncthreads();                                                // the chain of the previous chunk has left `prod` (first trip: the median has left sortbuf)
+  int ia = 0, ib = 0;                                               // this lane's two operands inside a record
+  {
+    int q = 0;
+    for (int r = 0; r < 6; r++) for (int c = r; c < 6; c++) { if (q == lane) { ia = r; ib = 6 + c; } q++; }
+    if (lane >= 21 && lane < 27) { ia = 12; ib = lane - 21; }
+    if (lane == 0 || lane == 6 || lane == 11 || lane == 15 || lane == 18 || lane == 20) acc = 0.0 + tp.wls_prior;   // add_prior, :734
+  }
+  // one measurement -> its two records; a measurement past the end, or one the reference skips (weight 0), is zeros: x + 0 * 0 = x
+  auto produce = [&](const PoseItem& t, int e, double* buf) {
+    double* dst = buf + lane * POSE_ENT;
+    double w = 0.0, err[2] = {0.0, 0.0};
     if (e < nf) {
-      const double err[2] = {(t.vfound[0] - t.image[0]) * t.sqrt_inv_noise, (t.vfound[1] - t.image[1]) * t.sqrt_inv_noise};
+      err[0] = (t.vfound[0] - t.image[0]) * t.sqrt_inv_noise; err[1] = (t.vfound[1] - t.image[1]) * t.sqrt_inv_noise;
       const double es = err[0] * err[0] + err[1] * err[1];
-      const double w = tukey_weight(es, sigma2);
-      if (bMarkOutliers && part == 0) { if (w == 0.0) pts[t.idx].n_out++; else pts[t.idx].n_in++; }   // :749-756
-      double pr[27];
-      if (w == 0.0) {
+      w = tukey_weight(es, sigma2);
+      if (bMarkOutliers) { if (w == 0.0) pts[t.idx].n_out++; else pts[t.idx].n_in++; }   // :749-756
+    }
+    if (w == 0.0) {
 #pragma unroll
-        for (int q = 0; q < 27; q++) pr[q] = 0.0;                   // the reference skips the measurement: x + 0 = x
-      } else {
-        double jac[12];
-        td_calc_jacobian(t, jac);                                    // CalcJacobian, jni/TrackerData.h:107-122
-        const double mm = qint ? (double)(int)err[row] : err[row];  // wls.add_mJ(v2(row), J.row(row), w), :766-767
-        double J[6];
+      for (int k = 0; k < 2 * POSE_REC; k++) dst[k] = 0.0;
+      return;
+    }
+    double jac[12];
+    td_calc_jacobian(t, jac);                                        // CalcJacobian, jni/TrackerData.h:107-122
 #pragma unroll
-        for (int k = 0; k < 6; k++) J[k] = t.sqrt_inv_noise * (row ? jac[6 + k] : jac[k]);
-        int q = 0;
+    for (int row = 0; row < 2; row++) {
 #pragma unroll
-        for (int r = 0; r < 6; r++) {
-          const double Jw = w * J[r];
-          pr[21 + r] = mm * Jw;
-#pragma unroll
-          for (int c = r; c < 6; c++) pr[q++] = Jw * J[c];
-        }
+      for (int k = 0; k < 6; k++) {
+        const double J = t.sqrt_inv_noise * jac[6 * row + k];        // wls.add_mJ(v2(row), sqrt_inv_noise * J.row(row), w), :760-767
+        dst[row * POSE_REC + k] = w * J; dst[row * POSE_REC + 6 + k] = J;
       }
-      double* dst = prod + (le * 2 + row) * 27;
-#pragma unroll
-      for (int q = 0; q < 27; q++) if ((q < 14) == (half == 0)) dst[q] = pr[q];
+      dst[row * POSE_REC + 12] = qint ? (double)(int)err[row] : err[row];
+    }
+  };
+  PoseItem cur, nx;
+  if (producer) {
+    item_load(cur, ws, lane < nf ? lane : nf - 1);
+    item_load(nx, ws, POSE_CHUNK + lane < nf ? POSE_CHUNK + lane : nf - 1);
+  }
+  __syncthreads();                                                  // the median has left the sort buffer
+  if (producer) produce(cur, lane, sortbuf);
+  __syncthreads();
+  for (int k = 0; k < nchunks; k++) {
+    if (producer) {
+      if (k + 1 < nchunks) {
+        cur = nx;
+        const int e2 = (k + 2) * POSE_CHUNK + lane;
+        item_load(nx, ws, e2 < nf ? e2 : nf - 1);
+        produce(cur, (k + 1) * POSE_CHUNK + lane, sortbuf + ((k + 1) & 1) * BUF);
+      }
+    } else {
+      const int left = nf - k * POSE_CHUNK;
+      const int ng = (2 * (left < POSE_CHUNK ? left : POSE_CHUNK) + POSE_GRP - 1) / POSE_GRP;    // groups of calls in this chunk (the tail is zero records)
+      constexpr int GSTR = (POSE_GRP / 2) * POSE_ENT;
+      const double* pa = sortbuf + (k & 1) * BUF + ia;
+      const double* pb = sortbuf + (k & 1) * BUF + ib;
+      double a0[POSE_GRP], b0[POSE_GRP], a1[POSE_GRP], b1[POSE_GRP];
+      pose_chain_load(a0, b0, pa, pb);
+      for (int g = 0; g < ng; g += 2) {                              // the read-ahead past the last group stays inside the sort buffer
+        pose_chain_load(a1, b1, pa + (g + 1) * GSTR, pb + (g + 1) * GSTR);
+        pose_chain_add(acc, a0, b0);
+        pose_chain_load(a0, b0, pa + (g + 2) * GSTR, pb + (g + 2) * GSTR);
+        if (g + 1 < ng) pose_chain_add(acc, a1, b1);
+      }
     }
     __syncthreads();
-    if (wave == 0 && lane < 27) {
-      const int cnt2 = 2 * (nf - c0 < POSE_CHUNK ? nf - c0 : POSE_CHUNK);      // rows of this chunk
-      const double* pp = prod + lane;
-      int k = 0;
-      for (; k + 8 <= cnt2; k += 8) {                               // the LDS reads of 8 rows are in flight ahead of the dependent additions
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = pp[(k + u) * 27];
-#pragma unroll
-        for (int u = 0; u < 8; u++) acc += v[u];
-      }
-      for (; k < cnt2; k++) acc += pp[k * 27];
-    }
   }
   POSE_STAMP(4);
   if (wave == 0 && lane < 27) red[lane] = acc;
@@ -1041,6 +1074,7 @@ void trk_fill_params(const vslam_params& p, TrackParams& t) {
   t.quirks = p.quirks; t.max_points = p.max_points; t.max_keyframes = p.max_keyframes; t.ba_delay = p.ba_delay_frames;
   t.ba_batch = p.ba_batch_frames > 1 ? p.ba_batch_frames : 1;
   t.grow_map = p.grow_map;
+  t.idle = p.idle_iterations != 0; t.fq_cap = 8192;
   {                                                                  // ATANCamera::OnePixelDist, jni/ATANCamera.cc:86-91
     double a[2], b[2];
     cam_unproject(t.cam, t.cam.size[0] / 2, t.cam.size[1] / 2, a);

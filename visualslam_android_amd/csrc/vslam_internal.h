@@ -98,6 +98,12 @@ struct TrackerState {       // Tracker members, jni/Tracker.h:77-150 (+ MapMaker
   int ba_accepted, kf_added, ba_converged_recent, ba_converged_full;
   int ba_countdown;         // > 0: a bundle adjustment is in flight, its results are applied when this reaches 0
   unsigned long long n_zmssd, n_ba_trials;
+  // the map-maker's idle jobs (vslam_params.idle_iterations)
+  int newq_head;            // mqNewQueue = the points [newq_head, n_points): made by AddPointEpipolar, not yet seen by ReFindNewlyMade
+  int fq_n;                 // mvFailureQueue length
+  int idle_count;           // evaluations of the lowest-priority job's condition (rand() % 20 == 0 made deterministic: every 20th)
+  int idle_do_fail;         // this pass runs ReFindFromFailureQueue
+  int n_refound_new, n_refound_failed, n_ba_all, n_ba_recent_idle;   // statistics
 };
 
 struct TrackParams {        // device copy of the tunables the kernels read
@@ -113,6 +119,8 @@ struct TrackParams {        // device copy of the tunables the kernels read
   int ba_delay;             // vslam_params.ba_delay_frames
   int ba_batch;             // vslam_params.ba_batch_frames (>= 1)
   int grow_map;             // vslam_params.grow_map
+  int idle;                 // vslam_params.idle_iterations
+  int fq_cap;               // capacity of a stream's failure queue
   double one_pixel_dist;    // ATANCamera::OnePixelDist, jni/ATANCamera.cc:86-91
   int kcap[NLEV];           // capacity of a keyframe's stored corner list per level (grow_map)
 };
@@ -129,6 +137,8 @@ struct MapDev {             // device pointers of the map + tracker of all strea
   uint8_t* kf_img[NLEV];    // [S][max_keyframes][h*pitch]
   uint32_t* kf_corners[NLEV];   // [S][max_keyframes][kcap_l]  Level::vCorners of the keyframes (grow_map only: epipolar search)
   int* kf_ncorners;         // [S][max_keyframes][NLEV]
+  unsigned long long* never_retry;   // [S][max_points][2]  MapMakerData::sNeverRetryKFs as a bit set over the keyframes (idle jobs only)
+  int2* fq;                 // [S][fq_cap]  mvFailureQueue: (keyframe, point)
   TrackerState* st;         // [S]
   int* pvs_list;            // [S][NLEV][max_points]
   int2* search_list;        // [S][max_points]  (point index, sub-pixel iterations)
@@ -200,6 +210,9 @@ int fe_keyframe_rest_gated(vslam_system* sys);               // non-max + candid
 int fe_thin_new_keyframe(vslam_system* sys, int level);      // ThinCandidates(new keyframe, level) for the streams with kf_pending
 int grow_alloc(vslam_system* sys);
 int grow_on_keyframe(vslam_system* sys);                      // AddSomeMapPoints(3, 0, 1, 2) for the streams with kf_pending
+int grow_idle_refind(vslam_system* sys, int mode);            // idle jobs: 0 ReFindNewlyMade, 1 ReFindFromFailureQueue (gated per stream on device)
+int mm_idle(vslam_system* sys);
+int mm_idle_job(vslam_system* sys, int job);                               // vslam_params.idle_iterations passes through MapMaker::run's idle jobs
 int fe_sbi(vslam_system* sys, const FrameDev& last);   // k_sbi on the front-end stream: this frame's SBI + rotation prior against `last`
 void cam_fill(CamModel& c, const double cam5[5], double width, double height, int quirks);
 int fe_make_keyframe_rest(vslam_system* sys, double min_score);
