@@ -16,7 +16,7 @@ lib.vslam_debug_ba_prof(out,1)
 g.track_frame(np.stack([frames[0]]*S))
 lib.vslam_debug_ba_prof(out,1)
 st=g.state(0)
-names=['init','pass1_project','radix_sigma','pass2_ABW','V_accum','U_accum','Vinv_Szero','S_tasks','solve','mapupd_camnew','find_new_err','commit','erase']
+names=['layout','find_err_uncached','radix_sigma','sweep_free(+U merge)','sweep_fixed','U_generic','-','schur','solve','map_update+cam_new','find_new_error','commit','erase_outliers']
 tot=sum(out[i] for i in range(13))
 print('S',S,'ba_accepted',st.ba_accepted,'trials',st.n_ba_trials,'kf',st.n_keyframes, 'total Mcycles %.2f'%(tot/1e6))
 for i,n in enumerate(names): print('%-16s %8.1f kcyc %5.1f%%'%(n,out[i]/1e3,100.0*out[i]/tot))

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Occupancy of the timed region of a bench.py run from a rocprofv3 kernel_trace csv: the window is the last --steps launches of
+k_pose with the batched grid; per kernel the summed duration inside the window, and per queue the busy time.
+
+usage: timeline.py <kernel_trace.csv> --steps 20 --min-grid 512"""
+import csv, sys, argparse, collections
+ap = argparse.ArgumentParser()
+ap.add_argument("file"); ap.add_argument("--steps", type=int, default=20); ap.add_argument("--min-grid", type=int, default=512)
+a = ap.parse_args()
+rows = []
+with open(a.file, newline="") as fh:
+    for r in csv.DictReader(fh):
+        g = 1
+        for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"):
+            try: g *= max(1, int(float(r.get(k, 1) or 1)))
+            except ValueError: pass
+        if r.get("Grid_Size"): g = int(float(r["Grid_Size"]))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0], r.get("Queue_Id", "?"), g))
+rows.sort()
+poses = [x for x in rows if x[2].startswith("k_pose") and x[4] >= a.min_grid]
+# two k_pose launches per step at most (coarse + fine); take the window covering the last `steps` fine launches = every launch
+ends = [x[1] for x in poses]
+per = 2 if len(poses) >= 2 * a.steps + 2 and (poses[-1][0] - poses[-2][0]) < (poses[-2][0] - poses[-3][0]) else 1
+first = poses[-a.steps * per - 1][1] if len(poses) > a.steps * per else rows[0][0]
+t0, t1 = first, poses[-1][1]
+print("window %.3f ms, %d steps -> %.3f ms/step" % ((t1 - t0) / 1e6, a.steps, (t1 - t0) / 1e6 / a.steps))
+acc = collections.defaultdict(lambda: [0, 0]); q = collections.defaultdict(list)
+ev = []
+for s, e, n, qu, g in rows:
+    s2, e2 = max(s, t0), min(e, t1)
+    if e2 <= s2: continue
+    acc[n][0] += e2 - s2; acc[n][1] += 1; q[qu].append((s2, e2)); ev.append((s2, 1)); ev.append((e2, -1))
+ev.sort()
+busy = 0; depth = 0; last = t0; hist = collections.defaultdict(int)
+for t, d in ev:
+    if depth > 0: busy += t - last
+    hist[depth] += t - last
+    depth += d; last = t
+hist[0] += t1 - last
+print("some kernel running: %.1f %% of the window; concurrency histogram (kernels in flight: %% of time): %s" % (100.0 * busy / (t1 - t0), {k: round(100.0 * v / (t1 - t0), 1) for k, v in sorted(hist.items())}))
+tot = sum(v[0] for v in acc.values())
+print("sum of kernel durations / window = %.2f" % (tot / (t1 - t0)))
+for n, (d, c) in sorted(acc.items(), key=lambda kv: -kv[1][0]):
+    print("%-44s %6d launches %9.3f ms/step %6.1f %% of window" % (n[:44], c, d / 1e6 / a.steps, 100.0 * d / (t1 - t0)))
+for qu, iv in q.items():
+    print("queue %s busy %.1f %%" % (qu, 100.0 * sum(e - s for s, e in iv) / (t1 - t0)))

@@ -16,6 +16,7 @@
 //                 MapMaker::ThinCandidates (jni/MapMaker.cc:393-422), ordered block compaction.
 #include "vslam_internal.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 #define BAND 16          // level-0 rows per workgroup (multiple of 8: three halvings stay inside a band)
 #define HALO 3           // FAST ring radius (cvfast.cpp:6094-6111)
@@ -230,6 +231,230 @@ __global__ __launch_bounds__(FE_THREADS) void k_fast_lvl(FeArgs a) {
   const int nrows = min(BAND, a.h[l] - y0);
   fast_band(t, lp, y0, nrows, a.w[l], a.h[l], a.thr[l], a.nchunk[l],
             a.cmask[l] + (size_t)s * a.h[l] * a.nchunk[l], a.rowcnt[l] + (size_t)s * a.h[l], mask_lds, cand, ncand);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same FAST-10 sweep WITHOUT staging the image in LDS (the form used whenever the level widths are multiples of 4 and
+// the input is 16-B aligned; the band kernels above stay as the general path).  One lane owns a strip 16 pixels wide and
+// SL_R rows tall and walks down it: one 16-B global load per row, a sliding window of seven rows in registers -- the centre
+// row's neighbours 3 to the left / right come from the neighbouring lanes' registers (wave shuffles; the two edge lanes of a
+// wavefront load one extra dword), the pixels 3 above / below are the window's first and last row -- so the quick reject
+// reads nothing but registers (it was LDS-issue bound).  Level 0 also produces its share of levels
+// 1..3 from the same registers (2x2 sums by v_perm + v_sad_u8) with lane-contiguous stores.
+// Quick reject (cvfast.cpp:6088-9241 as a filter): ten contiguous ring pixels contain two ADJACENT compass pixels
+// (0, 4, 8, 12), so a corner has such a pair both brighter than c + t or both darker than c - t.  ~2 % of the pixels of the
+// feeder's frames pass (0.4 % are corners).  Every seven rows a wavefront compacts its survivors (prefix sum of the lanes'
+// bit counts) into its own LDS list and runs the full 16-pixel run-of-10 test on them with dense lanes, the ring read back
+// through L1/L2 as aligned dwords; corners are OR-ed into the workgroup's mask words in LDS, which leave with coalesced
+// stores together with the row counts.  A workgroup owns 256 / (w / 16) whole strips-rows ("bands") of consecutive frames.
+#define SL_RMAX 64         // most rows of a strip; the height R (a multiple of 8: the three halvings stay inside a strip) is chosen per launch
+#define SL_THREADS 256
+#define SL_CAP 1024        // entries of a wavefront's candidate list (one row of a wavefront: 64 lanes x 16 pixels)
+
+struct SlArgs {
+  int w16[NLEV], nb[NLEV], bpw[NLEV], wg_first[NLEV + 1];   // strips per row, bands per frame, bands per workgroup, first workgroup of a level
+  int R[NLEV];                                              // rows of a strip
+  int S;
+};
+
+// sum of the 2x2 block (wa byte k, k+1; wb byte k, k+1) + 2, >> 2, for k = 0 and k = 2 -> two output pixels in bits 0..15
+DEVFN unsigned sl_half2(unsigned wa, unsigned wb) {
+  const unsigned q0 = __builtin_amdgcn_perm(wb, wa, 0x05040100u), q1 = __builtin_amdgcn_perm(wb, wa, 0x07060302u);
+  return (__builtin_amdgcn_sad_u8(q0, 0u, 2u) >> 2) | ((__builtin_amdgcn_sad_u8(q1, 0u, 2u) >> 2) << 8);
+}
+DEVFN unsigned sl_half4(unsigned a0, unsigned a1, unsigned b0, unsigned b1) { return sl_half2(a0, b0) | (sl_half2(a1, b1) << 16); }
+
+// full segment test of pixel (x, y) of an image read through the caches: per ring row the aligned dwords around x - 3
+DEVFN bool sl_full_test(const uint8_t* img, int pitch, int w, int x, int y, int thr) {
+  const int xb = (x - 3) & ~3, o = (x - 3) & 3;
+  const int x2 = min(xb + 8, w - 4);                                 // the third dword is only needed (and then inside the row) when o >= 2
+  unsigned A[7], B[7];
+  const uint8_t* r = img + (size_t)(y - 3) * pitch;
+#pragma unroll
+  for (int k = 0; k < 7; k++) {
+    const uint2 v = *(const uint2*)(r + xb);
+    const unsigned t = *(const unsigned*)(r + x2);
+    A[k] = __builtin_amdgcn_alignbyte(v.y, v.x, o);                  // pixels x-3 .. x
+    B[k] = __builtin_amdgcn_alignbyte(t, v.y, o);                    // pixels x+1 .. x+4
+    r += pitch;
+  }
+  const int c = (A[3] >> 24) & 255u, cb = c + thr, c_b = c - thr;
+  unsigned mb = 0, md = 0;                                          // ring pixel k -> bit k: the sign bits of cb - v / v - c_b are shifted in, k = 15 first
+#define SLPIX(k, dx, dy) { const int v = (int)(((dx) <= 0 ? (A[(dy) + 3] >> (8 * ((dx) + 3))) : (B[(dy) + 3] >> (8 * ((dx) - 1)))) & 255u); mb = __builtin_amdgcn_alignbit(mb, (unsigned)(cb - v), 31); md = __builtin_amdgcn_alignbit(md, (unsigned)(v - c_b), 31); }
+  SLPIX(15, -1, 3) SLPIX(14, -2, 2) SLPIX(13, -3, 1) SLPIX(12, -3, 0) SLPIX(11, -3, -1) SLPIX(10, -2, -2)
+  SLPIX(9, -1, -3) SLPIX(8, 0, -3) SLPIX(7, 1, -3) SLPIX(6, 2, -2) SLPIX(5, 3, -1) SLPIX(4, 3, 0)
+  SLPIX(3, 3, 1) SLPIX(2, 2, 2) SLPIX(1, 1, 3) SLPIX(0, 0, 3)
+#undef SLPIX
+  return ring_run10(mb) || ring_run10(md);
+}
+
+template <bool PYR>
+__global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fast_slide(FeArgs a, SlArgs q) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  int l = 0;
+  if (!PYR) { l = 1; if ((int)blockIdx.x >= q.wg_first[2]) l = 2; if ((int)blockIdx.x >= q.wg_first[3]) l = 3; }
+  const int wg = (int)blockIdx.x - (PYR ? 0 : q.wg_first[l]);
+  const int w = a.w[l], h = a.h[l], nchunk = a.nchunk[l], thr = a.thr[l];
+  const int W16 = q.w16[l], nb = q.nb[l], bpw = q.bpw[l], SL_R = q.R[l], SL_NSTEP = SL_R + 2 * HALO;
+  const uint8_t* img = PYR ? a.in : a.lvl[l];
+  const size_t sstride = PYR ? a.in_sstride : a.lvl_sstride[l];
+  const int pitch = PYR ? a.in_pitch : a.lvl_pitch[l];
+  int4* tb = (int4*)lds;                                             // per thread: stream, first row, first column, band of the workgroup
+  unsigned short* lists = (unsigned short*)(tb + SL_THREADS);
+  unsigned long long* mask = (unsigned long long*)(lists + (SL_THREADS / 64) * SL_CAP);   // [bpw][R][nchunk]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned short* list = lists + wave * SL_CAP;
+  const int bl = tid / W16, cg = tid - bl * W16;
+  const long gband = (long)wg * bpw + bl;
+  const bool active = bl < bpw && gband < (long)q.S * nb;
+  const int s = active ? (int)(gband / nb) : 0, b = active ? (int)(gband - (long)s * nb) : 0;
+  const int yb = b * SL_R, x0 = cg * 16;
+  tb[tid] = make_int4(s, yb, x0, active ? bl : -1);
+  for (int i = tid; i < bpw * SL_R * nchunk; i += SL_THREADS) mask[i] = 0ull;
+  __syncthreads();
+  const uint8_t* base = img + (size_t)s * sstride + x0;
+  unsigned xvalid = 0;                                               // columns of the strip FAST runs on (cvfast.cpp:6113-6117)
+  for (int j = 0; j < 16; j++) if (x0 + j >= HALO && x0 + j < w - HALO) xvalid |= 1u << j;
+  if (!active) xvalid = 0;
+  const bool eL = active && lane == 0 && cg > 0, eR = active && lane == 63 && cg < W16 - 1;
+
+  auto load_row = [&](int i, uint4& v, unsigned& vl, unsigned& vr) {  // row step i of the strip: image row yb - 3 + i
+    const int y = yb - HALO + i;
+    v = make_uint4(0, 0, 0, 0); vl = 0; vr = 0;
+    if (active && i < SL_NSTEP && y >= 0 && y < h) {
+      const uint8_t* p = base + (size_t)y * pitch;
+      v = *(const uint4*)p;
+      if (eL) vl = *(const unsigned*)(p - 4);
+      if (eR) vr = *(const unsigned*)(p + 16);
+    }
+  };
+  unsigned W[7][6];                                                  // the window: slot = row step % 7; [0] left neighbour dword, [1..4] own, [5] right
+#pragma unroll
+  for (int u = 0; u < 7; u++)
+#pragma unroll
+    for (int k = 0; k < 6; k++) W[u][k] = 0;
+  uint4 pf0, pf1; unsigned pl0, pr0, pl1, pr1;
+  load_row(0, pf0, pl0, pr0);
+  load_row(1, pf1, pl1, pr1);
+  unsigned l1p[2] = {0, 0}, l2p = 0;                                 // pyramid pieces waiting for their second row
+
+  for (int i0 = 0; i0 < SL_NSTEP; i0 += 7) {
+    unsigned pw[4] = {0, 0, 0, 0};                                   // quick-reject survivors of this round: 16 bits per row
+#pragma unroll
+    for (int u = 0; u < 7; u++) {
+      const int i = i0 + u;
+      if (i >= SL_NSTEP) continue;
+      const uint4 cur = pf0; const unsigned cl = pl0, cr = pr0;
+      pf0 = pf1; pl0 = pl1; pr0 = pr1;
+      load_row(i + 2, pf1, pl1, pr1);
+      unsigned nl = __shfl_up(cur.w, 1), nr = __shfl_down(cur.x, 1);
+      if (lane == 0) nl = cl;
+      if (lane == 63) nr = cr;
+      W[u][0] = nl; W[u][1] = cur.x; W[u][2] = cur.y; W[u][3] = cur.z; W[u][4] = cur.w; W[u][5] = nr;
+      if (PYR) {                                                     // jni/KeyFrame.cc:19-23 (2:1 area filter)
+        const int rb = i - HALO, y = yb + rb;                        // row of the band
+        if (active && rb >= 0 && rb < SL_R && y < h && (rb & 1)) {
+          const int up = (u + 6) % 7;
+          const unsigned o0 = sl_half4(W[up][1], W[up][2], W[u][1], W[u][2]), o1 = sl_half4(W[up][3], W[up][4], W[u][3], W[u][4]);
+          if ((y >> 1) < a.h[1]) *(uint2*)(a.lvl[1] + (size_t)s * a.lvl_sstride[1] + (size_t)(y >> 1) * a.lvl_pitch[1] + cg * 8) = make_uint2(o0, o1);
+          if ((rb & 3) == 3) {
+            const unsigned o2 = sl_half4(l1p[0], l1p[1], o0, o1);
+            if ((y >> 2) < a.h[2]) *(unsigned*)(a.lvl[2] + (size_t)s * a.lvl_sstride[2] + (size_t)(y >> 2) * a.lvl_pitch[2] + cg * 4) = o2;
+            if ((rb & 7) == 7) {
+              if ((y >> 3) < a.h[3]) *(unsigned short*)(a.lvl[3] + (size_t)s * a.lvl_sstride[3] + (size_t)(y >> 3) * a.lvl_pitch[3] + cg * 2) = (unsigned short)sl_half2(l2p, o2);
+            } else l2p = o2;
+          } else { l1p[0] = o0; l1p[1] = o1; }
+        }
+      }
+      // quick reject on the centre row (row step i - 3 = slot (u + 4) % 7): band row rel = i - 6
+      const int rel = i - 2 * HALO, yc = yb + rel;
+      if (rel >= 0 && yc >= HALO && yc < h - HALO) {                  // uniform but for yc (per band)
+        const int sc = (u + 4) % 7, sd = (u + 1) % 7;             // centre, row y - 3; row y + 3 is slot u
+        // branch-free: a pair of adjacent compass pixels both above c + t  <=>  min(max(p0, p8), max(p4, p12)) - c > t, both
+        // below c - t  <=>  c - max(min(p0, p8), min(p4, p12)) > t; the sign of t - max(...) is shifted into the row's bit word
+        unsigned pass = 0;
+#pragma unroll
+        for (int d = 3; d >= 0; d--) {
+          const unsigned cw = W[sc][1 + d], uw = W[u][1 + d], dw = W[sd][1 + d];
+          const unsigned p12w = __builtin_amdgcn_alignbyte(cw, W[sc][d], 1);        // pixels x-3 .. x
+          const unsigned p4w = __builtin_amdgcn_alignbyte(W[sc][2 + d], cw, 3);     // pixels x+3 .. x+6
+#pragma unroll
+          for (int j = 3; j >= 0; j--) {
+            const int c = (cw >> (8 * j)) & 255u;
+            const int p0 = (uw >> (8 * j)) & 255u, p8 = (dw >> (8 * j)) & 255u;
+            const int p4 = (p4w >> (8 * j)) & 255u, p12 = (p12w >> (8 * j)) & 255u;
+            const int bm = min(max(p0, p8), max(p4, p12)), dm = max(min(p0, p8), min(p4, p12));
+            const int v = max(bm - c, c - dm);
+            pass = __builtin_amdgcn_alignbit(pass, (unsigned)(thr - v), 31);
+          }
+        }
+        pass &= xvalid;
+        pw[u >> 1] |= pass << (16 * (u & 1));
+      }
+    }
+    // ---- the round's survivors: compact per wavefront, full test on dense lanes ----
+    const int relg = i0 - 2 * HALO;                                  // band row of the round's slot 0
+    int cnt = __popc(pw[0]) + __popc(pw[1]) + __popc(pw[2]) + __popc(pw[3]);
+    int tot = cnt;
+    for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d);
+#ifdef VSLAM_SL_SKIP_FLUSH
+    if (tot != 123456) continue;
+#endif
+    if (tot == 0) continue;
+    const int nsub = tot <= SL_CAP ? 1 : 7;                          // a round that overflows the list goes row by row
+    for (int sub = 0; sub < nsub; sub++) {
+      unsigned m4[4] = {pw[0], pw[1], pw[2], pw[3]};
+      if (nsub > 1) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) m4[k] = (sub >> 1) == k ? (pw[k] & (0xFFFFu << (16 * (sub & 1)))) : 0u;
+      }
+      const int c4 = __popc(m4[0]) + __popc(m4[1]) + __popc(m4[2]) + __popc(m4[3]);
+      int inc = c4;
+      for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+      const int n = __shfl(inc, 63);
+      int pos = inc - c4;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        unsigned m = m4[k];
+        while (m) {
+          const int bit = __ffs((int)m) - 1;
+          list[pos++] = (unsigned short)((lane << 7) | (k * 32 + bit));
+          m &= m - 1;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int k = lane; k < n; k += 64) {
+        const int e = list[k];
+        const int4 t = tb[wave * 64 + (e >> 7)];
+        const int rr = relg + ((e >> 4) & 7), x = t.z + (e & 15), y = t.y + rr;
+#ifdef VSLAM_SL_SKIP_FULL
+        if (x == 7 && y == 7)
+#else
+        if (sl_full_test(img + (size_t)t.x * sstride, pitch, w, x, y, thr))
+#endif
+          atomicOr(&mask[((size_t)t.w * SL_R + rr) * nchunk + (x >> 6)], 1ull << (x & 63));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+  // masks and row counts of the workgroup's bands
+  const int per = SL_R * nchunk;
+  for (int i = tid; i < bpw * per; i += SL_THREADS) {
+    const int bb = i / per, rem = i - bb * per, row = rem / nchunk, c = rem - row * nchunk;
+    const int4 t = tb[bb * W16];
+    if (t.w >= 0 && t.y + row < h) a.cmask[l][((size_t)t.x * h + t.y + row) * nchunk + c] = mask[i];
+  }
+  for (int i = tid; i < bpw * SL_R; i += SL_THREADS) {
+    const int bb = i / SL_R, row = i - bb * SL_R;
+    const int4 t = tb[bb * W16];
+    if (t.w < 0 || t.y + row >= h) continue;
+    int c = 0;
+    for (int k = 0; k < nchunk; k++) c += __popcll(mask[(size_t)i * nchunk + k]);
+    a.rowcnt[l][(size_t)t.x * h + t.y + row] = c;
+  }
 }
 
 // Raster-ordered corner lists + row LUT from the corner bit-masks, one workgroup per (band of 16 rows, level, stream): the
@@ -531,6 +756,55 @@ static void fill_fe_args(vslam_system* sys, FeArgs& a) {
   a.overflow = sys->fr.overflow;
 }
 
+// the strip form applies when every level is a multiple of 4 wide and at most 4096, and the level-0 input can be read 16 B at a time
+static bool fe_slide_ok(const vslam_system* sys, const FeArgs& a) {
+  static const bool off = getenv("VSLAM_FE_BANDS") != nullptr;        // diagnostic: force the band kernels
+  if (off) return false;
+  for (int l = 0; l < NLEV; l++) if ((a.w[l] & 3) || a.w[l] < 16 || a.w[l] > 4096 || a.h[l] < 7) return false;
+  return (((uintptr_t)a.in) & 15) == 0 && (a.in_pitch & 15) == 0 && (a.in_sstride & 15) == 0 && a.in_pitch >= ((a.w[0] + 15) & ~15);
+}
+static void fe_launch_slide(vslam_system* sys, FeArgs& a, hipStream_t fs, int S) {
+  SlArgs q;
+  q.S = S;
+  int nwg[NLEV];
+  size_t lds[NLEV];
+  const long slots = 4L * (sys->n_cu > 0 ? sys->n_cu : 256);          // workgroups the device holds at once (four per CU)
+  for (int l = 0; l < NLEV; l++) { q.w16[l] = (a.w[l] + 15) >> 4; q.bpw[l] = SL_THREADS / q.w16[l]; }
+  // strip height per launch (level 0; levels 1..3): the one that costs the fewest row steps, rounds of resident workgroups x (R + halo)
+  auto pick = [&](int l0, int l1) {
+    long best = -1; int bestR = 32;
+    for (int R = 16; R <= SL_RMAX; R += 8) {
+      long wgs = 0;
+      bool fits = true;                                                // 64 KB of dynamic LDS
+      for (int l = l0; l <= l1; l++) {
+        wgs += ((long)S * ((a.h[l] + R - 1) / R) + q.bpw[l] - 1) / q.bpw[l];
+        if ((size_t)SL_THREADS * 16 + (size_t)(SL_THREADS / 64) * SL_CAP * 2 + (size_t)q.bpw[l] * R * a.nchunk[l] * 8 > 60000) fits = false;
+      }
+      if (!fits && R > 16) continue;
+      const long cost = ((wgs + slots - 1) / slots) * (R + 2 * HALO);
+      if (best < 0 || cost < best) { best = cost; bestR = R; }
+    }
+    for (int l = l0; l <= l1; l++) q.R[l] = bestR;
+  };
+  pick(0, 0);
+  pick(1, NLEV - 1);
+  for (int l = 0; l < NLEV; l++) {
+    q.nb[l] = (a.h[l] + q.R[l] - 1) / q.R[l];
+    nwg[l] = (int)(((long)S * q.nb[l] + q.bpw[l] - 1) / q.bpw[l]);
+    lds[l] = (size_t)SL_THREADS * 16 + (size_t)(SL_THREADS / 64) * SL_CAP * 2 + (size_t)q.bpw[l] * q.R[l] * a.nchunk[l] * 8;
+  }
+  static const bool dbg = getenv("VSLAM_FE_DEBUG") != nullptr;
+  if (dbg) fprintf(stderr, "fe slide: S %d n_cu %d R %d %d %d %d nb %d %d %d %d wgs %d %d %d %d lds %zu %zu %zu %zu\n", S, sys->n_cu, q.R[0], q.R[1], q.R[2], q.R[3],
+                   q.nb[0], q.nb[1], q.nb[2], q.nb[3], nwg[0], nwg[1], nwg[2], nwg[3], lds[0], lds[1], lds[2], lds[3]);
+  q.wg_first[0] = 0; q.wg_first[1] = 0;
+  for (int l = 1; l < NLEV; l++) q.wg_first[l + 1] = q.wg_first[l] + nwg[l];
+  size_t lds123 = lds[1]; if (lds[2] > lds123) lds123 = lds[2]; if (lds[3] > lds123) lds123 = lds[3];
+  prof_mark(sys, 0);
+  hipLaunchKernelGGL(k_fast_slide<true>, dim3(nwg[0]), dim3(SL_THREADS), lds[0], fs, a, q);
+  prof_mark(sys, 1);
+  hipLaunchKernelGGL(k_fast_slide<false>, dim3(q.wg_first[NLEV]), dim3(SL_THREADS), lds123, fs, a, q);
+}
+
 int fe_make_keyframe_lite(vslam_system* sys, const uint8_t* gray, size_t row_stride, size_t stream_stride,
                           int on_device) {
   const LevelGeom* g = sys->geom;
@@ -560,14 +834,17 @@ int fe_make_keyframe_lite(vslam_system* sys, const uint8_t* gray, size_t row_str
   const int lp0 = (g[0].w + 15) & ~15, lp1 = (g[1].w + 15) & ~15, lp2 = (g[2].w + 15) & ~15;
   const size_t lds0 = (size_t)(BAND + 2 * HALO) * lp0 + (BAND / 2) * lp1 + (BAND / 4) * lp2 + 16 + (size_t)BAND * g[0].nchunk * 8 + (size_t)FB_ROWS * lp0 * 2 + 16;
   const int nb0 = (g[0].h + BAND - 1) / BAND;
-  prof_mark(sys, 0);
-  hipLaunchKernelGGL(k_pyr_fast0, dim3(nb0, sys->S), dim3(FE_THREADS), lds0, fs, a, lp0, lp1, lp2);
-  int nb = 0;
-  a.band_first[0] = 0;
-  for (int l = 1; l < NLEV; l++) { a.band_first[l] = nb; nb += (g[l].h + BAND - 1) / BAND; }
-  const size_t lds1 = (size_t)(BAND + 2 * HALO) * lp1 + 16 + (size_t)BAND * g[1].nchunk * 8 + (size_t)FB_ROWS * lp1 * 2 + 16;
-  prof_mark(sys, 1);
-  hipLaunchKernelGGL(k_fast_lvl, dim3(nb, sys->S), dim3(FE_THREADS), lds1, fs, a);
+  if (fe_slide_ok(sys, a)) fe_launch_slide(sys, a, fs, sys->S);
+  else {
+    prof_mark(sys, 0);
+    hipLaunchKernelGGL(k_pyr_fast0, dim3(nb0, sys->S), dim3(FE_THREADS), lds0, fs, a, lp0, lp1, lp2);
+    int nb = 0;
+    a.band_first[0] = 0;
+    for (int l = 1; l < NLEV; l++) { a.band_first[l] = nb; nb += (g[l].h + BAND - 1) / BAND; }
+    const size_t lds1 = (size_t)(BAND + 2 * HALO) * lp1 + 16 + (size_t)BAND * g[1].nchunk * 8 + (size_t)FB_ROWS * lp1 * 2 + 16;
+    prof_mark(sys, 1);
+    hipLaunchKernelGGL(k_fast_lvl, dim3(nb, sys->S), dim3(FE_THREADS), lds1, fs, a);
+  }
   prof_mark(sys, 2);
   hipLaunchKernelGGL(k_compact, dim3(nb0, NLEV, sys->S), dim3(COMPACT_THREADS), 0, fs, a);
   if (sys->p.use_sbi) {                                           // jni/Tracker.cc:86-97, 104-105
