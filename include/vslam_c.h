@@ -91,6 +91,10 @@ typedef struct vslam_params {
                                       ReFindFromFailureQueue (:1083-1096; the reference draws rand() % 20), HandleBadPoints.  0 (default): one
                                       BundleAdjustRecent per keyframe only.  -1: none after a frame, but the failure queue and never-retry sets are kept so that
                                       vslam_mapmaker_idle_job can run the jobs on request.  Needs the synchronous map-maker (ba_delay_frames = 0) */
+  int bootstrap;                   /* 1: a stream without a map runs Tracker::TrackForInitialMap (jni/Tracker.cc:247-288): vslam_press_spacebar starts the
+                                      trails on the next frame, a second press runs MapMaker::InitFromStereo (HomographyInit, the stereo points,
+                                      AddSomeMapPoints, BundleAdjustAll, CalcPlaneAligner) on the frame that consumes it.  Needs grow_map != 0
+                                      (keyframe corner lists) and the synchronous map-maker for the streams being initialised.  0 (default): maps are uploaded */
 } vslam_params;
 
 const char* vslam_last_error(void);
@@ -263,6 +267,20 @@ int vslam_get_idle_stats(vslam_system* sys, int stream, int out[6]);
  * (:97-98), 1 ReFindNewlyMade (:102-103), 2 BundleAdjustAll if not converged (:107-108), 3 every 20th call
  * ReFindFromFailureQueue (:112-113); each followed by HandleBadPoints (:117).  Needs idle_iterations != 0 at creation. */
 int vslam_mapmaker_idle_job(vslam_system* sys, int job);
+
+/* ---- map bootstrap (vslam_params.bootstrap) ----
+ * Tracker::mbUserPressedSpacebar (jni/Tracker.h:138) of one stream, or of every stream (stream < 0): consumed by the next frame. */
+int vslam_press_spacebar(vslam_system* sys, int stream);
+/* the seed that stands in for the reference's rand() state in HomographyInit's MLESAC and CalcPlaneAligner's RANSAC (default 1) */
+int vslam_set_boot_seed(vslam_system* sys, int stream, unsigned seed);
+/* out[0..5] = mnInitialStage (0 not started, 1 trails running, 2 complete), trails alive, InitFromStereo succeeded, homography inliers,
+ * map points made from the stereo pair, map good */
+int vslam_get_init_info(vslam_system* sys, int stream, int out[6]);
+/* the trails (jni/Tracker.h Trail): irInitialPos x, y, irCurrentPos x, y per trail, in list order */
+int vslam_get_trails(vslam_system* sys, int stream, int* out4, int cap, int* n);
+/* Reads the directory vslam_save_map wrote (MapMaker "SaveMap", jni/MapMaker.cc:1254-1286: map.dump, keyframes/<i>.info) back: point
+ * positions + source levels, keyframe poses as R (9, row-major) then t (3).  Arrays may be null to count only. */
+int vslam_read_map_dump(const char* dir, double* pos3, int* level, int point_cap, int* n_points, double* pose12, int kf_cap, int* n_keyframes);
 
 /* ---- measurement: HIP-event time per stage of vslam_track_frame, on the system's own stream ---- */
 #define VSLAM_N_STAGES 14

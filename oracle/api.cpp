@@ -53,6 +53,18 @@ void orc_sys_pose_stage(void* s, int stage) { System* S = (System*)s; if (S->tra
 void orc_sys_frame_end(void* s) { ((System*)s)->FrameEnd(); }
 void orc_sys_idle_iteration(void* s) { ((System*)s)->IdleIteration(); }
 void orc_sys_idle_job(void* s, int job) { ((System*)s)->IdleJob(job); }
+void orc_sys_press_spacebar(void* s) { ((System*)s)->spacebar = true; }
+void orc_sys_set_boot_seed(void* s, unsigned seed) { ((System*)s)->boot_seed = seed; }
+void orc_sys_get_init_info(void* sv, int out[6]) {
+  System* s = (System*)sv;
+  out[0] = s->init_stage; out[1] = (int)s->trails.size(); out[2] = s->init_ok ? 1 : 0; out[3] = s->n_hom_inliers; out[4] = s->n_init_points; out[5] = s->map_good ? 1 : 0;
+}
+int orc_sys_get_trails(void* sv, int* out4, int cap) {
+  System* s = (System*)sv;
+  const int n = (int)s->trails.size();
+  for (int i = 0; i < n && i < cap; i++) { out4[4 * i] = s->trails[i].init[0]; out4[4 * i + 1] = s->trails[i].init[1]; out4[4 * i + 2] = s->trails[i].cur[0]; out4[4 * i + 3] = s->trails[i].cur[1]; }
+  return n;
+}
 void orc_sys_get_idle_stats(void* sv, int out[6]) {
   System* s = (System*)sv;
   out[0] = s->n_refound_new; out[1] = s->n_refound_failed; out[2] = s->n_ba_all; out[3] = s->n_ba_recent_idle; out[4] = (int)s->failure_queue.size(); out[5] = (int)s->new_queue.size();

@@ -206,7 +206,8 @@ class OracleSystem:
         L.orc_sys_create.restype = C.c_void_p
         for f in ("orc_sys_destroy", "orc_sys_add_meas", "orc_sys_set_map_good", "orc_sys_set_pose", "orc_sys_set_velocity",
                   "orc_sys_track_frame", "orc_sys_get_state", "orc_sys_get_keyframe_pose", "orc_sys_frame_begin", "orc_sys_search_stage",
-                  "orc_sys_pose_stage", "orc_sys_frame_end", "orc_sys_idle_iteration", "orc_sys_idle_job", "orc_sys_get_idle_stats"):
+                  "orc_sys_pose_stage", "orc_sys_frame_end", "orc_sys_idle_iteration", "orc_sys_idle_job", "orc_sys_get_idle_stats",
+                  "orc_sys_press_spacebar", "orc_sys_set_boot_seed", "orc_sys_get_init_info"):
             getattr(L, f).restype = None
         self.L = L
         self.p = params
@@ -265,6 +266,23 @@ class OracleSystem:
 
     def idle_job(self, job):
         self.L.orc_sys_idle_job(self.h, job)
+
+    def press_spacebar(self):
+        self.L.orc_sys_press_spacebar(self.h)
+
+    def set_boot_seed(self, seed):
+        self.L.orc_sys_set_boot_seed(self.h, C.c_uint(seed))
+
+    def init_info(self):
+        o = np.zeros(6, np.int32)
+        self.L.orc_sys_get_init_info(self.h, _p(o))
+        return dict(zip(("stage", "trails", "init_ok", "hom_inliers", "stereo_points", "map_good"), (int(x) for x in o)))
+
+    def trails(self):
+        o = np.zeros((1000, 4), np.int32)
+        self.L.orc_sys_get_trails.restype = C.c_int
+        n = self.L.orc_sys_get_trails(self.h, _p(o), 1000)
+        return o[:n]
 
     def idle_stats(self):
         o = np.zeros(6, np.int32)
@@ -464,3 +482,22 @@ def minipatch_find(patch, img, corners, x, y, rng=10, max_ssd=100000):
     pos = np.array([x, y], np.int32)
     ok = lib().orc_minipatch_find(_p(patch), _p(img), img.shape[1], img.shape[0], img.shape[1], _p(corners), len(corners), int(rng), int(max_ssd), _p(pos))
     return bool(ok), int(pos[0]), int(pos[1])
+
+
+def homography_init(matches8, max_pixel_error=5.0, seed=1):
+    """HomographyInit::Compute on (n, 8) matches [first xy, second xy, 2x2 pixel Jacobian]: (ok, 3x4 second-from-first, inliers)."""
+    L = lib()
+    m = np.ascontiguousarray(matches8, np.float64)
+    out = np.zeros(12); ninl = C.c_int(0)
+    L.orc_homography_init.restype = C.c_int
+    ok = L.orc_homography_init(_p(m), C.c_int(len(m)), C.c_double(max_pixel_error), C.c_uint(seed), _p(out), C.byref(ninl))
+    return bool(ok), out, ninl.value
+
+
+def calc_plane_aligner(pos, seed=1):
+    L = lib()
+    p = np.ascontiguousarray(pos, np.float64)
+    out = np.zeros(12)
+    L.orc_calc_plane_aligner.restype = C.c_int
+    ok = L.orc_calc_plane_aligner(_p(p), C.c_int(len(p)), C.c_uint(seed), _p(out))
+    return bool(ok), out

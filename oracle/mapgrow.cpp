@@ -123,7 +123,7 @@ int System::ClosestKeyFrame(int kidx) {
 }
 
 // MapPoint::RefreshPixelVectors, jni/MapPoint.cc:4-29, with v3Normal_NC = (0, 0, -1)
-static void refresh_pixel_vectors(MapPoint& p, const KeyFrame& k, const V3& center, const V3& one_right, const V3& one_down) {
+void refresh_pixel_vectors(MapPoint& p, const KeyFrame& k, const V3& center, const V3& one_right, const V3& one_down) {
   const V3 pc = xform(k.pose, p.pos);
   const double dCamHeight = fabs(-pc[2]);
   const double dPixelRate = fabs(-center[2]), dOneRightRate = fabs(-one_right[2]), dOneDownRate = fabs(-one_down[2]);
@@ -133,7 +133,7 @@ static void refresh_pixel_vectors(MapPoint& p, const KeyFrame& k, const V3& cent
   p.pix_down = rot_inv(k.pose, v3(dop[0] - cop[0], dop[1] - cop[1], dop[2] - cop[2]));
 }
 
-static V3 unit_ray(const Camera& cam, double ix, double iy) {
+V3 unit_ray(const Camera& cam, double ix, double iy) {
   double u[2];
   cam.unproject(ix, iy, u);
   const double n = sqrt(u[0] * u[0] + u[1] * u[1] + 1.0);

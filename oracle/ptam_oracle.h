@@ -124,6 +124,15 @@ void orc_sys_frame_begin(void* sys, const uint8_t* gray, int stride);
 void orc_sys_search_stage(void* sys, int stage);
 void orc_sys_pose_stage(void* sys, int stage);
 void orc_sys_frame_end(void* sys);
+/* map bootstrap (bootstrap.cpp): the next frame of a system without a map starts the trails / runs InitFromStereo (jni/Tracker.cc:247-288) */
+void orc_sys_press_spacebar(void* sys);
+void orc_sys_set_boot_seed(void* sys, unsigned seed);
+void orc_sys_get_init_info(void* sys, int out[6]);   /* stage, trails, InitFromStereo succeeded, homography inliers, points after the stereo pass, map good */
+int orc_sys_get_trails(void* sys, int* out4 /* initial x, y, current x, y */, int cap);
+/* HomographyInit::Compute (jni/HomographyInit.cc:43-71) on n matches given as 8 doubles each: first (z = 1 plane), second, d pixel / d plane (2x2 row-major) */
+int orc_homography_init(const double* matches8, int n, double max_pixel_error, unsigned seed, double out12[12], int* n_inliers);
+/* MapMaker::CalcPlaneAligner (jni/MapMaker.cc:1104-1231) on n points */
+int orc_calc_plane_aligner(const double* pos3, int n, unsigned seed, double out12[12]);
 void orc_sys_idle_job(void* sys, int job);   /* one of them: 0 idle BundleAdjustRecent, 1 ReFindNewlyMade, 2 BundleAdjustAll, 3 ReFindFromFailureQueue */
 void orc_sys_idle_iteration(void* sys);        /* one pass through the idle jobs of MapMaker::run, jni/MapMaker.cc:94-117 */
 void orc_sys_get_idle_stats(void* sys, int out[6]);   /* points re-found by ReFindNewlyMade / ReFindFromFailureQueue, BundleAdjustAll / idle BundleAdjustRecent calls, queue lengths */

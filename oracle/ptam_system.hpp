@@ -2,6 +2,7 @@
 // mapping hot path: PatchFinder, TrackerData, Tracker::TrackFrame/TrackMap, Bundle, MapMaker's BA driver.
 // Scalar double precision, one function per reference function, file:line cited at each.
 #pragma once
+#include <array>
 #include <cstdint>
 #include <map>
 #include <set>
@@ -50,6 +51,7 @@ struct Finder {
 
 struct MapPoint {     // jni/MapPoint.h:22-69 + TrackerData (jni/TrackerData.h:36-66)
   V3 pos; bool bad = false;
+  bool boot = false;             // made by InitFromStereo: its pixel vectors use the reference's swapped neighbours (jni/MapMaker.cc:271-292)
   int src_kf = 0, src_level = 0; int irx = 0, iry = 0;
   V3 pix_right, pix_down;
   int n_outlier = 0, n_inlier = 0;
@@ -170,6 +172,17 @@ struct System {
   void ApplyBundle(PendingBA& pb);
   bool defer_ba = false;
   bool abort_flag = false;
+  // map bootstrap (bootstrap.cpp): Tracker::TrackForInitialMap and the trails (jni/Tracker.cc:247-346), MapMaker::InitFromStereo (jni/MapMaker.cc:204-376)
+  struct Trail { uint8_t patch[81]; int init[2], cur[2]; };
+  int init_stage = 0;            // TRAIL_TRACKING_NOT_STARTED / STARTED / COMPLETE
+  bool spacebar = false;         // mbUserPressedSpacebar
+  bool init_ok = false; int n_hom_inliers = 0, n_init_points = 0;
+  unsigned boot_seed = 1;        // stands in for the reference's rand() state
+  std::vector<Trail> trails; KeyFrame first_kf, prev_kf;
+  void TrackForInitialMap(); void TrailTrackingStart(); int TrailTrackingAdvance(int max_ssd);
+  bool InitFromStereo(const KeyFrame& kF, const KeyFrame& kS, const std::vector<std::array<int, 4>>& trail_matches);
+  void RefreshSceneDepth(KeyFrame& k);
+  SE3 CalcPlaneAligner(); void ApplyGlobalTransformationToMap(const SE3& new_from_old);
 };
 
 void make_keyframe_lite(KeyFrame& k, const uint8_t* gray, int w, int h, int stride, const int thr[4]);

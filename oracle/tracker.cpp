@@ -155,6 +155,7 @@ void System::FrameBegin(const uint8_t* gray, int stride) {
     ApplyMotionModel();
   }
   tracked_this_frame = Tracking();
+  if (!map_good) TrackForInitialMap();         // jni/Tracker.cc:144-145: no map yet, try to make one
 }
 
 void System::FrameEnd() {

@@ -32,7 +32,7 @@ class Params(C.Structure):
         ("wiggle_scale", C.c_double), ("ba_max_iterations", C.c_int), ("ba_convergence_limit", C.c_double),
         ("ba_min_tukey_sigma", C.c_double), ("ba_window", C.c_int), ("ba_min_keyframes", C.c_int),
         ("cam", C.c_double * 5), ("quirks", C.c_int), ("device", C.c_int), ("ba_delay_frames", C.c_int),
-        ("grow_map", C.c_int), ("ba_batch_frames", C.c_int), ("idle_iterations", C.c_int),
+        ("grow_map", C.c_int), ("ba_batch_frames", C.c_int), ("idle_iterations", C.c_int), ("bootstrap", C.c_int),
     ]
 
 
@@ -101,6 +101,11 @@ SYMBOLS = {
     "vslam_get_bundle_stats": (_i, [_sys, _i, _vp]),
     "vslam_get_idle_stats": (_i, [_sys, _i, _vp]),
     "vslam_mapmaker_idle_job": (_i, [_sys, _i]),
+    "vslam_press_spacebar": (_i, [_sys, _i]),
+    "vslam_set_boot_seed": (_i, [_sys, _i, C.c_uint]),
+    "vslam_get_init_info": (_i, [_sys, _i, _vp]),
+    "vslam_get_trails": (_i, [_sys, _i, _vp, _i, _vp]),
+    "vslam_read_map_dump": (_i, [C.c_char_p, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     "vslam_get_keyframe_measurements": (_i, [_sys, _i, _i, _vp, _vp, _vp, _vp, _i]),
     "vslam_get_template": (_i, [_sys, _i, _i, _vp, _ip, _ip, _ip]),
     "vslam_get_templates": (_i, [_sys, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -435,6 +440,23 @@ class System:
 
     def mapmaker_idle_job(self, job):
         _check(self.lib.vslam_mapmaker_idle_job(self.h, job))
+
+    def press_spacebar(self, stream=-1):
+        _check(self.lib.vslam_press_spacebar(self.h, stream))
+
+    def set_boot_seed(self, stream, seed):
+        _check(self.lib.vslam_set_boot_seed(self.h, stream, seed))
+
+    def init_info(self, stream):
+        o = np.zeros(6, np.int32)
+        _check(self.lib.vslam_get_init_info(self.h, stream, o.ctypes.data))
+        return dict(zip(("stage", "trails", "init_ok", "hom_inliers", "stereo_points", "map_good"), (int(x) for x in o)))
+
+    def trails(self, stream):
+        o = np.zeros((1000, 4), np.int32)
+        n = C.c_int(0)
+        _check(self.lib.vslam_get_trails(self.h, stream, o.ctypes.data, 1000, C.byref(n)))
+        return o[:n.value]
 
     def idle_stats(self, stream):
         o = np.zeros(6, np.int32)

@@ -330,9 +330,11 @@ __global__ __launch_bounds__(64) void k_ba_select(MapDev m, TrackParams tp, BaPo
     st->ba_converged_full = 0; st->ba_converged_recent = 0;           // :504-505
   }
   bool want = st->map_good && (mode != 0 || st->kf_pending) && !in_flight;
+  if (mode == 5 || mode == 6) want = want && st->boot_run;                                  // InitFromStereo's BundleAdjustAll calls, jni/MapMaker.cc:344-345, 361-365
+  if (mode == 6) want = want && !st->ba_converged_full;
   if (mode == 3) want = want && !st->ba_converged_recent;                                   // MapMaker::run :97-98
   if (mode == 4) want = want && st->ba_converged_recent && !st->ba_converged_full;          // :107-108
-  const bool all = mode == 2 || mode == 4;
+  const bool all = mode == 2 || mode == 4 || mode == 5 || mode == 6;
   if (want && mode == 3) st->n_ba_recent_idle++;
   if (want && mode == 4) st->n_ba_all++;
   const int nk = st->n_kf;
@@ -495,6 +497,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_writeback(MapDev m, TrackPara
   MapPointDev* pts = m.pts + (size_t)s * P;
   MeasDev* kfm = m.kf_meas + (size_t)s * K * P;
   __shared__ int sh_due;
+  if (mode == 5) { if (!st->boot_run) return; mode = 2; }   // InitFromStereo's adjustments: only the streams it runs for
   if (mode >= 3) {                         // asynchronous map-maker: is this stream's pending result due?
     if (threadIdx.x == 0) {
       int due = 0;
@@ -669,7 +672,8 @@ static int ba_drain(vslam_system* sys) {
 // mode 0: tracker-driven AddKeyFrame + BundleAdjustRecent; 1: BundleAdjustRecent; 2: BundleAdjustAll; 3 / 4: the same two as idle jobs of
 // MapMaker::run, for the streams whose adjustment has not converged (gated on device)
 int ba_run(vslam_system* sys, int mode) {
-  const int base = mode == 3 ? 1 : (mode == 4 ? 2 : mode);          // what the assembly and the write-back do
+  const int base = mode == 3 ? 1 : (mode == 4 || mode >= 5 ? 2 : mode);   // what the assembly does; 5 / 6: InitFromStereo's BundleAdjustAll (boot.hip)
+  const int wb = mode >= 5 ? 5 : base;                                    // ... and the write-back
   BaSystemWs* ws = (BaSystemWs*)sys->ba_ws;
   const BaConfig cfg = make_cfg(sys->tp);
   const bool async = mode == 0 && sys->tp.ba_delay > 0;
@@ -711,7 +715,14 @@ int ba_run(vslam_system* sys, int mode) {
   if (mode == 0) prof_mark(sys, 12);
   hipLaunchKernelGGL(k_ba_compute, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, ws->pool, cfg, -1);
   if (mode == 0) prof_mark(sys, 13);
-  hipLaunchKernelGGL(k_ba_writeback, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, base);
+  hipLaunchKernelGGL(k_ba_writeback, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, wb);
+  HIPCHK(hipGetLastError());
+  return VSLAM_OK;
+}
+
+int ba_launch_add_keyframe(vslam_system* sys) {
+  KfCopyArgs a; fill_kfcopy(sys, a);
+  hipLaunchKernelGGL(k_add_keyframe, dim3(32, sys->S), dim3(256), 0, sys->stream, sys->map, sys->tp, a);
   HIPCHK(hipGetLastError());
   return VSLAM_OK;
 }

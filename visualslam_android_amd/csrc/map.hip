@@ -172,6 +172,7 @@ extern "C" int vslam_map_set_good(vslam_system* sys, int s) {
 
 static void reset_tracker_fields(TrackerState& st) {   // Tracker::Reset, jni/Tracker.cc:45-62 (first call for a stream)
   if (st.frame == 0 && st.last_kf_dropped == 0 && st.depth_mean == 0.0) {
+    st.boot_seed = 1u;
     st.quality = 2; st.last_kf_dropped = -20; st.depth_mean = 1.0; st.depth_sigma = 1.0; st.ba_accepted = -2; st.ba_countdown = -1;
     for (int i = 0; i < 9; i++) st.pose_final.R[i] = (i % 4 == 0) ? 1.0 : 0.0;
     st.pose_cur = st.pose_final; st.start_pose = st.pose_final;
@@ -254,6 +255,7 @@ extern "C" int vslam_finish_frame(vslam_system* sys) {
   sys->frame_open = false;
   int r = ba_add_keyframe_and_adjust(sys);                                             // :128-132 -> MapMaker::AddKeyFrame
   if (!r && sys->p.idle_iterations > 0) r = mm_idle(sys);                              // the map-maker's idle jobs
+  if (!r && sys->p.bootstrap) r = boot_frame(sys);                                     // jni/Tracker.cc:144-145: TrackForInitialMap for the streams without a map
   prof_mark(sys, VSLAM_N_STAGES);
   if (sys->prof_on && sys->prof_frame < sys->prof_cap) sys->prof_frame++;
   if (!r) HIPCHK(hipEventRecord(sys->ev_track_done[sys->fr_idx], sys->stream));       // the front-end may now reuse this buffer
@@ -395,6 +397,47 @@ extern "C" int vslam_mapmaker_idle_job(vslam_system* sys, int job) {
   if (sys->frame_open) { vslam_set_error("mapmaker_idle_job: a frame is open (vslam_finish_frame first)"); return VSLAM_E_STATE; }
   if (sys->p.idle_iterations == 0) { vslam_set_error("mapmaker_idle_job: created with idle_iterations = 0 (no failure queue / never-retry sets are kept); use -1 for idle jobs on request only"); return VSLAM_E_STATE; }
   return mm_idle_job(sys, job);
+}
+
+// The dump of vslam_save_map read back (MapMaker's "SaveMap", jni/MapMaker.cc:1254-1286): <dir>/map.dump holds v3WorldPos (Eigen's
+// column print, one coordinate per line) + two blanks + nSourceLevel per good point, <dir>/keyframes/<i>.info the rows of [R | t].
+static int read_numbers(const char* path, std::vector<double>& out) {
+  FILE* f = fopen(path, "r");
+  if (!f) return -1;
+  char line[1024];
+  while (fgets(line, sizeof(line), f)) {
+    char* q = line;
+    for (;;) { char* e = nullptr; const double v = strtod(q, &e); if (e == q) break; q = e; out.push_back(v); }
+  }
+  fclose(f);
+  return 0;
+}
+extern "C" int vslam_read_map_dump(const char* dir, double* pos3, int* level, int point_cap, int* n_points, double* pose12, int kf_cap, int* n_keyframes) {
+  if (!dir) { vslam_set_error("read_map_dump: null directory"); return VSLAM_E_INVALID; }
+  char path[4096];
+  snprintf(path, sizeof(path), "%s/map.dump", dir);
+  std::vector<double> v;
+  if (read_numbers(path, v)) { vslam_set_error("read_map_dump: cannot open map.dump in the given directory"); return VSLAM_E_INVALID; }
+  if (v.size() % 4) { vslam_set_error("read_map_dump: map.dump does not hold whole points (x, y, z, level)"); return VSLAM_E_INVALID; }
+  const int np = (int)(v.size() / 4);
+  for (int i = 0; i < np && i < point_cap; i++) {
+    if (pos3) for (int k = 0; k < 3; k++) pos3[3 * i + k] = v[4 * (size_t)i + k];
+    if (level) level[i] = (int)v[4 * (size_t)i + 3];
+  }
+  int nk = 0;
+  for (;; nk++) {
+    snprintf(path, sizeof(path), "%s/keyframes/%d.info", dir, nk);
+    std::vector<double> q;
+    if (read_numbers(path, q)) break;
+    if (q.size() != 12) { vslam_set_error("read_map_dump: keyframes/%d.info does not hold a 3x4 pose", nk); return VSLAM_E_INVALID; }
+    if (nk < kf_cap && pose12) {
+      double* o = pose12 + 12 * (size_t)nk;
+      for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) o[r * 3 + c] = q[r * 4 + c]; o[9 + r] = q[r * 4 + 3]; }
+    }
+  }
+  if (n_points) *n_points = np;
+  if (n_keyframes) *n_keyframes = nk;
+  return VSLAM_OK;
 }
 
 extern "C" int vslam_get_message(vslam_system* sys, int s, char* buf, size_t cap) {

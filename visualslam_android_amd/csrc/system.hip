@@ -49,6 +49,7 @@ extern "C" int vslam_default_params(vslam_params* p, int width, int height, int 
   p->grow_map = 0;
   p->ba_batch_frames = 1;
   p->idle_iterations = 0;
+  p->bootstrap = 0;
   return VSLAM_OK;
 }
 
@@ -72,6 +73,10 @@ extern "C" int vslam_create(const vslam_params* p, vslam_system** out) {
       (p->idle_iterations != 0 && p->ba_delay_frames > 0)) {
     vslam_set_error("create: unsupported parameters: size %dx%d (48..4096), streams %d (>= 1), patch %d (8 or 11), ba_delay_frames %d (0..19 and below min_frames_between_kf %d), ba_batch_frames %d (0..ba_delay_frames), idle_iterations %d (>= -1, non-zero only with ba_delay_frames = 0)",
                     p->width, p->height, p->n_streams, p->patch_size, p->ba_delay_frames, p->min_frames_between_kf, p->ba_batch_frames, p->idle_iterations);
+    return VSLAM_E_INVALID;
+  }
+  if (p->bootstrap && (p->grow_map == 0 || p->ba_delay_frames > 0)) {
+    vslam_set_error("create: bootstrap needs grow_map != 0 (keyframe corner lists for InitFromStereo's AddSomeMapPoints) and ba_delay_frames = 0, got grow_map %d, ba_delay_frames %d", p->grow_map, p->ba_delay_frames);
     return VSLAM_E_INVALID;
   }
   int ndev = 0;
@@ -156,6 +161,7 @@ extern "C" int vslam_create(const vslam_params* p, vslam_system** out) {
     int r = trk_alloc(sys);
     if (!r) r = ba_alloc(sys);
     if (!r) r = grow_alloc(sys);
+    if (!r) r = boot_alloc(sys);
     if (!r && hipStreamSynchronize(sys->stream) != hipSuccess) r = VSLAM_E_HIP;
     if (!r) r = map_init_states(sys);
     if (r) { vslam_destroy(sys); return r; }

@@ -84,6 +84,8 @@ struct MeasDev {            // Measurement, jni/KeyFrame.h:46-51 (one slot per k
   int pad;
 };
 
+#define BOOT_MAX_TRAILS 1000   // MaxInitialTrails, jni/Tracker.cc:305
+
 struct TrackerState {       // Tracker members, jni/Tracker.h:77-150 (+ MapMaker flags used by the BA driver)
   Pose pose_final, start_pose, pose_cur;
   double velocity[6];
@@ -104,6 +106,14 @@ struct TrackerState {       // Tracker members, jni/Tracker.h:77-150 (+ MapMaker
   int idle_count;           // evaluations of the lowest-priority job's condition (rand() % 20 == 0 made deterministic: every 20th)
   int idle_do_fail;         // this pass runs ReFindFromFailureQueue
   int n_refound_new, n_refound_failed, n_ba_all, n_ba_recent_idle;   // statistics
+  // map bootstrap (vslam_params.bootstrap; boot.hip): Tracker::TrackForInitialMap, jni/Tracker.cc:247-288
+  int init_stage;           // mnInitialStage: 0 TRAIL_TRACKING_NOT_STARTED, 1 STARTED, 2 COMPLETE
+  int spacebar;             // mbUserPressedSpacebar
+  int n_trails, trail_buf;  // mlTrails (double-buffered: a frame's survivors are compacted into the other buffer)
+  int boot_action;          // this frame: 1 TrailTracking_Start, 2 TrailTracking_Advance
+  int boot_run;             // InitFromStereo is running for this stream (gates its kernels)
+  int boot_ok, n_hom_inliers, n_init_points;
+  unsigned boot_seed;       // stands in for the reference's rand() state
 };
 
 struct TrackParams {        // device copy of the tunables the kernels read
@@ -139,6 +149,12 @@ struct MapDev {             // device pointers of the map + tracker of all strea
   int* kf_ncorners;         // [S][max_keyframes][NLEV]
   unsigned long long* never_retry;   // [S][max_points][2]  MapMakerData::sNeverRetryKFs as a bit set over the keyframes (idle jobs only)
   int2* fq;                 // [S][fq_cap]  mvFailureQueue: (keyframe, point)
+  // map bootstrap (vslam_params.bootstrap): the trails and InitFromStereo's work arrays
+  uint8_t* trail_patch;     // [S][2][BOOT_MAX_TRAILS][81]  Trail::mPatch
+  int* trail_pos;           // [S][2][BOOT_MAX_TRAILS][4]   irInitialPos, irCurrentPos
+  double* boot_match;       // [S][BOOT_MAX_TRAILS][8]      HomographyMatch
+  int* boot_inl;            // [S][BOOT_MAX_TRAILS]
+  double* boot_ws;          // [S][max(3 * max_points, BOOT_MAX_TRAILS)]
   TrackerState* st;         // [S]
   int* pvs_list;            // [S][NLEV][max_points]
   int2* search_list;        // [S][max_points]  (point index, sub-pixel iterations)
@@ -181,6 +197,7 @@ struct vslam_system {
   bool have_sbi;            // a SmallBlurryImage of a previous frame exists (mpSBILastFrame)
   // KeyFrame::Level::vCandidates of the current frame (jni/KeyFrame.h:62-70), filled by vslam_make_keyframe_rest
   uint32_t* cand[NLEV]; double* cand_score[NLEV]; int* ncand; bool have_candidates;
+  bool boot_key_pressed = false;   // vslam_press_spacebar since the last frame: that frame launches the start / InitFromStereo pipelines
   TrackParams tp;
   MapDev map;
   void* ba_ws;                 // bundle-adjustment workspace (ba.hip)
@@ -212,6 +229,11 @@ int grow_alloc(vslam_system* sys);
 int grow_on_keyframe(vslam_system* sys);                      // AddSomeMapPoints(3, 0, 1, 2) for the streams with kf_pending
 int grow_idle_refind(vslam_system* sys, int mode);            // idle jobs: 0 ReFindNewlyMade, 1 ReFindFromFailureQueue (gated per stream on device)
 int mm_idle(vslam_system* sys);
+int boot_alloc(vslam_system* sys);
+int boot_frame(vslam_system* sys);                                        // TrackForInitialMap for the streams without a map (vslam_params.bootstrap)
+int grow_copy_corners(vslam_system* sys);                                 // Level::vCorners of the current frame into the keyframe slot n_kf (streams with kf_pending)
+int grow_levels(vslam_system* sys, const int* order, int n);              // ThinCandidates + AddPointEpipolar per level, in this order (streams with kf_pending)
+int ba_launch_add_keyframe(vslam_system* sys);                            // k_add_keyframe for the streams with kf_pending
 int mm_idle_job(vslam_system* sys, int job);                               // vslam_params.idle_iterations passes through MapMaker::run's idle jobs
 int fe_sbi(vslam_system* sys, const FrameDev& last);   // k_sbi on the front-end stream: this frame's SBI + rotation prior against `last`
 void cam_fill(CamModel& c, const double cam5[5], double width, double height, int quirks);
