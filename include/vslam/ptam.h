@@ -108,9 +108,16 @@ class MapMaker {
   int QueueSize() { return 0; }
   bool NeedNewKeyFrame(KeyFrame&) { int v = 0; vslam_detail::check(vslam_need_new_keyframe(mMap.sys, 0, &v)); return v != 0; }              // :761-773 (the tracker's current frame)
   bool IsDistanceToNearestKeyFrameExcessive(KeyFrame&) { int v = 0; vslam_detail::check(vslam_distance_to_nearest_keyframe_excessive(mMap.sys, 0, &v)); return v != 0; }   // :1098-1101
-  // :204-376.  The two-view bootstrap (HomographyInit + triangulation + plane alignment) is not built yet: no map is made and the
-  // caller is told so, as the reference tells it when the homography cannot be estimated (:216-220).
-  bool InitFromStereo(KeyFrame&, KeyFrame&, std::vector<std::pair<std::pair<double, double>, std::pair<double, double>>>&, mySE3&) { return false; }
+  // :204-376.  The two-view bootstrap runs on the device inside the frame that consumes the second spacebar press (a Tracker built
+  // with bBootstrap, vslam_params.bootstrap): the trails, the two keyframes and the matches never leave it.  This entry point
+  // reports what that frame did -- true and the tracker's pose once the map is good -- instead of taking host-side keyframes.
+  bool InitFromStereo(KeyFrame&, KeyFrame&, std::vector<std::pair<std::pair<double, double>, std::pair<double, double>>>&, mySE3& se3TrackerPose) {
+    int info[6];
+    if (vslam_get_init_info(mMap.sys, 0, info) != VSLAM_OK || !info[5]) return false;
+    vslam_track_state s; vslam_detail::check(vslam_get_state(mMap.sys, 0, &s));
+    memcpy(se3TrackerPose.R, s.pose, sizeof(se3TrackerPose.R)); memcpy(se3TrackerPose.t, s.pose + 9, sizeof(se3TrackerPose.t));
+    return true;
+  }
   void BundleAdjustRecent() { vslam_detail::check(vslam_bundle_adjust_recent(mMap.sys)); }             // :801-851
   void BundleAdjustAll() { vslam_detail::check(vslam_bundle_adjust_all(mMap.sys)); }                   // :776-798
   // :393-422, all four levels of the current candidate lists against keyframe nKeyFrame's measurements (< 0: the tracker's)
@@ -128,9 +135,12 @@ class MapMaker {
 // jni/Tracker.h:43-150 (public surface).
 class Tracker {
  public:
-  Tracker(int width, int heigth, const ATANCamera& c, Map& m, MapMaker& mm) : mMap(m), mMapMaker(mm) {   // jni/Tracker.cc:16-40
+  // bBootstrap: no map is uploaded, the tracker makes its own like the reference's (spacebar, spacebar: jni/Tracker.cc:247-288), and the
+  // map-maker grows it on every keyframe (AddKeyFrameFromTopOfQueue, jni/MapMaker.cc:481-506)
+  Tracker(int width, int heigth, const ATANCamera& c, Map& m, MapMaker& mm, bool bBootstrap = false) : mMap(m), mMapMaker(mm) {   // jni/Tracker.cc:16-40
     vslam_params p;
     vslam_detail::check(vslam_default_params(&p, width, heigth, 1));
+    if (bBootstrap) { p.bootstrap = 1; p.grow_map = 3; }
     for (int i = 0; i < 5; i++) p.cam[i] = c.params[i];
     vslam_detail::check(vslam_create(&p, &mMap.sys));
     mCurrentKF.sys = mMap.sys;

@@ -226,7 +226,8 @@ int vslam_patch_search(vslam_system* sys, int stage);
 int vslam_pose_update(vslam_system* sys, int stage);
 int vslam_finish_frame(vslam_system* sys);
 /* the JNI-equivalent per-frame entry: native_update (jni/jni_part.cpp:132-145): host gray image of stream 0..n-1,
- * synchronous; native_touchScreen (:120-124) has no effect once a map exists and is accepted for ABI parity. */
+ * synchronous; native_touchScreen (:120-124) = the spacebar of every stream: with vslam_params.bootstrap it starts the trails / runs
+ * InitFromStereo on the next frame of the streams that have no map, otherwise (and once a map exists) it has no effect. */
 int vslam_update(vslam_system* sys, const uint8_t* gray, size_t row_stride, size_t stream_stride);
 int vslam_touch(vslam_system* sys);
 

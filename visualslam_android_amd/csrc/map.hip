@@ -356,7 +356,11 @@ extern "C" int vslam_update(vslam_system* sys, const uint8_t* gray, size_t row_s
   return VSLAM_OK;
 }
 
-extern "C" int vslam_touch(vslam_system* sys) { return sys ? VSLAM_OK : VSLAM_E_INVALID; }
+// native_touchScreen (jni/jni_part.cpp:120-124): mbUserPressedSpacebar = true.  Only the map bootstrap reads the key.
+extern "C" int vslam_touch(vslam_system* sys) {
+  if (!sys) return VSLAM_E_INVALID;
+  return sys->p.bootstrap ? vslam_press_spacebar(sys, -1) : VSLAM_OK;
+}
 
 int ba_run(vslam_system* sys, int mode);
 extern "C" int vslam_bundle_adjust_recent(vslam_system* sys) { if (!sys) return VSLAM_E_INVALID; return ba_run(sys, 1); }
