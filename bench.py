@@ -125,7 +125,8 @@ def pmc_traffic(kernel):
         except (OSError, ValueError):
             continue
         if t.get("kernel") == kernel and "bytes_per_unit" in t:
-            return {"bytes_per_unit": float(t["bytes_per_unit"]), "unit": t.get("unit", ""), "source": os.path.relpath(f, ROOT)}
+            return {"bytes_per_unit": float(t["bytes_per_unit"]), "unit": t.get("unit", ""), "source": os.path.relpath(f, ROOT),
+                    "algorithmic_bytes_per_unit": float(t.get("algorithmic_bytes_per_unit", 0.0))}
     return None
 
 
@@ -424,7 +425,10 @@ def main():
                 tr = pmc_traffic({"ba_compute": "k_ba_compute", "front_end": "k_front_end"}.get(name, name))
                 if tr:                          # counters per unit of work (profiles/), scaled to this run's launch mix
                     units = trials_per_launch if name == "ba_compute" else Sk
-                    r_["traffic"] = round(tr["bytes_per_unit"] * units); r_["traffic_source"] = tr["source"]; r_["traffic_unit"] = tr["unit"]
+                    scale = 1.0                 # counters of a problem of another size: scaled by the ratio of the algorithmic bytes per unit
+                    if name == "ba_compute" and tr["algorithmic_bytes_per_unit"] > 0 and units > 0:
+                        scale = (ab_ / units) / tr["algorithmic_bytes_per_unit"]
+                    r_["traffic"] = round(tr["bytes_per_unit"] * units * scale); r_["traffic_source"] = tr["source"]; r_["traffic_unit"] = tr["unit"]
                 return r_
 
             # the dominant kernel = the largest summed HIP-event time over the timed region among the kernels with a byte model

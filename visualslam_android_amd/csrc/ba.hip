@@ -9,6 +9,7 @@
 #include "ba_device.h"
 #define BA_MAX_KF 128        // keyframes per stream = cameras of a bundle-adjustment problem (8-bit camera field of a slot: < 256)
 #include <string.h>
+#include <stdlib.h>
 
 struct BaPool {            // device arrays for N problems
   int N, max_cams, max_pts, max_meas, max_free;
@@ -621,7 +622,8 @@ static int ba_launch_batch(vslam_system* sys) {
   sys->ba_stream = sys->ba_streams[(size_t)(sys->ba_batch_id % (long)sys->ba_streams.size())];
   prof_mark(sys, 12);                                  // the batch's assemblies precede on this very stream
   // one workgroup per problem up to two per compute unit; the grid walks the batch's work list
-  const int cap = 2 * (sys->n_cu > 0 ? sys->n_cu : 256);
+  static const int per_cu_x2 = getenv("VSLAM_BA_WG_PER_CU_X2") ? atoi(getenv("VSLAM_BA_WG_PER_CU_X2")) : 4;   // diagnostic: background workgroups per CU, in halves
+  const int cap = per_cu_x2 * (sys->n_cu > 0 ? sys->n_cu : 256) / 2;
   const int ba_grid = sys->S < cap ? sys->S : cap;
   hipLaunchKernelGGL(k_ba_compute, dim3(ba_grid), dim3(BA_THREADS), 0, sys->ba_stream, ws->pool, cfg, slot);
   prof_mark(sys, PROF_BA_END);
