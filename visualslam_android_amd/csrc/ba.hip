@@ -49,7 +49,10 @@ __host__ __device__ inline BaView ba_view(const BaPool& b, int n) {
   return v;
 }
 
-__global__ __launch_bounds__(BA_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ba_compute(BaPool pool, BaConfig cfg, int slot) {
+#ifndef VSLAM_BA_WPE
+#define VSLAM_BA_WPE 2
+#endif
+__global__ __launch_bounds__(BA_THREADS) __attribute__((amdgpu_waves_per_eu(VSLAM_BA_WPE, VSLAM_BA_WPE))) void k_ba_compute(BaPool pool, BaConfig cfg, int slot) {
   // slot < 0: one workgroup per problem of the pool (synchronous map-maker, stand-alone Bundle); slot >= 0: the grid walks the
   // work list of one frame (asynchronous map-maker)
   const int count = slot < 0 ? pool.N : pool.work_n[slot];
