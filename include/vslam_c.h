@@ -281,6 +281,10 @@ int vslam_get_init_info(vslam_system* sys, int stream, int out[6]);
 int vslam_get_trails(vslam_system* sys, int stream, int* out4, int cap, int* n);
 /* Reads the directory vslam_save_map wrote (MapMaker "SaveMap", jni/MapMaker.cc:1254-1286: map.dump, keyframes/<i>.info) back: point
  * positions + source levels, keyframe poses as R (9, row-major) then t (3).  Arrays may be null to count only. */
+/* Writes the state such a dump holds (positions of the good points, keyframe poses; 6 significant digits) back into the map it was
+ * saved from: same keyframes and points, checked by count and source level.  Images, templates and measurements are not part of the
+ * reference's format, so this restores an estimate, it does not build a map. */
+int vslam_load_map(vslam_system* sys, int stream, const char* dir);
 int vslam_read_map_dump(const char* dir, double* pos3, int* level, int point_cap, int* n_points, double* pose12, int kf_cap, int* n_keyframes);
 
 /* ---- measurement: HIP-event time per stage of vslam_track_frame, on the system's own stream ---- */

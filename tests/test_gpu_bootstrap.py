@@ -115,4 +115,11 @@ def test_bootstrap_edge_cases_and_map_dump_round_trip(tmp_path):
         assert np.allclose(pos[:n.value], pts["pos"][good], rtol=2e-5, atol=1e-6)
         for k in range(nk.value):
             assert np.allclose(poses[k], np.array(g.keyframe_pose(0, k)[:]), rtol=2e-5, atol=1e-6)
+        # vslam_load_map: the dumped estimate written back over a disturbed map
+        g.set_point_positions(0, pts["pos"] + 0.01)
+        g.set_keyframe_pose(0, 1, np.array(g.keyframe_pose(0, 0)[:]))
+        g.load_map_dump(0, tmp_path)
+        after = g.points(0)
+        assert np.allclose(after["pos"][good], pts["pos"][good], rtol=2e-5, atol=1e-6)
+        assert np.allclose(np.array(g.keyframe_pose(0, 1)[:]), poses[1], rtol=1e-12, atol=1e-12)
     g.close()

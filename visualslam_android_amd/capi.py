@@ -106,6 +106,7 @@ SYMBOLS = {
     "vslam_get_init_info": (_i, [_sys, _i, _vp]),
     "vslam_get_trails": (_i, [_sys, _i, _vp, _i, _vp]),
     "vslam_read_map_dump": (_i, [C.c_char_p, _vp, _vp, _i, _vp, _vp, _i, _vp]),
+    "vslam_load_map": (_i, [_sys, _i, C.c_char_p]),
     "vslam_get_keyframe_measurements": (_i, [_sys, _i, _i, _vp, _vp, _vp, _vp, _i]),
     "vslam_get_template": (_i, [_sys, _i, _i, _vp, _ip, _ip, _ip]),
     "vslam_get_templates": (_i, [_sys, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -440,6 +441,9 @@ class System:
 
     def mapmaker_idle_job(self, job):
         _check(self.lib.vslam_mapmaker_idle_job(self.h, job))
+
+    def load_map_dump(self, stream, directory):
+        _check(self.lib.vslam_load_map(self.h, stream, str(directory).encode()))
 
     def press_spacebar(self, stream=-1):
         _check(self.lib.vslam_press_spacebar(self.h, stream))

@@ -23,6 +23,16 @@
 #pragma once
 #include "dev_math.h"
 
+#ifndef VSLAM_BA_WPE
+#define VSLAM_BA_WPE 2
+#endif
+// the phases of Bundle::Compute are out-of-line functions with their own register allocation (VSLAM_BA_INLINE_PHASES: diagnostic,
+// everything in the kernel's allocation so that amdgpu_waves_per_eu bounds it)
+#ifdef VSLAM_BA_INLINE_PHASES
+#define BA_PHASE_FN __device__ __forceinline__
+#else
+#define BA_PHASE_FN __device__ __attribute__((noinline))
+#endif
 #define BA_THREADS 256  // 4 waves; with amdgpu_waves_per_eu(2,2) on the kernel two problems share a CU (measured: 512 x 1 -4 %, 128 x 4 -4 %)
 #define BA_LDS_N 60      // reduced camera systems up to 60 x 60 (10 adjustable cameras) are solved in LDS
 #define BA_WAVES (BA_THREADS / 64)
@@ -319,7 +329,7 @@ DEVFN double ba_readlane_d(double v, int l) {
   const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-__device__ __attribute__((noinline)) bool ba_solve_wave(const BaView& v_, int n) {
+BA_PHASE_FN bool ba_solve_wave(const BaView& v_, int n) {
   const BaViewG v = ba_g(v_);
   constexpr int N = BA_WSOLVE_N;
   const int lane = threadIdx.x & 63;
@@ -395,7 +405,7 @@ DEVFN int ba_block_excl_scan(int AS1* a, int n, int* ired) {
   return total;
 }
 
-__device__ __attribute__((noinline)) void ba_build_layout(const BaView& v_, int nc, int np, int* ired, int* lds_i /* LDS, 2 * (max_pts + 1) ints */) {
+BA_PHASE_FN void ba_build_layout(const BaView& v_, int nc, int np, int* ired, int* lds_i /* LDS, 2 * (max_pts + 1) ints */) {
   const BaViewG v = ba_g(v_);
   // 1. per point: how many adjustable / fixed cameras measure it, which adjustable ones; V and epsilon_b start at zero
   for (int p = threadIdx.x; p < np; p += BA_THREADS) {
@@ -451,7 +461,7 @@ __device__ __attribute__((noinline)) void ba_build_layout(const BaView& v_, int 
 // number is returned.  Reads the static 32 B of a slot, writes 8 B.
 // ---------------------------------------------------------------------------------------------------------------------
 struct BaNewError { double ne; int nvalid; };
-__device__ __attribute__((noinline)) BaNewError ba_find_new_error(const BaView& v_, const BaConfig& cfg_, int M, double sigma2, int trial) {
+BA_PHASE_FN BaNewError ba_find_new_error(const BaView& v_, const BaConfig& cfg_, int M, double sigma2, int trial) {
   const BaViewG v = ba_g(v_);
   const BaConfig cfg = cfg_;
   const Pose AS1* cams = trial ? v.cam_new : v.cam_pose;
@@ -502,7 +512,7 @@ __device__ __attribute__((noinline)) BaNewError ba_find_new_error(const BaView& 
 // Returns this thread's share of the objective (pass 2's dCurrentError).
 // ---------------------------------------------------------------------------------------------------------------------
 #define BA_MFMA_FREE 5
-__device__ __attribute__((noinline)) double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int region, double sigma2, int nfree,
+BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int region, double sigma2, int nfree,
                                                         double* stg_ /* LDS [BA_WAVES][64][9] */, double* ured_ /* LDS [BA_WAVES][BA_MFMA_FREE][32] */) {
   const BaViewG v = ba_g(v_);
   const BaConfig cfg = cfg_;
@@ -623,7 +633,7 @@ __device__ __attribute__((noinline)) double ba_step_sweep(const BaView& v_, cons
 }
 
 // U, epsilon_a for more than BA_MFMA_FREE adjustable cameras: one wavefront per camera, lanes stride over the points
-__device__ __attribute__((noinline)) void ba_accum_U_generic(const BaView& v_, int nfree, int np) {
+BA_PHASE_FN void ba_accum_U_generic(const BaView& v_, int nfree, int np) {
   const BaViewG v = ba_g(v_);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int f = wave; f < nfree; f += BA_WAVES) {
@@ -653,7 +663,7 @@ __device__ __attribute__((noinline)) void ba_accum_U_generic(const BaView& v_, i
 }
 
 // S diagonal block + E of one adjustable camera (jni/Bundle.cc:362-396); called by one wavefront.  (More than BA_MFMA_FREE cameras.)
-__device__ __attribute__((noinline)) void ba_task_diag(const BaView& v_, int task, int np, int nS, double lambda) {
+BA_PHASE_FN void ba_task_diag(const BaView& v_, int task, int np, int nS, double lambda) {
   const BaViewG v = ba_g(v_);
   const int lane = threadIdx.x & 63;
   const int j = v.free_cams[task], row = v.cam_row[j];
@@ -690,7 +700,7 @@ __device__ __attribute__((noinline)) void ba_task_diag(const BaView& v_, int tas
 }
 
 // S off-diagonal block of one pair of adjustable cameras (:400-426); called by one wavefront.
-__device__ __attribute__((noinline)) void ba_task_pair(const BaView& v_, int task, int np, int nS, double lambda) {
+BA_PHASE_FN void ba_task_pair(const BaView& v_, int task, int np, int nS, double lambda) {
   const BaViewG v = ba_g(v_);
   const int lane = threadIdx.x & 63;
   int t = task, fj = 1;
@@ -739,7 +749,7 @@ __device__ __attribute__((noinline)) void ba_task_pair(const BaView& v_, int tas
 #define BA_MFMA_STAGE (4 * BA_MFMA_K * 16)              // doubles per wavefront: Y rows 0-15 / 16-31, W columns 0-15 / 16-31, each [K][16]
 static_assert(BA_MFMA_STAGE >= 32 * 32 && BA_MFMA_K % 4 == 0, "a wavefront's staging area also holds its 32 x 32 partial product");
 typedef double ba_v4d __attribute__((ext_vector_type(4)));
-__device__ __attribute__((noinline)) void ba_schur_mfma(const BaView& v_, int nfree, int np, int nS, double lambda, double* lds_) {
+BA_PHASE_FN void ba_schur_mfma(const BaView& v_, int nfree, int np, int nS, double lambda, double* lds_) {
   const BaViewG v = ba_g(v_);
   double AS3* lds = (double AS3*)lds_;                    // the staging buffer is LDS: ds_read / ds_write, not flat
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -837,7 +847,7 @@ __device__ __attribute__((noinline)) void ba_schur_mfma(const BaView& v_, int nf
 // map updates (jni/Bundle.cc:440-462, :484): trial point positions; returns this thread's share of |update|^2.
 // Up to BA_MFMA_FREE adjustable cameras: the lane mapping of ba_schur_mfma (one lane per (point, camera), contiguous F slots);
 // the first lane of a point adds the cameras' terms in camera order.
-__device__ __attribute__((noinline)) double ba_map_update(const BaView& v_, int nfree, int np, double lambda) {
+BA_PHASE_FN double ba_map_update(const BaView& v_, int nfree, int np, double lambda) {
   const BaViewG v = ba_g(v_);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double ssq = 0.0;
@@ -910,7 +920,7 @@ __device__ __attribute__((noinline)) double ba_map_update(const BaView& v_, int 
 // Erase the outliers of this step in LIST order (jni/Bundle.cc:517-528).  The slots are point-major, the reference's list is
 // whatever order AddMeas was called in: the bad slots mark their list index in an LDS bit map, then the map is expanded in
 // index order (popcount scan) into the (p, c) pairs.  Returns the new total of outlier measurements.
-__device__ __attribute__((noinline)) int ba_erase_outliers(const BaView& v_, int M, int nm, int nout, unsigned* bits /* LDS [(max_meas + 31) / 32] */, int* ired) {
+BA_PHASE_FN int ba_erase_outliers(const BaView& v_, int M, int nm, int nout, unsigned* bits /* LDS [(max_meas + 31) / 32] */, int* ired) {
   const BaViewG v = ba_g(v_);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nwords = (nm + 31) >> 5;

@@ -444,6 +444,35 @@ extern "C" int vslam_read_map_dump(const char* dir, double* pos3, int* level, in
   return VSLAM_OK;
 }
 
+// The state a dump holds -- positions of the good points, keyframe poses -- written back into the map it was saved from (same
+// keyframes, same points; the images, templates and measurements are not part of the reference's format): a checkpoint of what the
+// bundle adjustment has estimated.
+extern "C" int vslam_load_map(vslam_system* sys, int s, const char* dir) {
+  CHK_STREAM(sys, s);
+  TrackerState st;
+  int r = get_state(sys, s, &st); if (r) return r;
+  const int n = st.n_points, nk = st.n_kf;
+  std::vector<double> pos(3 * (size_t)(n > 0 ? n : 1)), poses(12 * (size_t)(nk > 0 ? nk : 1));
+  std::vector<int> lev((size_t)(n > 0 ? n : 1));
+  int np = 0, nkf = 0;
+  r = vslam_read_map_dump(dir, pos.data(), lev.data(), n, &np, poses.data(), nk, &nkf); if (r) return r;
+  std::vector<MapPointDev> p((size_t)(n > 0 ? n : 1));
+  if (n > 0) HIPCHK(hipMemcpy(p.data(), sys->map.pts + (size_t)s * sys->p.max_points, sizeof(MapPointDev) * n, hipMemcpyDeviceToHost));
+  int good = 0;
+  for (int i = 0; i < n; i++) if (!p[i].bad) good++;
+  if (np != good || nkf != nk) { vslam_set_error("load_map: the dump holds %d points and %d keyframes, the map %d good points and %d keyframes", np, nkf, good, nk); return VSLAM_E_STATE; }
+  int k = 0;
+  for (int i = 0; i < n; i++) {
+    if (p[i].bad) continue;
+    if (lev[k] != p[i].src_level) { vslam_set_error("load_map: point %d of the dump has source level %d, the map's %d", k, lev[k], p[i].src_level); return VSLAM_E_STATE; }
+    for (int q = 0; q < 3; q++) p[i].pos[q] = pos[3 * (size_t)k + q];
+    k++;
+  }
+  if (n > 0) HIPCHK(hipMemcpy(sys->map.pts + (size_t)s * sys->p.max_points, p.data(), sizeof(MapPointDev) * n, hipMemcpyHostToDevice));
+  for (int kf = 0; kf < nk; kf++) { r = vslam_map_set_keyframe_pose(sys, s, kf, poses.data() + 12 * (size_t)kf); if (r) return r; }
+  return VSLAM_OK;
+}
+
 extern "C" int vslam_get_message(vslam_system* sys, int s, char* buf, size_t cap) {
   CHK_STREAM(sys, s);
   TrackerState st;
