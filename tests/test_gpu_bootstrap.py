@@ -64,7 +64,7 @@ def test_trails_and_init_from_stereo_match_the_oracle(patch):
                 same_path = so.n_ba_trials == sg.n_ba_trials
                 rel_o = _mat(o.keyframe_pose(1)) @ np.linalg.inv(_mat(o.keyframe_pose(0)))
                 rel_g = _mat(g.keyframe_pose(s, 1)) @ np.linalg.inv(_mat(g.keyframe_pose(s, 0)))
-                assert np.abs(rel_o - rel_g).max() < (1e-5 if same_path else 2e-3), (tag, np.abs(rel_o - rel_g).max())
+                assert np.abs(rel_o - rel_g).max() < (1e-5 if same_path else 5e-3), (tag, np.abs(rel_o - rel_g).max())
                 po, pg = o.points(), g.points(s)
                 assert np.array_equal(po["bad"][:n0], pg["bad"][:n0]) or not same_path, tag
                 co = (_mat(o.keyframe_pose(0)) @ np.c_[po["pos"][:n0], np.ones(n0)].T).T

@@ -512,20 +512,22 @@ BA_PHASE_FN BaNewError ba_find_new_error(const BaView& v_, const BaConfig& cfg_,
 // Returns this thread's share of the objective (pass 2's dCurrentError).
 // ---------------------------------------------------------------------------------------------------------------------
 #define BA_MFMA_FREE 5
+#define BA_U_PAIRS ((BA_MFMA_FREE * 27 + 63) / 64)
+#define BA_SWEEP_STAGE 27   // doubles per lane of a wavefront's staging area in the step sweep (V / epsilon_b use 9 of them)
 BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int region, double sigma2, int nfree,
-                                                        double* stg_ /* LDS [BA_WAVES][64][9] */, double* ured_ /* LDS [BA_WAVES][BA_MFMA_FREE][32] */) {
+                                                        double* stg_ /* LDS [BA_WAVES][64][BA_SWEEP_STAGE] */, double* ured_ /* LDS [BA_WAVES][BA_MFMA_FREE][32] */) {
   const BaViewG v = ba_g(v_);
   const BaConfig cfg = cfg_;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double AS3* stg = (double AS3*)stg_ + wave * 64 * 9;
+  double AS3* stg = (double AS3*)stg_ + wave * 64 * BA_SWEEP_STAGE;
   const int nch = v.ch_n[region];
   const int AS1* ch = region ? v.chX : v.chF;
   const int AS1* off = region ? v.pt_offX : v.pt_offF;
   const int base = region ? v.ch_n[2] : 0;
   const bool fastU = region == 0 && nfree <= BA_MFMA_FREE;
   double cur = 0.0;
-  double uacc[BA_MFMA_FREE];
-  _Pragma("unroll") for (int f = 0; f < BA_MFMA_FREE; f++) uacc[f] = 0.0;
+  double uacc[BA_U_PAIRS];                                             // lane's sums: (camera, value) pairs lane, lane + 64, lane + 128
+  _Pragma("unroll") for (int k = 0; k < BA_U_PAIRS; k++) uacc[k] = 0.0;
   for (int k = wave; k < nch; k += BA_WAVES) {
     const int p0 = ch[k], p1 = ch[k + 1];
     const int a0 = base + off[p0], ntot = base + off[p1] - a0;         // <= 64 slots, or ONE point with more (a keyframe-rich map: fixed cameras)
@@ -605,29 +607,53 @@ BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int reg
       __builtin_amdgcn_wave_barrier();
     }
     // ---- U, epsilon_a ----
+    // Every lane leaves the 27 products of its own camera in LDS, the slots of a camera packed together in slot order (rank by
+    // ballots); lane (f, q) then adds value q of camera f's entries in that order.  (The predecessor multiplied the 27 products
+    // by a 0 / 1 mask for each of the five cameras and reduced each masked set across the wavefront: five times the products and
+    // ~1500 shuffle-address / select / bpermute instructions per chunk.)
     if (fastU) {
       double A[12];
       _Pragma("unroll") for (int q = 0; q < 12; q++) A[q] = 0.0;
       if (valid) ba_jac_A(c, d, A);
       const int ford = valid ? SL_FORD(info) : 255;
+      int offf[BA_MFMA_FREE], cntf[BA_MFMA_FREE];
+      int mypos = 0, run = 0;
       _Pragma("unroll") for (int f = 0; f < BA_MFMA_FREE; f++) {
-        if (f < nfree) {
-          const double m = ford == f ? 1.0 : 0.0;
-          double t32[32];
-          int q = 0;
-          _Pragma("unroll") for (int r = 0; r < 6; r++) for (int cc = 0; cc <= r; cc++) t32[q++] = m * (A[r] * A[cc] + A[6 + r] * A[6 + cc]);       // :40-47
-          _Pragma("unroll") for (int r = 0; r < 6; r++) t32[21 + r] = m * (A[r] * e0 + A[6 + r] * e1);
-          _Pragma("unroll") for (int r = 27; r < 32; r++) t32[r] = 0.0;
-          uacc[f] += wave_multi_sum<32>(t32);
+        const unsigned long long mk = __ballot(ford == f);
+        const int cf = (int)__popcll(mk);
+        if (ford == f) mypos = run + (int)__popcll(mk & ((1ull << lane) - 1ull));
+        offf[f] = run; cntf[f] = cf; run += cf;
+      }
+      if (ford < BA_MFMA_FREE) {
+        double AS3* dst = stg + mypos * 27;
+        int q = 0;
+        _Pragma("unroll") for (int r = 0; r < 6; r++) for (int cc = 0; cc <= r; cc++) dst[q++] = A[r] * A[cc] + A[6 + r] * A[6 + cc];       // :40-47
+        _Pragma("unroll") for (int r = 0; r < 6; r++) dst[21 + r] = A[r] * e0 + A[6 + r] * e1;
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_wave_barrier();
+      _Pragma("unroll") for (int k = 0; k < BA_U_PAIRS; k++) {
+        const int pid = lane + 64 * k;
+        if (pid < nfree * 27) {
+          const int f = pid / 27, q = pid - 27 * f;
+          int o = offf[0], cf = cntf[0];
+          _Pragma("unroll") for (int g = 1; g < BA_MFMA_FREE; g++) if (f == g) { o = offf[g]; cf = cntf[g]; }
+          double acc = uacc[k];
+          const double AS3* src = stg + o * 27 + q;
+          for (int r = 0; r < cf; r++) acc += src[r * 27];
+          uacc[k] = acc;
         }
       }
+      __builtin_amdgcn_wave_barrier();
     }
     }
   }
   if (fastU) {
     double AS3* ured = (double AS3*)ured_ + wave * BA_MFMA_FREE * 32;
-    const int vi = wave_multi_index<32>(lane);
-    _Pragma("unroll") for (int f = 0; f < BA_MFMA_FREE; f++) if (!(lane & 1) && f < nfree) ured[f * 32 + vi] = uacc[f];
+    _Pragma("unroll") for (int k = 0; k < BA_U_PAIRS; k++) {
+      const int pid = lane + 64 * k;
+      if (pid < nfree * 27) { const int f = pid / 27, q = pid - 27 * f; ured[f * 32 + q] = uacc[k]; }
+    }
   }
   return cur;
 }
@@ -994,7 +1020,7 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
   unsigned long long ba_t0 = clock64();
 #endif
   static_assert(sizeof(lds_buf) >= 2 * 4097 * sizeof(int) && sizeof(lds_buf) >= (65536 / 32) * sizeof(unsigned) &&
-                sizeof(lds_buf) >= (BA_WAVES * 64 * 9 + BA_WAVES * BA_MFMA_FREE * 32) * sizeof(double), "the LDS buffer serves the layout, the step sweep and the erase");
+                sizeof(lds_buf) >= (BA_WAVES * 64 * BA_SWEEP_STAGE + BA_WAVES * BA_MFMA_FREE * 32) * sizeof(double), "the LDS buffer serves the layout, the step sweep and the erase");
   ba_build_layout(v_, nc, np, ired, (int*)lds_buf);
   const int M = v.ch_n[3];                                            // slots = measurements of the list
   BA_STAMP(0);
@@ -1018,7 +1044,7 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
     const double sigma2 = sh_sigma2;
     BA_STAMP(2);
     // passes 1 + 2 (:209-321) in one sweep: weights, objective, V / epsilon_b, U / epsilon_a; A, B, W are re-derived by their consumers
-    double* stg = lds_buf; double* ured = lds_buf + BA_WAVES * 64 * 9;
+    double* stg = lds_buf; double* ured = lds_buf + BA_WAVES * 64 * BA_SWEEP_STAGE;
     double cur = ba_step_sweep(v_, cfg, 0, sigma2, nfree, stg, ured);
     __syncthreads();
     if (nfree <= BA_MFMA_FREE) {
