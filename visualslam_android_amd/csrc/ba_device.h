@@ -74,7 +74,7 @@ struct BaView {          // pointers already offset to one problem
   double* sl_cm; double* sl_d; double* sl_eps;
   int* pt_offF; int* pt_offX;                      // [max_pts + 1] slot offsets per point inside region F / region X
   unsigned long long* pt_maskF;                    // [max_pts] adjustable-camera ordinals that measure the point
-  int* chF; int* chX; int* ch_n;                   // chunk tables of the step sweep: first point of every chunk (<= 64 slots, whole points); ch_n[0..3] = chunks F, chunks X, slots F, slots
+  int* chF; int* chX; int* ch_n;                   // chunk tables of the step sweep: first slot (region-relative) of every chunk (<= 64 slots, whole points); ch_n[0..3] = chunks F, chunks X, slots F, slots
   double* S; double* E; double* cam_up;
   double* scratch;       // [max_meas] squared error per slot (+inf: not in the median)
   int* outl;             // [max_meas][2] (p, c) in erase order
@@ -443,11 +443,11 @@ BA_PHASE_FN void ba_build_layout(const BaView& v_, int nc, int np, int* ired, in
     const int* o = threadIdx.x == 0 ? oF : oX;
     int AS1* ch = threadIdx.x == 0 ? v.chF : v.chX;
     int k = 0, start = 0;
-    if (np > 0) ch[0] = 0;
+    if (np > 0) ch[0] = o[0];
     for (int p = 0; p < np; p++) {
-      if (o[p + 1] - o[start] > 64 && p > start) { ch[++k] = p; start = p; }   // a point with more than 64 slots stands alone
+      if (o[p + 1] - o[start] > 64 && p > start) { ch[++k] = o[p]; start = p; }   // a point with more than 64 slots stands alone
     }
-    if (np > 0) ch[++k] = np;
+    if (np > 0) ch[++k] = o[np];
     v.ch_n[threadIdx.x == 0 ? 0 : 1] = k;
     if (threadIdx.x == 0) { v.ch_n[2] = MF; v.ch_n[3] = MF + MX; }
   }
@@ -513,13 +513,16 @@ BA_PHASE_FN BaNewError ba_find_new_error(const BaView& v_, const BaConfig& cfg_,
 // ---------------------------------------------------------------------------------------------------------------------
 #define BA_MFMA_FREE 5
 #define BA_U_PAIRS ((BA_MFMA_FREE * 27 + 63) / 64)
+#define BA_MAX_CAMS_LDS 128  // cameras whose poses the step sweep keeps in LDS (= the most keyframes a map holds)
 #define BA_SWEEP_STAGE 27   // doubles per lane of a wavefront's staging area in the step sweep (V / epsilon_b use 9 of them)
 BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int region, double sigma2, int nfree,
-                                                        double* stg_ /* LDS [BA_WAVES][64][BA_SWEEP_STAGE] */, double* ured_ /* LDS [BA_WAVES][BA_MFMA_FREE][32] */) {
+                                                        double* stg_ /* LDS [BA_WAVES][64][BA_SWEEP_STAGE] */, double* ured_ /* LDS [BA_WAVES][BA_MFMA_FREE][32] */,
+                                                        const double* cams_ /* LDS: the committed camera poses, 12 doubles each */) {
   const BaViewG v = ba_g(v_);
   const BaConfig cfg = cfg_;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double AS3* stg = (double AS3*)stg_ + wave * 64 * BA_SWEEP_STAGE;
+  const double AS3* camL = (const double AS3*)cams_;
   const int nch = v.ch_n[region];
   const int AS1* ch = region ? v.chX : v.chF;
   const int AS1* off = region ? v.pt_offX : v.pt_offF;
@@ -528,9 +531,23 @@ BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int reg
   double cur = 0.0;
   double uacc[BA_U_PAIRS];                                             // lane's sums: (camera, value) pairs lane, lane + 64, lane + 128
   _Pragma("unroll") for (int k = 0; k < BA_U_PAIRS; k++) uacc[k] = 0.0;
+  // The static part of a slot (32 B) is loaded a chunk ahead: the chunk table entry of the next chunk at the top of this one,
+  // its slots' fields behind this chunk's projection -- a wavefront has at most one other wavefront on its SIMD to hide a
+  // dependent chain of global loads behind.  The camera poses come out of LDS.
+  struct SlotIn { int info, pt; double f0, f1, sn; };
+  auto load_in = [&](int a, int n, SlotIn& r) {
+    const int s = a + (lane < n ? lane : 0);
+    r.info = v.sl_info[s]; r.pt = v.sl_pt[s]; r.f0 = SL(sl_found, 0, s); r.f1 = SL(sl_found, 1, s); r.sn = v.sl_sin[s];
+  };
+  int cs0 = 0, cs1 = 0;
+  SlotIn cin; cin.info = 0; cin.pt = 0; cin.f0 = 0; cin.f1 = 0; cin.sn = 0;
+  if (wave < nch) { cs0 = ch[wave]; cs1 = ch[wave + 1]; load_in(base + cs0, min(64, cs1 - cs0), cin); }
   for (int k = wave; k < nch; k += BA_WAVES) {
-    const int p0 = ch[k], p1 = ch[k + 1];
-    const int a0 = base + off[p0], ntot = base + off[p1] - a0;         // <= 64 slots, or ONE point with more (a keyframe-rich map: fixed cameras)
+    const int a0 = base + cs0, ntot = cs1 - cs0;                       // <= 64 slots, or ONE point with more (a keyframe-rich map: fixed cameras)
+    const int kn = k + BA_WAVES;
+    int ns0 = 0, ns1 = 0;
+    if (kn < nch) { ns0 = ch[kn]; ns1 = ch[kn + 1]; }
+    SlotIn nin = cin;
     const int ntrip = (ntot + 63) >> 6;
     double carry[9];                                                   // lane 0: the running sums of a point that spans several trips
     _Pragma("unroll") for (int q = 0; q < 9; q++) carry[q] = 0.0;
@@ -538,10 +555,14 @@ BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int reg
     const int a = a0 + 64 * trip, n = min(64, ntot - 64 * trip);
     const bool act = lane < n;
     const int s = a + (act ? lane : 0);
-    const int info = v.sl_info[s], pt = v.sl_pt[s];
-    const double f0 = SL(sl_found, 0, s), f1 = SL(sl_found, 1, s), sn = v.sl_sin[s];
+    SlotIn in = cin;
+    if (trip > 0) load_in(a, n, in);
+    const int info = in.info, pt = in.pt;
+    const double f0 = in.f0, f1 = in.f1, sn = in.sn;
     const int cam = SL_CAM(info);
-    const Pose T = ba_load_pose(v.cam_pose + cam);
+    Pose T;
+    _Pragma("unroll") for (int q = 0; q < 9; q++) T.R[q] = camL[cam * 12 + q];
+    _Pragma("unroll") for (int q = 0; q < 3; q++) T.t[q] = camL[cam * 12 + 9 + q];
     double X[3];
     _Pragma("unroll") for (int q = 0; q < 3; q++) X[q] = v.pt_pos[3 * pt + q];
     int st = act ? SL_STATE(info) : MS_ERASED;
@@ -583,6 +604,7 @@ BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int reg
       _Pragma("unroll") for (int q = 0; q < 9; q++) stg[lane * 9 + q] = pr9[q];
       __builtin_amdgcn_s_waitcnt(0xC07F);
       __builtin_amdgcn_wave_barrier();
+      if (kn < nch && trip == (ntrip > 0 ? ntrip : 1) - 1) load_in(base + ns0, min(64, ns1 - ns0), nin);   // the next chunk's slots, behind the sums below
       const int ptprev = __shfl_up(pt, 1);
       if (act && (lane == 0 || ptprev != pt)) {                       // first slot of the point in this region (or in this trip of its slots)
         const int cnt = ntrip > 1 ? n : off[pt + 1] - off[pt];
@@ -647,6 +669,7 @@ BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int reg
       __builtin_amdgcn_wave_barrier();
     }
     }
+    cs0 = ns0; cs1 = ns1; cin = nin;
   }
   if (fastU) {
     double AS3* ured = (double AS3*)ured_ + wave * BA_MFMA_FREE * 32;
@@ -1020,7 +1043,7 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
   unsigned long long ba_t0 = clock64();
 #endif
   static_assert(sizeof(lds_buf) >= 2 * 4097 * sizeof(int) && sizeof(lds_buf) >= (65536 / 32) * sizeof(unsigned) &&
-                sizeof(lds_buf) >= (BA_WAVES * 64 * BA_SWEEP_STAGE + BA_WAVES * BA_MFMA_FREE * 32) * sizeof(double), "the LDS buffer serves the layout, the step sweep and the erase");
+                sizeof(lds_buf) >= (BA_WAVES * 64 * BA_SWEEP_STAGE + BA_WAVES * BA_MFMA_FREE * 32 + 12 * BA_MAX_CAMS_LDS) * sizeof(double), "the LDS buffer serves the layout, the step sweep and the erase");
   ba_build_layout(v_, nc, np, ired, (int*)lds_buf);
   const int M = v.ch_n[3];                                            // slots = measurements of the list
   BA_STAMP(0);
@@ -1044,8 +1067,10 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
     const double sigma2 = sh_sigma2;
     BA_STAMP(2);
     // passes 1 + 2 (:209-321) in one sweep: weights, objective, V / epsilon_b, U / epsilon_a; A, B, W are re-derived by their consumers
-    double* stg = lds_buf; double* ured = lds_buf + BA_WAVES * 64 * BA_SWEEP_STAGE;
-    double cur = ba_step_sweep(v_, cfg, 0, sigma2, nfree, stg, ured);
+    double* stg = lds_buf; double* ured = lds_buf + BA_WAVES * 64 * BA_SWEEP_STAGE; double* camsL = ured + BA_WAVES * BA_MFMA_FREE * 32;
+    for (int t = threadIdx.x; t < nc * 12; t += BA_THREADS) camsL[t] = ((const double AS1*)v.cam_pose)[t];   // Pose = R[9], t[3]
+    __syncthreads();
+    double cur = ba_step_sweep(v_, cfg, 0, sigma2, nfree, stg, ured, camsL);
     __syncthreads();
     if (nfree <= BA_MFMA_FREE) {
       for (int t = threadIdx.x; t < nfree * 27; t += BA_THREADS) {     // wave partials in wave order
@@ -1057,7 +1082,7 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
       }
     }
     BA_STAMP(3);
-    cur += ba_step_sweep(v_, cfg, 1, sigma2, nfree, stg, ured);
+    cur += ba_step_sweep(v_, cfg, 1, sigma2, nfree, stg, ured, camsL);
     cur = ba_block_sum(cur, red);
     if (threadIdx.x == 0) sh_cur_err = cur;
     __syncthreads();
