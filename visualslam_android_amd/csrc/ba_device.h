@@ -896,46 +896,87 @@ BA_PHASE_FN void ba_schur_mfma(const BaView& v_, int nfree, int np, int nS, doub
 // map updates (jni/Bundle.cc:440-462, :484): trial point positions; returns this thread's share of |update|^2.
 // Up to BA_MFMA_FREE adjustable cameras: the lane mapping of ba_schur_mfma (one lane per (point, camera), contiguous F slots);
 // the first lane of a point adds the cameras' terms in camera order.
-BA_PHASE_FN double ba_map_update(const BaView& v_, int nfree, int np, double lambda) {
+BA_PHASE_FN double ba_map_update(const BaView& v_, int nfree, int np, double lambda, double* lds_ /* LDS: staging [BA_WAVES][64][BA_SWEEP_STAGE], then poses and updates */) {
   const BaViewG v = ba_g(v_);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double ssq = 0.0;
   if (nfree > 0 && nfree <= BA_MFMA_FREE) {
-    const bool active = lane < BA_MFMA_PPC * nfree;
-    const int pl = active ? lane / nfree : 0, f = active ? lane - pl * nfree : 0;
-    const int j = v.free_cams[f];
-    double Rj[9], cu[6];
-    _Pragma("unroll") for (int k = 0; k < 9; k++) Rj[k] = v.cam_pose[j].R[k];
-    _Pragma("unroll") for (int k = 0; k < 6; k++) cu[k] = v.cam_up[v.cam_row[j] + k];
-    for (int p0 = wave * BA_MFMA_PPC; p0 < np; p0 += BA_WAVES * BA_MFMA_PPC) {
-      const int p = p0 + pl;
-      const bool inr = active && p < np;
-      MeasState ms;
-      ba_load_state(v, inr ? ba_slot_of(v, p, f) : -1, ms);
+    // One lane per F slot, a chunk of whole points per wavefront trip (the step sweep's tables), the slot's state loaded a chunk
+    // ahead; W^T * (camera update) of every slot goes to LDS and the first lane of each point adds its slots in order, then
+    // solves for the point (:440-462, :484).  Poses and camera updates come out of LDS.
+    double AS3* stg = (double AS3*)lds_ + wave * 64 * BA_SWEEP_STAGE;
+    double AS3* camL = (double AS3*)lds_ + BA_WAVES * 64 * BA_SWEEP_STAGE + BA_WAVES * BA_MFMA_FREE * 32;
+    double AS3* cuL = camL + 12 * BA_MAX_CAMS_LDS;
+    const int nc = v.res->n_cams;
+    for (int t = threadIdx.x; t < nc * 12; t += BA_THREADS) camL[t] = ((const double AS1*)v.cam_pose)[t];
+    for (int t = threadIdx.x; t < nfree * 6; t += BA_THREADS) cuL[t] = v.cam_up[v.cam_row[v.free_cams[t / 6]] + t % 6];
+    __syncthreads();
+    const int nch = v.ch_n[0];
+    const int AS1* ch = v.chF;
+    struct SIn { int info, pt; double cm[3], d[4]; };
+    auto load_in = [&](int a, int n, SIn& r) {
+      const int s = a + (lane < n ? lane : 0);
+      r.info = v.sl_info[s]; r.pt = v.sl_pt[s];
+      _Pragma("unroll") for (int q = 0; q < 3; q++) r.cm[q] = SL(sl_cm, q, s);
+      _Pragma("unroll") for (int q = 0; q < 4; q++) r.d[q] = SL(sl_d, q, s);
+    };
+    int cs0 = 0, cs1 = 0;
+    SIn cin; cin.info = 0; cin.pt = 0;
+    _Pragma("unroll") for (int q = 0; q < 3; q++) cin.cm[q] = 0;
+    _Pragma("unroll") for (int q = 0; q < 4; q++) cin.d[q] = 0;
+    if (wave < nch) { cs0 = ch[wave]; cs1 = ch[wave + 1]; load_in(cs0, cs1 - cs0, cin); }
+    for (int k = wave; k < nch; k += BA_WAVES) {
+      const int n = cs1 - cs0;                                         // <= 64: a point has at most BA_MFMA_FREE slots in region F
+      const int kn = k + BA_WAVES;
+      int ns0 = 0, ns1 = 0;
+      if (kn < nch) { ns0 = ch[kn]; ns1 = ch[kn + 1]; }
+      SIn nin = cin;
+      const bool act = lane < n;
+      const int pt = cin.pt;
       double t[3] = {0, 0, 0};
-      if (ms.st == MS_OK) {
-        double W[18];
+      if (act && SL_STATE(cin.info) == MS_OK) {
+        MeasState ms;
+        _Pragma("unroll") for (int q = 0; q < 3; q++) ms.cm[q] = cin.cm[q];
+        _Pragma("unroll") for (int q = 0; q < 4; q++) ms.d[q] = cin.d[q];
+        ms.st = MS_OK;
+        const int cam = SL_CAM(cin.info), f = SL_FORD(cin.info);
+        double Rj[9], cu[6], W[18];
+        _Pragma("unroll") for (int q = 0; q < 9; q++) Rj[q] = camL[cam * 12 + q];
+        _Pragma("unroll") for (int q = 0; q < 6; q++) cu[q] = cuL[f * 6 + q];
         ba_jac_W(ms, Rj, W);
-        _Pragma("unroll") for (int c = 0; c < 3; c++) { double s = 0; for (int r = 0; r < 6; r++) s += W[r * 3 + c] * cu[r]; t[c] = s; }
+        _Pragma("unroll") for (int c = 0; c < 3; c++) { double sx = 0; for (int r = 0; r < 6; r++) sx += W[r * 3 + c] * cu[r]; t[c] = sx; }
       }
-      double sum[3] = {0, 0, 0};
-      for (int ff = 0; ff < nfree; ff++) {
-        const int src = pl * nfree + ff;
-        const double a0 = __shfl(t[0], src), a1 = __shfl(t[1], src), a2 = __shfl(t[2], src);
-        // a camera that does not measure the point (or whose measurement is bad) contributes nothing, as in the reference's loop
-        const bool has = __shfl(ms.st == MS_OK ? 1 : 0, src) != 0;
-        if (has) { sum[0] += a0; sum[1] += a1; sum[2] += a2; }
-      }
-      if (inr && f == 0) {
-        const double eb[3] = {PT(pt_eb, 0, p), PT(pt_eb, 1, p), PT(pt_eb, 2, p)};
+      _Pragma("unroll") for (int c = 0; c < 3; c++) stg[lane * 3 + c] = t[c];
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_wave_barrier();
+      if (kn < nch) load_in(ns0, ns1 - ns0, nin);
+      const int ptprev = __shfl_up(pt, 1);
+      if (act && (lane == 0 || ptprev != pt)) {
+        const int cnt = v.pt_offF[pt + 1] - v.pt_offF[pt];
+        double sum[3] = {0, 0, 0};
+        for (int j = 0; j < cnt; j++) { _Pragma("unroll") for (int c = 0; c < 3; c++) sum[c] += stg[(lane + j) * 3 + c]; }
+        const double eb[3] = {PT(pt_eb, 0, pt), PT(pt_eb, 1, pt), PT(pt_eb, 2, pt)};
         double Vi[9];
-        ba_vstar_inv(v, p, lambda, Vi);
+        ba_vstar_inv(v, pt, lambda, Vi);
         const double x[3] = {eb[0] - sum[0], eb[1] - sum[1], eb[2] - sum[2]};
         _Pragma("unroll") for (int r = 0; r < 3; r++) {
           const double u = Vi[r * 3] * x[0] + Vi[r * 3 + 1] * x[1] + Vi[r * 3 + 2] * x[2];
           ssq += u * u;
-          v.pt_new[3 * p + r] = v.pt_pos[3 * p + r] + u;               // :484
+          v.pt_new[3 * pt + r] = v.pt_pos[3 * pt + r] + u;             // :484
         }
+      }
+      __builtin_amdgcn_wave_barrier();
+      cs0 = ns0; cs1 = ns1; cin = nin;
+    }
+    for (int p = threadIdx.x; p < np; p += BA_THREADS) {               // points no adjustable camera measures: the update is V*^-1 epsilon_b
+      if (v.pt_offF[p + 1] - v.pt_offF[p] > 0) continue;
+      const double eb[3] = {PT(pt_eb, 0, p), PT(pt_eb, 1, p), PT(pt_eb, 2, p)};
+      double Vi[9];
+      ba_vstar_inv(v, p, lambda, Vi);
+      _Pragma("unroll") for (int r = 0; r < 3; r++) {
+        const double u = Vi[r * 3] * eb[0] + Vi[r * 3 + 1] * eb[1] + Vi[r * 3 + 2] * eb[2];
+        ssq += u * u;
+        v.pt_new[3 * p + r] = v.pt_pos[3 * p + r] + u;
       }
     }
     return ssq;
@@ -1043,7 +1084,7 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
   unsigned long long ba_t0 = clock64();
 #endif
   static_assert(sizeof(lds_buf) >= 2 * 4097 * sizeof(int) && sizeof(lds_buf) >= (65536 / 32) * sizeof(unsigned) &&
-                sizeof(lds_buf) >= (BA_WAVES * 64 * BA_SWEEP_STAGE + BA_WAVES * BA_MFMA_FREE * 32 + 12 * BA_MAX_CAMS_LDS) * sizeof(double), "the LDS buffer serves the layout, the step sweep and the erase");
+                sizeof(lds_buf) >= (BA_WAVES * 64 * BA_SWEEP_STAGE + BA_WAVES * BA_MFMA_FREE * 32 + 12 * BA_MAX_CAMS_LDS + 6 * BA_MFMA_FREE) * sizeof(double), "the LDS buffer serves the layout, the step sweep and the erase");
   ba_build_layout(v_, nc, np, ired, (int*)lds_buf);
   const int M = v.ch_n[3];                                            // slots = measurements of the list
   BA_STAMP(0);
@@ -1121,7 +1162,7 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
       __syncthreads();
       BA_STAMP(8);
       // map updates (:440-462)
-      double ssq = ba_map_update(v_, nfree, np, lambda);
+      double ssq = ba_map_update(v_, nfree, np, lambda, lds_buf);
       for (int t = threadIdx.x; t < nS; t += BA_THREADS) ssq += v.cam_up[t] * v.cam_up[t];
       ssq = ba_block_sum(ssq, red);                                    // :467-470
       for (int j = threadIdx.x; j < nc; j += BA_THREADS) {             // :476-482
