@@ -461,10 +461,17 @@ BA_PHASE_FN void ba_build_layout(const BaView& v_, int nc, int np, int* ired, in
 // number is returned.  Reads the static 32 B of a slot, writes 8 B.
 // ---------------------------------------------------------------------------------------------------------------------
 struct BaNewError { double ne; int nvalid; };
-BA_PHASE_FN BaNewError ba_find_new_error(const BaView& v_, const BaConfig& cfg_, int M, double sigma2, int trial) {
+BA_PHASE_FN BaNewError ba_find_new_error(const BaView& v_, const BaConfig& cfg_, int M, double sigma2, int trial, double* lds_ /* LDS: 12 doubles per camera */) {
   const BaViewG v = ba_g(v_);
   const BaConfig cfg = cfg_;
-  const Pose AS1* cams = trial ? v.cam_new : v.cam_pose;
+  const Pose AS1* camsG = trial ? v.cam_new : v.cam_pose;
+  double AS3* camL = (double AS3*)lds_;                                // the poses out of LDS: one dependent global round trip less per slot
+  {
+    const int nc = v.res->n_cams;
+    __syncthreads();
+    for (int t = threadIdx.x; t < nc * 12; t += BA_THREADS) camL[t] = ((const double AS1*)camsG)[t];
+    __syncthreads();
+  }
   const double AS1* pts = trial ? v.pt_new : v.pt_pos;
   double ne = 0.0;
   int nv = 0;
@@ -478,7 +485,7 @@ BA_PHASE_FN BaNewError ba_find_new_error(const BaView& v_, const BaConfig& cfg_,
     }
     Pose T[BA_ILP_PROJ]; double X[BA_ILP_PROJ][3];
     _Pragma("unroll") for (int u = 0; u < BA_ILP_PROJ; u++) {
-      T[u] = ba_load_pose(cams + SL_CAM(info[u]));
+      { const int cj = SL_CAM(info[u]); _Pragma("unroll") for (int q = 0; q < 9; q++) T[u].R[q] = camL[cj * 12 + q]; _Pragma("unroll") for (int q = 0; q < 3; q++) T[u].t[q] = camL[cj * 12 + 9 + q]; }
       _Pragma("unroll") for (int k = 0; k < 3; k++) X[u][k] = pts[3 * mp[u] + k];
     }
     _Pragma("unroll") for (int u = 0; u < BA_ILP_PROJ; u++) {
@@ -1095,7 +1102,7 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
     const bool cached = sh_cache_valid != 0;                       // the previous step was accepted: FindNewError has left them
     int nvalid;
     if (cached) nvalid = sh_next_nvalid;
-    else nvalid = ba_block_sum_i(ba_find_new_error(v_, cfg, M, 1.0, 0).nvalid, ired);
+    else nvalid = ba_block_sum_i(ba_find_new_error(v_, cfg, M, 1.0, 0, lds_buf).nvalid, ired);
     BA_STAMP(1);
     if (nvalid == 0) { if (threadIdx.x == 0) sh_error = 1; __syncthreads(); break; }
     {                                                              // :220-227 Tukey sigma, clamped
@@ -1177,7 +1184,7 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
       __syncthreads();
       BA_STAMP(9);
       // FindNewError (:537-561)
-      const BaNewError fne = ba_find_new_error(v_, cfg, M, sigma2, 1);
+      const BaNewError fne = ba_find_new_error(v_, cfg, M, sigma2, 1, lds_buf);
       const double ne = ba_block_sum(fne.ne, red);
       const int nv_next = ba_block_sum_i(fne.nvalid, ired);
       BA_STAMP(10);
