@@ -383,6 +383,8 @@ BA_PHASE_FN bool ba_solve_wave(const BaView& v_, int n) {
 // ---------------------------------------------------------------------------------------------------------------------
 #define SL_FORD(info) (((info) >> 16) & 255)                 // ordinal of the (adjustable) camera, 255 for a fixed one
 #define SL_MAKE(cam, st, ford) ((cam) | ((st) << 8) | ((ford) << 16))
+#define SL_HASF (1 << 24)                                     // X slot of a point that adjustable cameras measure too (its V / epsilon_b sums continue the F sweep's)
+#define SL_HAS_F(info) (((info) >> 24) & 1)
 #define SL_WITH_STATE(info, st) (((info) & ~(3 << 8)) | ((st) << 8))
 
 // a[0..n) counts -> exclusive offsets, a[n] = total (returned); all threads call
@@ -429,7 +431,7 @@ BA_PHASE_FN void ba_build_layout(const BaView& v_, int nc, int np, int* ired, in
       if (i < 0) continue;
       const bool fx = v.cam_fixed[c] != 0;
       const int s = fx ? kx++ : kf++;
-      v.sl_info[s] = SL_MAKE(c, MS_OK, fx ? 255 : v.cam_row[c] / 6);
+      v.sl_info[s] = SL_MAKE(c, MS_OK, fx ? 255 : v.cam_row[c] / 6) | (fx && v.pt_offF[p + 1] - v.pt_offF[p] > 0 ? SL_HASF : 0);
       v.sl_pt[s] = p; v.sl_logical[s] = i;
       SL(sl_found, 0, s) = MS(ms_found, 0, i); SL(sl_found, 1, s) = MS(ms_found, 1, i);
       v.sl_sin[s] = v.ms_sin[i];
@@ -532,7 +534,6 @@ BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int reg
   const double AS3* camL = (const double AS3*)cams_;
   const int nch = v.ch_n[region];
   const int AS1* ch = region ? v.chX : v.chF;
-  const int AS1* off = region ? v.pt_offX : v.pt_offF;
   const int base = region ? v.ch_n[2] : 0;
   const bool fastU = region == 0 && nfree <= BA_MFMA_FREE;
   double cur = 0.0;
@@ -572,6 +573,12 @@ BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int reg
     _Pragma("unroll") for (int q = 0; q < 3; q++) T.t[q] = camL[cam * 12 + 9 + q];
     double X[3];
     _Pragma("unroll") for (int q = 0; q < 3; q++) X[q] = v.pt_pos[3 * pt + q];
+    // region X continues the sums the F sweep left for the point: loaded now (every lane of the point, one broadcast access),
+    // used by the point's first lane after the projection
+    const bool cont = region == 1 && SL_HAS_F(info);
+    double vprev[9];
+    _Pragma("unroll") for (int q = 0; q < 6; q++) vprev[q] = cont ? PT(pt_V, q, pt) : 0.0;
+    _Pragma("unroll") for (int q = 0; q < 3; q++) vprev[6 + q] = cont ? PT(pt_eb, q, pt) : 0.0;
     int st = act ? SL_STATE(info) : MS_ERASED;
     bool valid = false;
     double c[3] = {0, 0, 1}, d[4] = {0, 0, 0, 0}, e0 = 0, e1 = 0;
@@ -613,13 +620,14 @@ BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int reg
       __builtin_amdgcn_wave_barrier();
       if (kn < nch && trip == (ntrip > 0 ? ntrip : 1) - 1) load_in(base + ns0, min(64, ns1 - ns0), nin);   // the next chunk's slots, behind the sums below
       const int ptprev = __shfl_up(pt, 1);
-      if (act && (lane == 0 || ptprev != pt)) {                       // first slot of the point in this region (or in this trip of its slots)
-        const int cnt = ntrip > 1 ? n : off[pt + 1] - off[pt];
+      const bool leader = act && (lane == 0 || ptprev != pt);          // first slot of the point in this region (or in this trip of its slots)
+      const unsigned long long lm = __ballot(leader);
+      if (leader) {
+        const unsigned long long above = lane < 63 ? lm >> (lane + 1) : 0ull;   // the point's slots end where the next point's begin
+        const int cnt = above ? (int)__ffsll((long long)above) : n - lane;
         double acc[9];
-        const bool cont = region == 1 && v.pt_offF[pt + 1] - v.pt_offF[pt] > 0;   // continue the sum the F sweep left
         if (trip == 0) {
-          _Pragma("unroll") for (int q = 0; q < 6; q++) acc[q] = cont ? PT(pt_V, q, pt) : 0.0;
-          _Pragma("unroll") for (int q = 0; q < 3; q++) acc[6 + q] = cont ? PT(pt_eb, q, pt) : 0.0;
+          _Pragma("unroll") for (int q = 0; q < 9; q++) acc[q] = vprev[q];
         } else {
           _Pragma("unroll") for (int q = 0; q < 9; q++) acc[q] = carry[q];
         }
@@ -958,13 +966,23 @@ BA_PHASE_FN double ba_map_update(const BaView& v_, int nfree, int np, double lam
       __builtin_amdgcn_wave_barrier();
       if (kn < nch) load_in(ns0, ns1 - ns0, nin);
       const int ptprev = __shfl_up(pt, 1);
-      if (act && (lane == 0 || ptprev != pt)) {
-        const int cnt = v.pt_offF[pt + 1] - v.pt_offF[pt];
+      const bool leader = act && (lane == 0 || ptprev != pt);
+      const unsigned long long lm = __ballot(leader);
+      // the point's V and epsilon_b for its first lane: requested by every lane of the point (one broadcast access) before the sums
+      double eb[3], vq[6];
+      _Pragma("unroll") for (int q = 0; q < 3; q++) eb[q] = PT(pt_eb, q, pt);
+      _Pragma("unroll") for (int q = 0; q < 6; q++) vq[q] = PT(pt_V, q, pt);
+      if (leader) {
+        const unsigned long long above = lane < 63 ? lm >> (lane + 1) : 0ull;
+        const int cnt = above ? (int)__ffsll((long long)above) : n - lane;
         double sum[3] = {0, 0, 0};
         for (int j = 0; j < cnt; j++) { _Pragma("unroll") for (int c = 0; c < 3; c++) sum[c] += stg[(lane + j) * 3 + c]; }
-        const double eb[3] = {PT(pt_eb, 0, pt), PT(pt_eb, 1, pt), PT(pt_eb, 2, pt)};
         double Vi[9];
-        ba_vstar_inv(v, pt, lambda, Vi);
+        if (vq[0] * vq[2] * vq[5] == 0) { _Pragma("unroll") for (int q = 0; q < 9; q++) Vi[q] = 0.0; }   // ba_vstar_inv on the values in hand
+        else {
+          const double Vs[9] = {vq[0] * (1.0 + lambda), vq[1], vq[3], vq[1], vq[2] * (1.0 + lambda), vq[4], vq[3], vq[4], vq[5] * (1.0 + lambda)};
+          inv3(Vs, Vi);
+        }
         const double x[3] = {eb[0] - sum[0], eb[1] - sum[1], eb[2] - sum[2]};
         _Pragma("unroll") for (int r = 0; r < 3; r++) {
           const double u = Vi[r * 3] * x[0] + Vi[r * 3 + 1] * x[1] + Vi[r * 3 + 2] * x[2];
