@@ -631,9 +631,13 @@ BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int reg
         } else {
           _Pragma("unroll") for (int q = 0; q < 9; q++) acc[q] = carry[q];
         }
-        for (int j = 0; j < cnt; j++) {
-          _Pragma("unroll") for (int q = 0; q < 9; q++) acc[q] += stg[(lane + j) * 9 + q];
+        int j = 0;
+        for (; j + 2 <= cnt; j += 2) {                                  // two slots' entries in flight, added in slot order
+          double x0[9], x1[9];
+          _Pragma("unroll") for (int q = 0; q < 9; q++) { x0[q] = stg[(lane + j) * 9 + q]; x1[q] = stg[(lane + j + 1) * 9 + q]; }
+          _Pragma("unroll") for (int q = 0; q < 9; q++) acc[q] = (acc[q] + x0[q]) + x1[q];
         }
+        if (j < cnt) { _Pragma("unroll") for (int q = 0; q < 9; q++) acc[q] += stg[(lane + j) * 9 + q]; }
         _Pragma("unroll") for (int q = 0; q < 9; q++) carry[q] = acc[q];
         if (trip == ntrip - 1 || ntrip <= 1) {
           // lower triangle of V: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) -> components 0..5
@@ -677,7 +681,17 @@ BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int reg
           _Pragma("unroll") for (int g = 1; g < BA_MFMA_FREE; g++) if (f == g) { o = offf[g]; cf = cntf[g]; }
           double acc = uacc[k];
           const double AS3* src = stg + o * 27 + q;
-          for (int r = 0; r < cf; r++) acc += src[r * 27];
+          int r = 0;
+          for (; r + 8 <= cf; r += 8) {                                 // eight LDS reads in flight, the additions in slot order
+            double x[8];
+            _Pragma("unroll") for (int u = 0; u < 8; u++) x[u] = src[(r + u) * 27];
+            _Pragma("unroll") for (int u = 0; u < 8; u++) acc += x[u];
+          }
+          {
+            double x[8];
+            _Pragma("unroll") for (int u = 0; u < 8; u++) x[u] = r + u < cf ? src[(r + u) * 27] : 0.0;
+            _Pragma("unroll") for (int u = 0; u < 8; u++) if (r + u < cf) acc += x[u];
+          }
           uacc[k] = acc;
         }
       }
