@@ -33,7 +33,10 @@
 #else
 #define BA_PHASE_FN __device__ __attribute__((noinline))
 #endif
-#define BA_THREADS 256  // 4 waves; with amdgpu_waves_per_eu(2,2) on the kernel two problems share a CU (measured: 512 x 1 -4 %, 128 x 4 -4 %)
+#ifndef BA_THREADS
+#define BA_THREADS 256
+#endif
+// 4 waves; with amdgpu_waves_per_eu(2,2) on the kernel two problems share a CU (measured: 512 x 1 -4 %, 128 x 4 -4 %)
 #define BA_LDS_N 60      // reduced camera systems up to 60 x 60 (10 adjustable cameras) are solved in LDS
 #define BA_WAVES (BA_THREADS / 64)
 #define BA_ILP_PROJ 4   // projection passes: 4 measurements in flight (1 -> 4: -31 % on FindNewError once the view pointers were global and scalar; 6 spills: 5x slower)
@@ -1100,7 +1103,11 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
   __shared__ int hist[768];
   __shared__ unsigned long long sel[1];
   __shared__ double sh_lambda, sh_factor, sh_sigma2, sh_cur_err, sh_new_err;
-  __shared__ double lds_buf[BA_WAVES * BA_MFMA_STAGE > BA_LDS_N * (BA_LDS_N + 1) ? BA_WAVES * BA_MFMA_STAGE : BA_LDS_N * (BA_LDS_N + 1)];
+  constexpr int LDS_MFMA = BA_WAVES * BA_MFMA_STAGE, LDS_SOLVE = BA_LDS_N * (BA_LDS_N + 1);
+  constexpr int LDS_SWEEP = BA_WAVES * 64 * BA_SWEEP_STAGE + BA_WAVES * BA_MFMA_FREE * 32 + 12 * BA_MAX_CAMS_LDS + 6 * BA_MFMA_FREE;
+  constexpr int LDS_LAYOUT = (2 * 4097 * (int)sizeof(int) + 7) / 8;
+  constexpr int LDS_A = LDS_MFMA > LDS_SOLVE ? LDS_MFMA : LDS_SOLVE, LDS_B = LDS_SWEEP > LDS_LAYOUT ? LDS_SWEEP : LDS_LAYOUT;
+  __shared__ double lds_buf[LDS_A > LDS_B ? LDS_A : LDS_B];
   double* lds_A = lds_buf;
   __shared__ int sh_converged, sh_hitmax, sh_counter, sh_accepted, sh_error, sh_nout, sh_cache_valid, sh_next_nvalid;
   BaResult AS1* R = v.res;
