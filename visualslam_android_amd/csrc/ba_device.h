@@ -552,7 +552,16 @@ BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int reg
   };
   int cs0 = 0, cs1 = 0;
   SlotIn cin; cin.info = 0; cin.pt = 0; cin.f0 = 0; cin.f1 = 0; cin.sn = 0;
-  if (wave < nch) { cs0 = ch[wave]; cs1 = ch[wave + 1]; load_in(base + cs0, min(64, cs1 - cs0), cin); }
+  double cX[3] = {0, 0, 0};                                            // the point of this lane's slot: requested at the end of the previous chunk
+  if (wave < nch) {
+    cs0 = ch[wave]; cs1 = ch[wave + 1]; load_in(base + cs0, min(64, cs1 - cs0), cin);
+    _Pragma("unroll") for (int q = 0; q < 3; q++) cX[q] = v.pt_pos[3 * cin.pt + q];
+  }
+  // What a slot leaves for the later phases of the step: its state (every region); the weighted camera derivatives d of an F slot
+  // (the reduced camera system and the map update re-derive W from them; v3Cam is re-derived there from the point and the pose);
+  // v3Cam and epsilon too when more than BA_MFMA_FREE cameras are adjusted (the wave-per-block forms read them).  An X slot is
+  // consumed here and now: nothing else is stored for it.
+  const bool storeD = region == 0, storeAll = region == 0 && !fastU;
   for (int k = wave; k < nch; k += BA_WAVES) {
     const int a0 = base + cs0, ntot = cs1 - cs0;                       // <= 64 slots, or ONE point with more (a keyframe-rich map: fixed cameras)
     const int kn = k + BA_WAVES;
@@ -575,7 +584,8 @@ BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int reg
     _Pragma("unroll") for (int q = 0; q < 9; q++) T.R[q] = camL[cam * 12 + q];
     _Pragma("unroll") for (int q = 0; q < 3; q++) T.t[q] = camL[cam * 12 + 9 + q];
     double X[3];
-    _Pragma("unroll") for (int q = 0; q < 3; q++) X[q] = v.pt_pos[3 * pt + q];
+    _Pragma("unroll") for (int q = 0; q < 3; q++) X[q] = cX[q];
+    if (trip > 0) { _Pragma("unroll") for (int q = 0; q < 3; q++) X[q] = v.pt_pos[3 * pt + q]; }
     // region X continues the sums the F sweep left for the point: loaded now (every lane of the point, one broadcast access),
     // used by the point's first lane after the projection
     const bool cont = region == 1 && SL_HAS_F(info);
@@ -587,7 +597,7 @@ BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int reg
     double c[3] = {0, 0, 1}, d[4] = {0, 0, 0, 0}, e0 = 0, e1 = 0;
     if (st != MS_ERASED) {
       pose_xform(T, X, c);
-      SL(sl_cm, 0, s) = c[0]; SL(sl_cm, 1, s) = c[1]; SL(sl_cm, 2, s) = c[2];
+      if (storeAll) { SL(sl_cm, 0, s) = c[0]; SL(sl_cm, 1, s) = c[1]; SL(sl_cm, 2, s) = c[2]; }
       if (c[2] <= 0) { st = MS_BAD; cur += 1.0; }                       // pass 1: bBad (:186-189); pass 2: :243-246
       else {
         const CamProj pr = cam_project(cfg.cam, c[0] / c[2], c[1] / c[2]);
@@ -597,12 +607,12 @@ BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int reg
         const double e2 = e0 * e0 + e1 * e1;
         const double dWeight = tukey_sqrt_weight(e2, sigma2);
         e0 *= dWeight; e1 *= dWeight;
-        SL(sl_eps, 0, s) = e0; SL(sl_eps, 1, s) = e1;
+        if (storeAll) { SL(sl_eps, 0, s) = e0; SL(sl_eps, 1, s) = e1; }
         if (dWeight == 0) { st = MS_BAD; cur += 1.0; }
         else {
           st = MS_OK; valid = true;
           cur += tukey_objective(e2, sigma2);
-          _Pragma("unroll") for (int q = 0; q < 4; q++) { d[q] = sn * (dWeight * dd[q]); SL(sl_d, q, s) = d[q]; }   // weighted from here on
+          _Pragma("unroll") for (int q = 0; q < 4; q++) { d[q] = sn * (dWeight * dd[q]); if (storeD) SL(sl_d, q, s) = d[q]; }   // weighted from here on
         }
       }
       v.sl_info[s] = SL_WITH_STATE(info, st);
@@ -701,6 +711,7 @@ BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int reg
       __builtin_amdgcn_wave_barrier();
     }
     }
+    if (kn < nch) { _Pragma("unroll") for (int q = 0; q < 3; q++) cX[q] = v.pt_pos[3 * nin.pt + q]; }   // the next chunk's points (its slot fields have arrived by now)
     cs0 = ns0; cs1 = ns1; cin = nin;
   }
   if (fastU) {
@@ -839,8 +850,20 @@ BA_PHASE_FN void ba_schur_mfma(const BaView& v_, int nfree, int np, int nS, doub
   const bool active = lane < BA_MFMA_PPC * nfree;
   const int pl = active ? lane / nfree : 0, f = active ? lane - pl * nfree : 0;
   const int j = v.free_cams[f];
-  double Rj[9];
+  double Rj[9], tj[3];
   _Pragma("unroll") for (int k = 0; k < 9; k++) Rj[k] = v.cam_pose[j].R[k];
+  _Pragma("unroll") for (int k = 0; k < 3; k++) tj[k] = v.cam_pose[j].t[k];
+  // the state of a slot as this phase needs it: the stored weighted derivatives; v3Cam = camera j applied to the point (the same
+  // expression, the same bits as in the sweep that produced d)
+  auto load_state_x = [&](int slot, int pc, MeasState& m) {
+    const int ic = slot < 0 ? 0 : slot;
+    m.st = slot < 0 ? MS_ERASED : SL_STATE(v.sl_info[ic]);
+    _Pragma("unroll") for (int q = 0; q < 4; q++) m.d[q] = SL(sl_d, q, ic);
+    const double X[3] = {v.pt_pos[3 * pc], v.pt_pos[3 * pc + 1], v.pt_pos[3 * pc + 2]};
+    m.cm[0] = tj[0] + (Rj[0] * X[0] + Rj[1] * X[1] + Rj[2] * X[2]);
+    m.cm[1] = tj[1] + (Rj[3] * X[0] + Rj[4] * X[1] + Rj[5] * X[2]);
+    m.cm[2] = tj[2] + (Rj[6] * X[0] + Rj[7] * X[1] + Rj[8] * X[2]);
+  };
   ba_v4d d00 = {0, 0, 0, 0}, d10 = {0, 0, 0, 0}, d11 = {0, 0, 0, 0};
   __builtin_amdgcn_s_waitcnt(0);
   __builtin_amdgcn_wave_barrier();
@@ -851,7 +874,7 @@ BA_PHASE_FN void ba_schur_mfma(const BaView& v_, int nfree, int np, int nS, doub
   MeasState ms_n; double V_n[6], eb_n[3];
   {
     const int pc = pfirst + pl < np ? pfirst + pl : np - 1;
-    ba_load_state(v, slot_at(pfirst), ms_n);
+    load_state_x(slot_at(pfirst), pc, ms_n);
     _Pragma("unroll") for (int k = 0; k < 6; k++) V_n[k] = PT(pt_V, k, pc);
     _Pragma("unroll") for (int k = 0; k < 3; k++) eb_n[k] = PT(pt_eb, k, pc);
   }
@@ -863,7 +886,7 @@ BA_PHASE_FN void ba_schur_mfma(const BaView& v_, int nfree, int np, int nS, doub
     _Pragma("unroll") for (int k = 0; k < 3; k++) eb[k] = eb_n[k];
     {
       const int pn = p0 + STRIDE + pl, pc = pn < np ? pn : np - 1;
-      ba_load_state(v, slot_at(p0 + STRIDE), ms_n);
+      load_state_x(slot_at(p0 + STRIDE), pc, ms_n);
       _Pragma("unroll") for (int k = 0; k < 6; k++) V_n[k] = PT(pt_V, k, pc);
       _Pragma("unroll") for (int k = 0; k < 3; k++) eb_n[k] = PT(pt_eb, k, pc);
     }
@@ -945,18 +968,20 @@ BA_PHASE_FN double ba_map_update(const BaView& v_, int nfree, int np, double lam
     __syncthreads();
     const int nch = v.ch_n[0];
     const int AS1* ch = v.chF;
-    struct SIn { int info, pt; double cm[3], d[4]; };
+    struct SIn { int info, pt; double d[4]; };
     auto load_in = [&](int a, int n, SIn& r) {
       const int s = a + (lane < n ? lane : 0);
       r.info = v.sl_info[s]; r.pt = v.sl_pt[s];
-      _Pragma("unroll") for (int q = 0; q < 3; q++) r.cm[q] = SL(sl_cm, q, s);
       _Pragma("unroll") for (int q = 0; q < 4; q++) r.d[q] = SL(sl_d, q, s);
     };
     int cs0 = 0, cs1 = 0;
     SIn cin; cin.info = 0; cin.pt = 0;
-    _Pragma("unroll") for (int q = 0; q < 3; q++) cin.cm[q] = 0;
     _Pragma("unroll") for (int q = 0; q < 4; q++) cin.d[q] = 0;
-    if (wave < nch) { cs0 = ch[wave]; cs1 = ch[wave + 1]; load_in(cs0, cs1 - cs0, cin); }
+    double cX[3] = {0, 0, 0};                                          // the slot's point: v3Cam is re-derived from it, and the point's first lane updates it
+    if (wave < nch) {
+      cs0 = ch[wave]; cs1 = ch[wave + 1]; load_in(cs0, cs1 - cs0, cin);
+      _Pragma("unroll") for (int q = 0; q < 3; q++) cX[q] = v.pt_pos[3 * cin.pt + q];
+    }
     for (int k = wave; k < nch; k += BA_WAVES) {
       const int n = cs1 - cs0;                                         // <= 64: a point has at most BA_MFMA_FREE slots in region F
       const int kn = k + BA_WAVES;
@@ -968,12 +993,12 @@ BA_PHASE_FN double ba_map_update(const BaView& v_, int nfree, int np, double lam
       double t[3] = {0, 0, 0};
       if (act && SL_STATE(cin.info) == MS_OK) {
         MeasState ms;
-        _Pragma("unroll") for (int q = 0; q < 3; q++) ms.cm[q] = cin.cm[q];
         _Pragma("unroll") for (int q = 0; q < 4; q++) ms.d[q] = cin.d[q];
         ms.st = MS_OK;
         const int cam = SL_CAM(cin.info), f = SL_FORD(cin.info);
         double Rj[9], cu[6], W[18];
         _Pragma("unroll") for (int q = 0; q < 9; q++) Rj[q] = camL[cam * 12 + q];
+        _Pragma("unroll") for (int q = 0; q < 3; q++) ms.cm[q] = camL[cam * 12 + 9 + q] + (Rj[3 * q] * cX[0] + Rj[3 * q + 1] * cX[1] + Rj[3 * q + 2] * cX[2]);   // pose_xform
         _Pragma("unroll") for (int q = 0; q < 6; q++) cu[q] = cuL[f * 6 + q];
         ba_jac_W(ms, Rj, W);
         _Pragma("unroll") for (int c = 0; c < 3; c++) { double sx = 0; for (int r = 0; r < 6; r++) sx += W[r * 3 + c] * cu[r]; t[c] = sx; }
@@ -1004,10 +1029,11 @@ BA_PHASE_FN double ba_map_update(const BaView& v_, int nfree, int np, double lam
         _Pragma("unroll") for (int r = 0; r < 3; r++) {
           const double u = Vi[r * 3] * x[0] + Vi[r * 3 + 1] * x[1] + Vi[r * 3 + 2] * x[2];
           ssq += u * u;
-          v.pt_new[3 * pt + r] = v.pt_pos[3 * pt + r] + u;             // :484
+          v.pt_new[3 * pt + r] = cX[r] + u;                            // :484
         }
       }
       __builtin_amdgcn_wave_barrier();
+      if (kn < nch) { _Pragma("unroll") for (int q = 0; q < 3; q++) cX[q] = v.pt_pos[3 * nin.pt + q]; }
       cs0 = ns0; cs1 = ns1; cin = nin;
     }
     for (int p = threadIdx.x; p < np; p += BA_THREADS) {               // points no adjustable camera measures: the update is V*^-1 epsilon_b
