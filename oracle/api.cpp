@@ -53,6 +53,7 @@ void orc_sys_pose_stage(void* s, int stage) { System* S = (System*)s; if (S->tra
 void orc_sys_frame_end(void* s) { ((System*)s)->FrameEnd(); }
 void orc_sys_idle_iteration(void* s) { ((System*)s)->IdleIteration(); }
 void orc_sys_idle_job(void* s, int job) { ((System*)s)->IdleJob(job); }
+void orc_sys_set_last_keyframe_dropped(void* s, int frame) { ((System*)s)->last_kf_dropped = frame; }   // Tracker::mnLastKeyFrameDropped
 void orc_sys_press_spacebar(void* s) { ((System*)s)->spacebar = true; }
 void orc_sys_set_boot_seed(void* s, unsigned seed) { ((System*)s)->boot_seed = seed; }
 void orc_sys_get_init_info(void* sv, int out[6]) {

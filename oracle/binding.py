@@ -207,7 +207,7 @@ class OracleSystem:
         for f in ("orc_sys_destroy", "orc_sys_add_meas", "orc_sys_set_map_good", "orc_sys_set_pose", "orc_sys_set_velocity",
                   "orc_sys_track_frame", "orc_sys_get_state", "orc_sys_get_keyframe_pose", "orc_sys_frame_begin", "orc_sys_search_stage",
                   "orc_sys_pose_stage", "orc_sys_frame_end", "orc_sys_idle_iteration", "orc_sys_idle_job", "orc_sys_get_idle_stats",
-                  "orc_sys_press_spacebar", "orc_sys_set_boot_seed", "orc_sys_get_init_info"):
+                  "orc_sys_press_spacebar", "orc_sys_set_last_keyframe_dropped", "orc_sys_set_boot_seed", "orc_sys_get_init_info"):
             getattr(L, f).restype = None
         self.L = L
         self.p = params
@@ -266,6 +266,9 @@ class OracleSystem:
 
     def idle_job(self, job):
         self.L.orc_sys_idle_job(self.h, job)
+
+    def set_last_keyframe_dropped(self, frame):
+        self.L.orc_sys_set_last_keyframe_dropped(self.h, C.c_int(frame))
 
     def press_spacebar(self):
         self.L.orc_sys_press_spacebar(self.h)

@@ -125,6 +125,7 @@ void orc_sys_search_stage(void* sys, int stage);
 void orc_sys_pose_stage(void* sys, int stage);
 void orc_sys_frame_end(void* sys);
 /* map bootstrap (bootstrap.cpp): the next frame of a system without a map starts the trails / runs InitFromStereo (jni/Tracker.cc:247-288) */
+void orc_sys_set_last_keyframe_dropped(void* sys, int frame);   /* Tracker::mnLastKeyFrameDropped (jni/Tracker.h), -20 at start */
 void orc_sys_press_spacebar(void* sys);
 void orc_sys_set_boot_seed(void* sys, unsigned seed);
 void orc_sys_get_init_info(void* sys, int out[6]);   /* stage, trails, InitFromStereo succeeded, homography inliers, points after the stereo pass, map good */

@@ -195,6 +195,42 @@ def test_asynchronous_mapmaker_delay():
     g.close()
 
 
+def test_asynchronous_mapmaker_streams_keyframing_on_different_frames():
+    """The asynchronous map-maker with independent sequences: three streams whose keyframe frames differ (their
+    mnLastKeyFrameDropped phases are staggered as bench.py does), ba_delay_frames = 6 with batches of 3 frames on the ring of
+    map-maker streams -- an adjustment is launched while later frames assemble other streams' problems beside it.  Every stream
+    against its own oracle configured alike: bit-exact until its first adjustment lands, then the free-running bars; the
+    keyframe sets, LM trial counts and keyframe poses at the end."""
+    w, h, S, n, D = 320, 240, 3, 40, 6
+    scenes = [scene(w, h, 900 + s, n, per_level=(120, 50, 20, 8)) for s in range(S)]
+    kw = dict(ba_delay_frames=D, min_frames_between_kf=12)
+    g = capi.System(capi.default_params(w, h, S, ba_batch_frames=3, **kw))
+    oracles = []
+    for s, (f, m, _fr) in enumerate(scenes):
+        g.load_map(s, m); g.set_pose(s, f.pose(-1))
+        g.set_last_keyframe_dropped(s, -12 + 4 * s)
+        o = make_oracle(capi.default_params(w, h, 1, **kw), m, f.pose(-1))
+        o.set_last_keyframe_dropped(-12 + 4 * s)
+        oracles.append(o)
+    kf_frames = [[] for _ in range(S)]
+    for i in range(n):
+        g.track_frame(np.stack([sc[2][i] for sc in scenes]))
+        for s in range(S):
+            oracles[s].track_frame(scenes[s][2][i])
+            so, sg = oracles[s].state(), g.state(s)
+            if so.kf_added:
+                kf_frames[s].append(i)
+            assert so.kf_added == sg.kf_added and so.n_keyframes == sg.n_keyframes, (s, i)
+            assert_tracker_close(oracles[s], g, s, "stream %d frame %d" % (s, i))
+    assert all(len(k) >= 2 for k in kf_frames) and len({k[0] for k in kf_frames}) == S, kf_frames     # different frames
+    g.synchronize()
+    for s in range(S):
+        assert g.state(s).n_ba_trials == oracles[s].state().n_ba_trials > 0, s
+        for k in range(g.state(s).n_keyframes):
+            assert pose_err(oracles[s].keyframe_pose(k), g.keyframe_pose(s, k)) < 1e-5, (s, k)
+    g.close()
+
+
 def test_independent_streams_in_one_batch():
     w, h, S, n = 320, 240, 3, 5
     scenes = [scene(w, h, 500 + s, n, per_level=(120, 50, 20, 8)) for s in range(S)]

@@ -6,7 +6,7 @@ from helpers import *
 W,H=640,480
 f,m,frames=make_scene(W,H,n_frames=2)
 S=int(sys.argv[1]) if len(sys.argv)>1 else 1
-vp=capi.default_params(W,H,S,patch_size=8)
+vp=capi.default_params(W,H,S,patch_size=8, ba_window=int(sys.argv[2]) if len(sys.argv)>2 else 5)
 g=capi.System(vp)
 for s in range(S):
     g.load_map(s,m); g.set_pose(s,f.pose(-1))
