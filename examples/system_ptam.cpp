@@ -1,8 +1,12 @@
 // The reference's JNI glue (jni/jni_part.cpp:18-75, class SystemPTAM) rebuilt on include/vslam/ptam.h with the Android
 // camera replaced by the synthetic feeder: create ATANCamera, Map, MapMaker, Tracker; feed frames to TrackFrame.
-// Usage: system_ptam [n_frames]     (needs an MI355X; prints the tracker's user message per frame)
+// Usage: system_ptam [n_frames]        a ground-truth map is uploaded, then n_frames are tracked
+//        system_ptam [n_frames] boot   no map: the screen is touched at frames 0 and 12 and the tracker makes its own
+//                                      (trail tracking + MapMaker::InitFromStereo on the device), then keeps tracking
+// (needs an MI355X; prints the tracker's user message per frame)
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 #include "../include/vslam/ptam.h"
 #include "../include/vslam_feeder.h"
@@ -10,11 +14,11 @@
 class SystemPTAM {   // same members and construction order as jni/jni_part.cpp:20-46
  public:
   Map* mpMap; MapMaker* mpMapMaker; Tracker* mpTracker; ATANCamera* mpCamera;
-  SystemPTAM(int w, int h) {
+  SystemPTAM(int w, int h, bool bootstrap = false) {
     mpCamera = new ATANCamera("Camera");
     mpMap = new Map;
     mpMapMaker = new MapMaker(*mpMap, *mpCamera);
-    mpTracker = new Tracker(w, h, *mpCamera, *mpMap, *mpMapMaker);
+    mpTracker = new Tracker(w, h, *mpCamera, *mpMap, *mpMapMaker, bootstrap);
   }
   ~SystemPTAM() { delete mpTracker; delete mpMapMaker; delete mpMap; delete mpCamera; }
   void onTouchScreen() { mpTracker->mbUserPressedSpacebar = true; }                 // :49-51
@@ -26,6 +30,25 @@ int main(int argc, char** argv) {
   const double cam[5] = {0.841906, 1.10893, 0.505171, 0.470265, -0.0133843};
   vslam_feeder* f = nullptr;
   if (vslam_feeder_create(W, H, cam, 1234, 2, &f)) return 2;
+  if (argc > 2 && std::string(argv[2]) == "boot") {               // the reference's own start: no map, two touches (jni/Tracker.cc:247-288)
+    SystemPTAM boot(W, H, true);
+    cv::Mat bw(H, W, CV_8UC1), rgb(H, W, CV_8UC4);
+    for (int t = 0; t < n; t++) {
+      double p[12];
+      vslam_feeder_pose(f, t, p);
+      vslam_feeder_render_pose(f, p, 100 + t, bw.data, bw.step);
+      if (t == 0 || t == 12) boot.onTouchScreen();
+      boot.update(bw, rgb);
+      int info[6];
+      vslam_get_init_info(boot.mpMap->sys, 0, info);
+      printf("frame %d: stage %d trails %d | %s\n", t, info[0], info[1], boot.mpTracker->GetMessageForUser().c_str());
+    }
+    KeyFrame k0, k1; std::vector<std::pair<std::pair<double, double>, std::pair<double, double>>> none; mySE3 T;
+    const bool ok = boot.mpMapMaker->InitFromStereo(k0, k1, none, T);
+    printf("InitFromStereo: %s, camera at t = (%.3f %.3f %.3f)\n", ok ? "map made" : "no map", T.t[0], T.t[1], T.t[2]);
+    vslam_feeder_destroy(f);
+    return ok ? 0 : 1;
+  }
   SystemPTAM sys(W, H);
   vslam_system* dev = sys.mpMap->sys;
   // ground-truth map from one source keyframe (the bootstrap InitFromStereo is out of scope): every 7th maximal corner

@@ -20,3 +20,16 @@ def test_system_ptam_example_tracks():
         assert "Tracking Map, quality good." in l, l
         err = float(re.search(r"max = ([0-9.e+-]+)", l).group(1))
         assert err < 2e-2, l
+
+
+def test_system_ptam_example_bootstraps_its_own_map():
+    """The reference's own start through the C++ drop-in classes: no map, two screen touches (jni/jni_part.cpp:49-51 ->
+    Tracker::mbUserPressedSpacebar), trail tracking, InitFromStereo on the device, then tracking of the map it made."""
+    exe = os.path.join(ROOT, "examples", "_build", "system_ptam")
+    out = subprocess.run([exe, "20", "boot"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("frame ")]
+    assert len(lines) == 20
+    assert "press spacebar again" in lines[5] and "stage 1" in lines[5]
+    assert all("Tracking Map, quality good." in l for l in lines[13:]), lines[13:]
+    assert "InitFromStereo: map made" in out.stdout

@@ -478,7 +478,9 @@ extern "C" int vslam_get_message(vslam_system* sys, int s, char* buf, size_t cap
   TrackerState st;
   int r = get_state(sys, s, &st); if (r) return r;
   if (!buf || !cap) return VSLAM_E_INVALID;
-  if (!st.map_good) snprintf(buf, cap, "Point camera at planar scene and press spacebar to start tracking for initial map.");   // jni/Tracker.cc:240
+  if (!st.map_good && st.init_stage == 1) snprintf(buf, cap, "Translate the camera slowly sideways, and press spacebar again to perform stereo init.");   // jni/Tracker.cc:284
+  else if (!st.map_good && st.init_stage == 2) buf[0] = 0;                                                                       // TRAIL_TRACKING_COMPLETE without a map: TrackForInitialMap says nothing
+  else if (!st.map_good) snprintf(buf, cap, "Point camera at planar scene and press spacebar to start tracking for initial map.");   // :260
   else if (st.lost_frames >= 3) snprintf(buf, cap, "** Attempting recovery **.");                                                // :134
   else snprintf(buf, cap, "Tracking Map, quality %s Found: %d/%d %d/%d %d/%d %d/%d Map: %dP, %dKF%s",                            // :110-124
                 st.quality == 2 ? "good." : st.quality == 1 ? "poor." : "bad.", st.found[0], st.attempted[0], st.found[1], st.attempted[1],
