@@ -523,12 +523,13 @@ BA_PHASE_FN BaNewError ba_find_new_error(const BaView& v_, const BaConfig& cfg_,
 // camera by masked wavefront reductions and carried in registers over the chunks; left per wavefront in `ured`.
 // Returns this thread's share of the objective (pass 2's dCurrentError).
 // ---------------------------------------------------------------------------------------------------------------------
-#define BA_MFMA_FREE 5
-#define BA_U_PAIRS ((BA_MFMA_FREE * 27 + 63) / 64)
+#define BA_MFMA_FREE 5    // adjustable cameras of one pass of the matrix-core form of the reduced camera system
+#define BA_FAST_FREE 10   // adjustable cameras up to which U / epsilon_a are summed inside the sweep and the map update runs over the dense F slots
+#define BA_U_PAIRS ((BA_FAST_FREE * 27 + 63) / 64)
 #define BA_MAX_CAMS_LDS 128  // cameras whose poses the step sweep keeps in LDS (= the most keyframes a map holds)
 #define BA_SWEEP_STAGE 27   // doubles per lane of a wavefront's staging area in the step sweep (V / epsilon_b use 9 of them)
 BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int region, double sigma2, int nfree,
-                                                        double* stg_ /* LDS [BA_WAVES][64][BA_SWEEP_STAGE] */, double* ured_ /* LDS [BA_WAVES][BA_MFMA_FREE][32] */,
+                                                        double* stg_ /* LDS [BA_WAVES][64][BA_SWEEP_STAGE] */, double* ured_ /* unused: a wavefront leaves its U / epsilon_a sums at the head of its own staging area, [camera][27] */,
                                                         const double* cams_ /* LDS: the committed camera poses, 12 doubles each */) {
   const BaViewG v = ba_g(v_);
   const BaConfig cfg = cfg_;
@@ -538,7 +539,7 @@ BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int reg
   const int nch = v.ch_n[region];
   const int AS1* ch = region ? v.chX : v.chF;
   const int base = region ? v.ch_n[2] : 0;
-  const bool fastU = region == 0 && nfree <= BA_MFMA_FREE;
+  const bool fastU = region == 0 && nfree <= BA_FAST_FREE;
   double cur = 0.0;
   double uacc[BA_U_PAIRS];                                             // lane's sums: (camera, value) pairs lane, lane + 64, lane + 128
   _Pragma("unroll") for (int k = 0; k < BA_U_PAIRS; k++) uacc[k] = 0.0;
@@ -561,7 +562,7 @@ BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int reg
   // (the reduced camera system and the map update re-derive W from them; v3Cam is re-derived there from the point and the pose);
   // v3Cam and epsilon too when more than BA_MFMA_FREE cameras are adjusted (the wave-per-block forms read them).  An X slot is
   // consumed here and now: nothing else is stored for it.
-  const bool storeD = region == 0, storeAll = region == 0 && !fastU;
+  const bool storeD = region == 0, storeAll = region == 0 && nfree > BA_MFMA_FREE;
   for (int k = wave; k < nch; k += BA_WAVES) {
     const int a0 = base + cs0, ntot = cs1 - cs0;                       // <= 64 slots, or ONE point with more (a keyframe-rich map: fixed cameras)
     const int kn = k + BA_WAVES;
@@ -670,15 +671,15 @@ BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int reg
       _Pragma("unroll") for (int q = 0; q < 12; q++) A[q] = 0.0;
       if (valid) ba_jac_A(c, d, A);
       const int ford = valid ? SL_FORD(info) : 255;
-      int offf[BA_MFMA_FREE], cntf[BA_MFMA_FREE];
+      int offf[BA_FAST_FREE], cntf[BA_FAST_FREE];
       int mypos = 0, run = 0;
-      _Pragma("unroll") for (int f = 0; f < BA_MFMA_FREE; f++) {
+      _Pragma("unroll") for (int f = 0; f < BA_FAST_FREE; f++) {
         const unsigned long long mk = __ballot(ford == f);
         const int cf = (int)__popcll(mk);
         if (ford == f) mypos = run + (int)__popcll(mk & ((1ull << lane) - 1ull));
         offf[f] = run; cntf[f] = cf; run += cf;
       }
-      if (ford < BA_MFMA_FREE) {
+      if (ford < BA_FAST_FREE) {
         double AS3* dst = stg + mypos * 27;
         int q = 0;
         _Pragma("unroll") for (int r = 0; r < 6; r++) for (int cc = 0; cc <= r; cc++) dst[q++] = A[r] * A[cc] + A[6 + r] * A[6 + cc];       // :40-47
@@ -691,7 +692,7 @@ BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int reg
         if (pid < nfree * 27) {
           const int f = pid / 27, q = pid - 27 * f;
           int o = offf[0], cf = cntf[0];
-          _Pragma("unroll") for (int g = 1; g < BA_MFMA_FREE; g++) if (f == g) { o = offf[g]; cf = cntf[g]; }
+          _Pragma("unroll") for (int g = 1; g < BA_FAST_FREE; g++) if (f == g) { o = offf[g]; cf = cntf[g]; }
           double acc = uacc[k];
           const double AS3* src = stg + o * 27 + q;
           int r = 0;
@@ -715,10 +716,10 @@ BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int reg
     cs0 = ns0; cs1 = ns1; cin = nin;
   }
   if (fastU) {
-    double AS3* ured = (double AS3*)ured_ + wave * BA_MFMA_FREE * 32;
+    (void)ured_;
     _Pragma("unroll") for (int k = 0; k < BA_U_PAIRS; k++) {
       const int pid = lane + 64 * k;
-      if (pid < nfree * 27) { const int f = pid / 27, q = pid - 27 * f; ured[f * 32 + q] = uacc[k]; }
+      if (pid < nfree * 27) stg[pid] = uacc[k];                        // [camera][27]: the staging area is free after the last chunk
     }
   }
   return cur;
@@ -955,12 +956,12 @@ BA_PHASE_FN double ba_map_update(const BaView& v_, int nfree, int np, double lam
   const BaViewG v = ba_g(v_);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double ssq = 0.0;
-  if (nfree > 0 && nfree <= BA_MFMA_FREE) {
+  if (nfree > 0 && nfree <= BA_FAST_FREE) {
     // One lane per F slot, a chunk of whole points per wavefront trip (the step sweep's tables), the slot's state loaded a chunk
     // ahead; W^T * (camera update) of every slot goes to LDS and the first lane of each point adds its slots in order, then
     // solves for the point (:440-462, :484).  Poses and camera updates come out of LDS.
     double AS3* stg = (double AS3*)lds_ + wave * 64 * BA_SWEEP_STAGE;
-    double AS3* camL = (double AS3*)lds_ + BA_WAVES * 64 * BA_SWEEP_STAGE + BA_WAVES * BA_MFMA_FREE * 32;
+    double AS3* camL = (double AS3*)lds_ + BA_WAVES * 64 * BA_SWEEP_STAGE;
     double AS3* cuL = camL + 12 * BA_MAX_CAMS_LDS;
     const int nc = v.res->n_cams;
     for (int t = threadIdx.x; t < nc * 12; t += BA_THREADS) camL[t] = ((const double AS1*)v.cam_pose)[t];
@@ -1130,7 +1131,7 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
   __shared__ unsigned long long sel[1];
   __shared__ double sh_lambda, sh_factor, sh_sigma2, sh_cur_err, sh_new_err;
   constexpr int LDS_MFMA = BA_WAVES * BA_MFMA_STAGE, LDS_SOLVE = BA_LDS_N * (BA_LDS_N + 1);
-  constexpr int LDS_SWEEP = BA_WAVES * 64 * BA_SWEEP_STAGE + BA_WAVES * BA_MFMA_FREE * 32 + 12 * BA_MAX_CAMS_LDS + 6 * BA_MFMA_FREE;
+  constexpr int LDS_SWEEP = BA_WAVES * 64 * BA_SWEEP_STAGE + 12 * BA_MAX_CAMS_LDS + 6 * BA_FAST_FREE;
   constexpr int LDS_LAYOUT = (2 * 4097 * (int)sizeof(int) + 7) / 8;
   constexpr int LDS_A = LDS_MFMA > LDS_SOLVE ? LDS_MFMA : LDS_SOLVE, LDS_B = LDS_SWEEP > LDS_LAYOUT ? LDS_SWEEP : LDS_LAYOUT;
   __shared__ double lds_buf[LDS_A > LDS_B ? LDS_A : LDS_B];
@@ -1156,7 +1157,7 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
   unsigned long long ba_t0 = clock64();
 #endif
   static_assert(sizeof(lds_buf) >= 2 * 4097 * sizeof(int) && sizeof(lds_buf) >= (65536 / 32) * sizeof(unsigned) &&
-                sizeof(lds_buf) >= (BA_WAVES * 64 * BA_SWEEP_STAGE + BA_WAVES * BA_MFMA_FREE * 32 + 12 * BA_MAX_CAMS_LDS + 6 * BA_MFMA_FREE) * sizeof(double), "the LDS buffer serves the layout, the step sweep and the erase");
+                sizeof(lds_buf) >= (size_t)LDS_SWEEP * sizeof(double), "the LDS buffer serves the layout, the step sweep and the erase");
   ba_build_layout(v_, nc, np, ired, (int*)lds_buf);
   const int M = v.ch_n[3];                                            // slots = measurements of the list
   BA_STAMP(0);
@@ -1180,19 +1181,20 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
     const double sigma2 = sh_sigma2;
     BA_STAMP(2);
     // passes 1 + 2 (:209-321) in one sweep: weights, objective, V / epsilon_b, U / epsilon_a; A, B, W are re-derived by their consumers
-    double* stg = lds_buf; double* ured = lds_buf + BA_WAVES * 64 * BA_SWEEP_STAGE; double* camsL = ured + BA_WAVES * BA_MFMA_FREE * 32;
+    double* stg = lds_buf; double* ured = nullptr; double* camsL = lds_buf + BA_WAVES * 64 * BA_SWEEP_STAGE;
     for (int t = threadIdx.x; t < nc * 12; t += BA_THREADS) camsL[t] = ((const double AS1*)v.cam_pose)[t];   // Pose = R[9], t[3]
     __syncthreads();
     double cur = ba_step_sweep(v_, cfg, 0, sigma2, nfree, stg, ured, camsL);
     __syncthreads();
-    if (nfree <= BA_MFMA_FREE) {
+    if (nfree <= BA_FAST_FREE) {
       for (int t = threadIdx.x; t < nfree * 27; t += BA_THREADS) {     // wave partials in wave order
         const int f = t / 27, q = t - 27 * f, j = v.free_cams[f];
         double x = 0.0;
-        for (int w = 0; w < BA_WAVES; w++) x += ured[(w * BA_MFMA_FREE + f) * 32 + q];
+        for (int w = 0; w < BA_WAVES; w++) x += lds_buf[w * 64 * BA_SWEEP_STAGE + f * 27 + q];
         if (q < 21) { int r = 0, qq = q; while (qq > r) { qq -= r + 1; r++; } v.cam_U[36 * j + r * 6 + qq] = x; }
         else v.cam_ea[6 * j + (q - 21)] = x;
       }
+      __syncthreads();                                                 // the sums sit in the staging areas the next sweep writes
     }
     BA_STAMP(3);
     cur += ba_step_sweep(v_, cfg, 1, sigma2, nfree, stg, ured, camsL);
@@ -1200,7 +1202,7 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
     if (threadIdx.x == 0) sh_cur_err = cur;
     __syncthreads();
     BA_STAMP(4);
-    if (nfree > BA_MFMA_FREE) { ba_accum_U_generic(v_, nfree, np); __syncthreads(); }
+    if (nfree > BA_FAST_FREE) { ba_accum_U_generic(v_, nfree, np); __syncthreads(); }
     BA_STAMP(5);
     // ---- inner loop over lambda (:326-501) ----
     if (threadIdx.x == 0) sh_new_err = sh_cur_err + 9999;
