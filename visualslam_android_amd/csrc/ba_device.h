@@ -560,9 +560,9 @@ BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int reg
   }
   // What a slot leaves for the later phases of the step: its state (every region); the weighted camera derivatives d of an F slot
   // (the reduced camera system and the map update re-derive W from them; v3Cam is re-derived there from the point and the pose);
-  // v3Cam and epsilon too when more than BA_MFMA_FREE cameras are adjusted (the wave-per-block forms read them).  An X slot is
+  // v3Cam and epsilon too when more than BA_FAST_FREE cameras are adjusted (the wave-per-block forms read them).  An X slot is
   // consumed here and now: nothing else is stored for it.
-  const bool storeD = region == 0, storeAll = region == 0 && nfree > BA_MFMA_FREE;
+  const bool storeD = region == 0, storeAll = region == 0 && nfree > BA_FAST_FREE;
   for (int k = wave; k < nch; k += BA_WAVES) {
     const int a0 = base + cs0, ntot = cs1 - cs0;                       // <= 64 slots, or ONE point with more (a keyframe-rich map: fixed cameras)
     const int kn = k + BA_WAVES;
@@ -842,14 +842,25 @@ BA_PHASE_FN void ba_task_pair(const BaView& v_, int task, int np, int nS, double
 #define BA_MFMA_STAGE (4 * BA_MFMA_K * 16)              // doubles per wavefront: Y rows 0-15 / 16-31, W columns 0-15 / 16-31, each [K][16]
 static_assert(BA_MFMA_STAGE >= 32 * 32 && BA_MFMA_K % 4 == 0, "a wavefront's staging area also holds its 32 x 32 partial product");
 typedef double ba_v4d __attribute__((ext_vector_type(4)));
-BA_PHASE_FN void ba_schur_mfma(const BaView& v_, int nfree, int np, int nS, double lambda, double* lds_) {
+// One pass: the block of S whose rows belong to the adjustable cameras of ordinals [r0, r0 + nr) and whose columns to those of
+// [c0, c0 + ncl), nr, ncl <= BA_MFMA_FREE.  r0 == c0 (a diagonal block; then nr == ncl): lower triangle + mirror, U* on the cameras'
+// own 6 x 6 blocks, and E of these cameras out of row 30.  r0 != c0 (an off-diagonal block of a problem with up to 2 * BA_MFMA_FREE
+// adjustable cameras, e.g. BASELINE configs[3]'s 10-keyframe window): the whole 32 x 32 product, written with its transpose.
+template <bool DIAG>
+BA_PHASE_FN void ba_schur_mfma(const BaView& v_, int np, int nS, double lambda, double* lds_, int r0, int nr, int c0, int ncl) {
   const BaViewG v = ba_g(v_);
   double AS3* lds = (double AS3*)lds_;                    // the staging buffer is LDS: ds_read / ds_write, not flat
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double AS3* Y0 = lds + wave * BA_MFMA_STAGE; double AS3* Y1 = Y0 + BA_MFMA_K * 16; double AS3* W0 = Y1 + BA_MFMA_K * 16; double AS3* W1 = W0 + BA_MFMA_K * 16;
   for (int t = lane; t < BA_MFMA_STAGE; t += 64) Y0[t] = 0.0;      // rows / columns no lane ever writes stay zero
-  const bool active = lane < BA_MFMA_PPC * nfree;
-  const int pl = active ? lane / nfree : 0, f = active ? lane - pl * nfree : 0;
+  constexpr bool diag = DIAG;                            // r0 == c0
+  const int ncam = diag ? nr : nr + ncl;                 // cameras a trip's lanes cover: a diagonal pass derives Y and W of a camera in one lane
+  const int PPC = diag ? BA_MFMA_PPC : (64 / ncam < BA_MFMA_PPC ? 64 / ncam : BA_MFMA_PPC);   // points per wavefront and trip (a diagonal pass: 64 / 5 = 12 at least)
+  const bool active = lane < PPC * ncam;
+  const int pl = active ? lane / ncam : 0, fi = active ? lane - pl * ncam : 0;
+  const bool isrow = diag || fi < nr, iscol = diag || fi >= nr;
+  const int frow = fi, fcol = diag ? fi : fi - nr;        // position of the camera inside the row / column group
+  const int f = isrow ? r0 + frow : c0 + fcol;            // its ordinal among the adjustable cameras
   const int j = v.free_cams[f];
   double Rj[9], tj[3];
   _Pragma("unroll") for (int k = 0; k < 9; k++) Rj[k] = v.cam_pose[j].R[k];
@@ -865,12 +876,13 @@ BA_PHASE_FN void ba_schur_mfma(const BaView& v_, int nfree, int np, int nS, doub
     m.cm[1] = tj[1] + (Rj[3] * X[0] + Rj[4] * X[1] + Rj[5] * X[2]);
     m.cm[2] = tj[2] + (Rj[6] * X[0] + Rj[7] * X[1] + Rj[8] * X[2]);
   };
-  ba_v4d d00 = {0, 0, 0, 0}, d10 = {0, 0, 0, 0}, d11 = {0, 0, 0, 0};
+  ba_v4d d00 = {0, 0, 0, 0}, d10 = {0, 0, 0, 0}, d11 = {0, 0, 0, 0}, d01 = {0, 0, 0, 0};
   __builtin_amdgcn_s_waitcnt(0);
   __builtin_amdgcn_wave_barrier();
   // software pipeline over the trips: the operands of trip t+1 are in flight while trip t is derived, staged and multiplied
-  constexpr int STRIDE = BA_WAVES * BA_MFMA_PPC;
-  const int pfirst = wave * BA_MFMA_PPC;
+  const int STRIDE = BA_WAVES * PPC;
+  const int pfirst = wave * PPC;
+  const int ksteps = diag ? BA_MFMA_K / 4 : (3 * PPC + 3) / 4;
   auto slot_at = [&](int p0) -> int { const int p = p0 + pl; return (active && p < np) ? ba_slot_of(v, p, f) : -1; };
   MeasState ms_n; double V_n[6], eb_n[3];
   {
@@ -906,24 +918,33 @@ BA_PHASE_FN void ba_schur_mfma(const BaView& v_, int nfree, int np, int nS, doub
     }
     if (active) {
       _Pragma("unroll") for (int r = 0; r < 6; r++) {
-        const int row = 6 * f + r;
-        double AS3* yd = (row < 16 ? Y0 + row : Y1 + (row - 16)) + 3 * pl * 16;
-        double AS3* wd = (row < 16 ? W0 + row : W1 + (row - 16)) + 3 * pl * 16;
-        _Pragma("unroll") for (int c = 0; c < 3; c++) { yd[c * 16] = Y[r * 3 + c]; wd[c * 16] = W[r * 3 + c]; }
+        if (isrow) {
+          const int row = 6 * frow + r;
+          double AS3* yd = (row < 16 ? Y0 + row : Y1 + (row - 16)) + 3 * pl * 16;
+          _Pragma("unroll") for (int c = 0; c < 3; c++) yd[c * 16] = Y[r * 3 + c];
+        }
+        if (iscol) {
+          const int col = 6 * fcol + r;
+          double AS3* wd = (col < 16 ? W0 + col : W1 + (col - 16)) + 3 * pl * 16;
+          _Pragma("unroll") for (int c = 0; c < 3; c++) wd[c * 16] = W[r * 3 + c];
+        }
       }
-      if (f == 0) {                                               // row 30 of the left operand: V*^-1 eb_p, so that D[30][.] = sum_p W (V*^-1 eb) (:388-396)
+      if (diag && fi == 0) {                                        // row 30 of the left operand: V*^-1 eb_p, so that D[30][.] = sum_p W (V*^-1 eb) (:388-396)
         _Pragma("unroll") for (int c = 0; c < 3; c++) Y1[(3 * pl + c) * 16 + 14] = p < np ? Vi[c * 3] * eb[0] + Vi[c * 3 + 1] * eb[1] + Vi[c * 3 + 2] * eb[2] : 0.0;
       }
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0) only: the prefetched global loads stay in flight
     __builtin_amdgcn_wave_barrier();
-    _Pragma("unroll") for (int ks = 0; ks < BA_MFMA_K / 4; ks++) {
+    auto mfma_step = [&](int ks) {
       const int o = (ks * 4 + (lane >> 4)) * 16 + (lane & 15);
       const double a0 = Y0[o], a1 = Y1[o], b0 = W0[o], b1 = W1[o];
-      d00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, d00, 0, 0, 0);   // the tile of rows 0-15 x columns 16-31 lies above the diagonal: not needed
+      d00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, d00, 0, 0, 0);
       d10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, d10, 0, 0, 0);
       d11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, d11, 0, 0, 0);
-    }
+      if (!diag) d01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, d01, 0, 0, 0);   // a diagonal block's tile above the diagonal is not needed
+    };
+    if constexpr (diag) { _Pragma("unroll") for (int ks = 0; ks < BA_MFMA_K / 4; ks++) mfma_step(ks); }
+    else { for (int ks = 0; ks < ksteps; ks++) mfma_step(ks); }
     __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0) only: the prefetched global loads stay in flight
     __builtin_amdgcn_wave_barrier();
   }
@@ -931,20 +952,22 @@ BA_PHASE_FN void ba_schur_mfma(const BaView& v_, int nfree, int np, int nS, doub
   __syncthreads();
   _Pragma("unroll") for (int q = 0; q < 4; q++) {
     const int r = (lane >> 4) + 4 * q, c = lane & 15;
-    Y0[r * 32 + c] = d00[q]; Y0[(16 + r) * 32 + c] = d10[q]; Y0[(16 + r) * 32 + 16 + c] = d11[q];
+    Y0[r * 32 + c] = d00[q]; Y0[(16 + r) * 32 + c] = d10[q]; Y0[(16 + r) * 32 + 16 + c] = d11[q]; Y0[r * 32 + 16 + c] = d01[q];
   }
   __syncthreads();
+  const int nrow = 6 * nr, ncol = 6 * ncl;
   for (int t = threadIdx.x; t < 32 * 32; t += BA_THREADS) {
     const int r = t >> 5, c = t & 31;
-    if (!(r < nS || r == 30) || c >= nS || (r < nS && c > r)) continue;
+    if (c >= ncol) continue;
+    if (diag ? (!(r < nrow || r == 30) || (r < nrow && c > r)) : r >= nrow) continue;
     double sum = 0.0;
     for (int w = 0; w < BA_WAVES; w++) sum += lds[w * BA_MFMA_STAGE + t];
-    if (r == 30) { const int fk = c / 6, kk = v.free_cams[fk]; v.E[c] = v.cam_ea[6 * kk + (c - 6 * fk)] - sum; continue; }   // rows of S follow the adjustable cameras in order (cam_row == 6 * ordinal)
-    const int fj = r / 6, jj = v.free_cams[fj];
+    if (r == 30) { const int fk = c0 + c / 6, kk = v.free_cams[fk]; v.E[6 * c0 + c] = v.cam_ea[6 * kk + (c % 6)] - sum; continue; }   // rows of S follow the adjustable cameras in order (cam_row == 6 * ordinal)
+    const int R = 6 * r0 + r, C = 6 * c0 + c;
     double u = 0.0;
-    if (c / 6 == fj) { u = v.cam_U[36 * jj + (r - 6 * fj) * 6 + (c - 6 * fj)]; if (r == c) u *= (1.0 + lambda); }
+    if (diag && c / 6 == r / 6) { const int jj = v.free_cams[r0 + r / 6]; u = v.cam_U[36 * jj + (r % 6) * 6 + (c % 6)]; if (r == c) u *= (1.0 + lambda); }
     const double val = u - sum;
-    v.S[(size_t)r * nS + c] = val; v.S[(size_t)c * nS + r] = val;
+    v.S[(size_t)R * nS + C] = val; v.S[(size_t)C * nS + R] = val;
   }
   __syncthreads();
 }
@@ -1212,7 +1235,13 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
       BA_STAMP(6);
       // S: diagonal blocks + E (:362-396) and off-diagonal blocks (:400-426); V*^-1 (:329-347) is formed where it is used
       if (nfree == 0) { }                                              // only fixed cameras: no camera unknowns, the points move alone
-      else if (nfree <= BA_MFMA_FREE) ba_schur_mfma(v_, nfree, np, nS, lambda, lds_buf);
+      else if (nfree <= BA_MFMA_FREE) ba_schur_mfma<true>(v_, np, nS, lambda, lds_buf, 0, nfree, 0, nfree);
+      else if (nfree <= 2 * BA_MFMA_FREE) {                           // two groups of cameras: two diagonal blocks and the block between them
+        const int g0 = (nfree + 1) / 2, g1 = nfree - g0;
+        ba_schur_mfma<true>(v_, np, nS, lambda, lds_buf, 0, g0, 0, g0);
+        ba_schur_mfma<true>(v_, np, nS, lambda, lds_buf, g0, g1, g0, g1);
+        ba_schur_mfma<false>(v_, np, nS, lambda, lds_buf, g0, g1, 0, g0);
+      }
       else {
         for (int t = threadIdx.x; t < nS * nS; t += BA_THREADS) v.S[t] = 0.0;
         __syncthreads();
