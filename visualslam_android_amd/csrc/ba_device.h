@@ -674,10 +674,13 @@ BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int reg
       int offf[BA_FAST_FREE], cntf[BA_FAST_FREE];
       int mypos = 0, run = 0;
       _Pragma("unroll") for (int f = 0; f < BA_FAST_FREE; f++) {
-        const unsigned long long mk = __ballot(ford == f);
-        const int cf = (int)__popcll(mk);
-        if (ford == f) mypos = run + (int)__popcll(mk & ((1ull << lane) - 1ull));
-        offf[f] = run; cntf[f] = cf; run += cf;
+        offf[f] = run; cntf[f] = 0;
+        if (f < nfree) {                                               // (uniform)
+          const unsigned long long mk = __ballot(ford == f);
+          const int cf = (int)__popcll(mk);
+          if (ford == f) mypos = run + (int)__popcll(mk & ((1ull << lane) - 1ull));
+          cntf[f] = cf; run += cf;
+        }
       }
       if (ford < BA_FAST_FREE) {
         double AS3* dst = stg + mypos * 27;
@@ -688,11 +691,12 @@ BA_PHASE_FN double ba_step_sweep(const BaView& v_, const BaConfig& cfg_, int reg
       __builtin_amdgcn_s_waitcnt(0xC07F);
       __builtin_amdgcn_wave_barrier();
       _Pragma("unroll") for (int k = 0; k < BA_U_PAIRS; k++) {
+        if (64 * k >= nfree * 27) break;                               // (uniform)
         const int pid = lane + 64 * k;
         if (pid < nfree * 27) {
           const int f = pid / 27, q = pid - 27 * f;
           int o = offf[0], cf = cntf[0];
-          _Pragma("unroll") for (int g = 1; g < BA_FAST_FREE; g++) if (f == g) { o = offf[g]; cf = cntf[g]; }
+          _Pragma("unroll") for (int g = 1; g < BA_FAST_FREE; g++) if (g < nfree && f == g) { o = offf[g]; cf = cntf[g]; }
           double acc = uacc[k];
           const double AS3* src = stg + o * 27 + q;
           int r = 0;
