@@ -464,14 +464,14 @@ __global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 // lut[y] is the offset of the first word of row y (jni/KeyFrame.cc:43-49).  (One workgroup per (level, stream) walking the
 // whole level was the fourth largest kernel of the path: the level-0 workgroup did nearly all the work.)
 #define COMPACT_THREADS 256
-__global__ __launch_bounds__(COMPACT_THREADS) void k_compact(FeArgs a) {
+__global__ __launch_bounds__(COMPACT_THREADS) void k_compact(FeArgs a, int cband /* rows per workgroup */) {
   __shared__ int wsum[COMPACT_THREADS / 64];
   __shared__ int sh_above;
   const int b = blockIdx.x, l = blockIdx.y, s = blockIdx.z;
   const int h = a.h[l], nchunk = a.nchunk[l], cap = a.cap[l];
-  const int y0 = b * BAND;
+  const int y0 = b * cband;
   if (y0 >= h) return;
-  const int nrows = min(BAND, h - y0);
+  const int nrows = min(cband, h - y0);
   const int* rc = a.rowcnt[l] + (size_t)s * h;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int above = 0;
@@ -846,7 +846,10 @@ int fe_make_keyframe_lite(vslam_system* sys, const uint8_t* gray, size_t row_str
     hipLaunchKernelGGL(k_fast_lvl, dim3(nb, sys->S), dim3(FE_THREADS), lds1, fs, a);
   }
   prof_mark(sys, 2);
-  hipLaunchKernelGGL(k_compact, dim3(nb0, NLEV, sys->S), dim3(COMPACT_THREADS), 0, fs, a);
+  {
+    static const int cb = getenv("VSLAM_COMPACT_BAND") ? atoi(getenv("VSLAM_COMPACT_BAND")) : 32;   // rows of a level per workgroup of the compaction (measured alone, 1024 frames: 16 rows 96 us, 32: 62, 64: 96, 128: 78, 256: 156)
+    hipLaunchKernelGGL(k_compact, dim3((g[0].h + cb - 1) / cb, NLEV, sys->S), dim3(COMPACT_THREADS), 0, fs, a, cb);
+  }
   if (sys->p.use_sbi) {                                           // jni/Tracker.cc:86-97, 104-105
     int r = fe_sbi(sys, sys->have_sbi ? sys->frbuf[b ^ 1] : sys->fr);
     if (r) return r;
@@ -968,7 +971,7 @@ int fe_keyframe_corners(vslam_system* sys, int s, int kf) {
   for (int l = 1; l < NLEV; l++) { a.band_first[l] = nb; nb += (g[l].h + BAND - 1) / BAND; }
   const size_t lds1 = (size_t)(BAND + 2 * HALO) * lp1 + 16 + (size_t)BAND * g[1].nchunk * 8 + (size_t)FB_ROWS * lp1 * 2 + 16;
   hipLaunchKernelGGL(k_fast_lvl, dim3(nb, 1), dim3(FE_THREADS), lds1, sys->stream, a);
-  hipLaunchKernelGGL(k_compact, dim3((g[0].h + BAND - 1) / BAND, NLEV, 1), dim3(COMPACT_THREADS), 0, sys->stream, a);
+  hipLaunchKernelGGL(k_compact, dim3((g[0].h + BAND - 1) / BAND, NLEV, 1), dim3(COMPACT_THREADS), 0, sys->stream, a, BAND);
   uint32_t* d[NLEV];
   for (int l = 0; l < NLEV; l++) d[l] = sys->map.kf_corners[l] + ((size_t)s * K + kf) * sys->tp.kcap[l];
   hipLaunchKernelGGL(k_store_kf_corners, dim3(NLEV), dim3(256), 0, sys->stream, scr.corners[0], scr.corners[1], scr.corners[2], scr.corners[3], scr.ncorners,
