@@ -1,16 +1,16 @@
 // Frame front-end on gfx950: KeyFrame::MakeKeyFrame_Lite (jni/KeyFrame.cc:5-51) and fast_nonmax
 // (jni/vision/cvfast.cpp:9243-9400) for all streams of a system at once.
 //
-// Kernels (byte/integer work, one pass over each level image; measured LDS-issue bound):
-//   k_pyr_fast0   one workgroup per 16-row band of level 0: the band (+3-row halo) is staged in LDS
-//                 with 16-B coalesced loads, levels 1..3 of the band are produced from LDS
-//                 ((a+b+c+d+2)>>2) and written, and FAST-10 runs on the staged rows in two phases: a 5-read
-//                 quick reject on every pixel, then the full segment test on the compacted survivors, which
-//                 set bits of the band's 64-bit corner-mask words in LDS.
-//   k_fast_lvl    the same FAST band sweep for levels 1..3 (their rows come back from L2/MALL).
-//   k_compact     per (stream, level): block scan over the popcounts of the mask words (raster order); every
-//                 thread expands its words at its scanned offset -> bit-exact raster-ordered corner list
-//                 and row LUT (jni/KeyFrame.cc:43-49) without ordered atomics.
+// Kernels (byte/integer work, one pass over each level image; VALU-issue bound):
+//   k_fast_slide<PYR>  the form used whenever the level widths are multiples of 4 and the input is 16-B aligned: a lane owns
+//                 a strip 16 pixels wide, walks down it with a sliding window of seven rows in registers (no LDS staging),
+//                 runs a branch-free quick reject on every pixel, compacts the ~2 % survivors per wavefront and runs the
+//                 16-pixel run-of-10 test on them; level 0 also writes its share of levels 1..3 from the same registers.
+//   k_pyr_fast0 / k_fast_lvl   the general path (any width / alignment): one workgroup per 16-row band staged in LDS,
+//                 pyramid from LDS, quick reject + compacted full test per 4 rows, corner-mask words in LDS.
+//   k_compact     per (band of rows, level, stream): the workgroup adds the row counts above its band, scans the popcounts
+//                 of its mask words (raster order) and every thread expands its words at its scanned offset -> bit-exact
+//                 raster-ordered corner list and row LUT (jni/KeyFrame.cc:43-49) without ordered atomics.
 //   k_score / k_nonmax   compute_fast_score_old + nonmax_suppression, one lane per corner.
 //   k_candidates / k_thin_candidates   MakeKeyFrame_Rest's Shi-Tomasi candidates (jni/KeyFrame.cc:66-95) and
 //                 MapMaker::ThinCandidates (jni/MapMaker.cc:393-422), ordered block compaction.

@@ -10,10 +10,12 @@
 //              (FindPatchCoarse/ZMSSDAtPoint) with packed-byte dot products and group shuffles
 //   k_subpixN  inverse-compositional sub-pixel refinement (MakeSubPixTemplate, IterateSubPix*) of the found patches
 //              that carry a sub-pixel budget
-//   k_pose     one workgroup per stream: the 10 Gauss-Newton iterations of a stage (:466-488 / :543-577):
-//              re-projection, 2x6 Jacobians, Tukey sigma (radix select for the median), weighted normal equations
-//              reduced with wave shuffles, 6x6 solve, SE3 exp; then measurement export, scene depth,
-//              UpdateMotionModel, AssessTrackingQuality and the new-keyframe decision (:594-625, :802-878, :128-132)
+//   k_pose     one workgroup (two wavefronts) per stream: the 10 Gauss-Newton iterations of a stage (:466-488 / :543-577):
+//              re-projection, 2x6 Jacobians, Tukey sigma (radix select for the median), weighted normal equations summed
+//              in the reference's order (one wavefront produces the add_mJ operands into LDS, lane q of the other walks
+//              sum q), 6x6 solve, SE3 exp; then measurement export, scene depth, UpdateMotionModel,
+//              AssessTrackingQuality and the new-keyframe decision (:594-625, :802-878, :128-132)
+// Transcendentals come from vslam_libm.h (one source for this file and the oracle); nothing here may be contracted into FMAs.
 #include "vslam_internal.h"
 
 #define TRK_THREADS 256
