@@ -1,24 +1,26 @@
 // Bundle::Compute (jni/Bundle.cc:136-178) / Do_LM_Step (:202-532) as ONE persistent workgroup per problem:
 // the whole Levenberg-Marquardt loop runs inside one launch, no host round-trip.
 //
-// The kernel is bound by HBM traffic (512 problems resident, every sweep goes to memory), so the layout is built around the
-// bytes an LM trial has to move (fp64, struct-of-arrays, component-major):
-//   cameras: pose, trial pose, fixed flag, start row, U (6x6 lower), epsilon_a
+// The layout is built around the bytes an LM trial has to move (fp64, struct-of-arrays, component-major) and around the dependent
+// loads a persistent workgroup of two wavefronts per SIMD cannot hide:
+//   cameras: pose, trial pose, fixed flag, start row, U (6x6 lower), epsilon_a     (poses and camera updates are read from LDS)
 //   points : position, trial position, V (3x3 lower), epsilon_b                      (V*^-1 is recomputed where it is used)
 //   measurements: the caller's list (AddMeas order = the reference's std::list order: ms_p, ms_c, ms_found, ms_sin, lut[c][p])
 //     is re-laid once per Compute into SLOTS: region F = the measurements in adjustable cameras, region X = those in fixed
-//     cameras, each point-major (points ascending, cameras ascending within a point).  A point's F slots are
-//     [pt_offF[p], pt_offF[p+1]) with pt_maskF[p] = set of adjustable-camera ordinals present, so "the measurement of point
-//     p in adjustable camera f" is an offset + a popcount instead of the lut's dependent 4-byte gather, and every sweep
-//     reads contiguous slots.  Per slot: static (camera | state, point, found position, sqrt-inv-noise = 32 B, logical
-//     index for the outlier order) and, rewritten once per LM step, v3Cam, the weighted camera derivatives and epsilon (72 B).
-//   The Jacobians A (2x6), B (2x3) and W = A^T B (6x3) are NOT stored: every consumer re-derives them from v3Cam, the
-//   weighted derivatives and the camera rotation.  Nothing of FindNewError's trial projection is stored either (the
-//   accepted state is projected again by the next step's sweep: same expressions, same bits): a trial writes 8 B per
-//   measurement (the squared error for the median).
-// Sweeps per accepted LM trial: one fused step sweep over all slots (projection, Tukey weight, V / epsilon_b by the point's
-// first lane out of LDS in slot order, U / epsilon_a by masked wavefront sums), then per trial the Schur operands (F slots), the
-// map update (F slots) and the trial error (all slots, static part only).
+//     cameras, each point-major (points ascending, cameras ascending within a point), cut into chunks of <= 64 slots of whole
+//     points.  A point's F slots are [pt_offF[p], pt_offF[p+1]) with pt_maskF[p] = set of adjustable-camera ordinals present, so
+//     "the measurement of point p in adjustable camera f" is an offset + a popcount instead of the lut's dependent 4-byte
+//     gather, and every sweep reads contiguous slots.  Per slot: static (camera | state | ordinal | has-F-slots, point, found
+//     position, sqrt-inv-noise = 32 B, logical index for the outlier order); rewritten once per LM step: the state, and for an
+//     F slot the four weighted camera derivatives (32 B) -- an X slot is consumed inside the sweep and stores nothing else.
+//   The Jacobians A (2x6), B (2x3) and W = A^T B (6x3) are NOT stored, nor is v3Cam (up to BA_FAST_FREE adjustable cameras):
+//   every consumer re-derives them from the point, the pose and the weighted derivatives -- the same expressions, the same bits.
+//   Nothing of FindNewError's trial projection is stored either (the accepted state is projected again by the next step's
+//   sweep): a trial writes 8 B per measurement (the squared error for the median).
+// Sweeps per accepted LM trial: one fused step sweep over all slots (projection, Tukey weight; V / epsilon_b by the point's first
+// lane out of LDS in slot order; U / epsilon_a: each lane's 27 products packed per camera in LDS, lane (camera, value) adds them
+// in slot order), then per trial the Schur operands (F slots, matrix cores), the map update (F slots) and the trial error (all
+// slots, static part only).  A slot's static fields are loaded a chunk ahead; points' leaders and counts come from ballots.
 // Reductions are deterministic (fixed lane / wave order, no floating-point atomics).
 #pragma once
 #include "dev_math.h"
