@@ -364,17 +364,18 @@ def test_thin_candidates_matches_oracle():
 
 
 def test_small_blurry_image_rotation_prior():
-    """use_sbi = 1 (the reference's gvnUseSBI): SmallBlurryImage template bit-exact, rotation prior and the tracked poses
+    """use_sbi = 1 (the reference's gvnUseSBI): SmallBlurryImage template, rotation prior and the tracked poses bit for bit
     against the oracle configured alike (jni/SmallBlurryImage.cc, jni/Tracker.cc:86-105, 781-798, 885-893)."""
     from oracle import binding as orc
     w, h = 640, 480
     f, m, frames = scene(w, h, 31, 8)
-    vp = capi.default_params(w, h, 2, patch_size=8, use_sbi=1)
+    kw = dict(patch_size=8, min_frames_between_kf=1000)       # no keyframe, so no bundle adjustment moves the map: every frame is ==
+    vp = capi.default_params(w, h, 2, use_sbi=1, **kw)
     g = capi.System(vp)
     for s in range(2):
         g.load_map(s, m); g.set_pose(s, f.pose(-1))
-    o = make_oracle(capi.default_params(w, h, 1, patch_size=8, use_sbi=1), m, f.pose(-1))
-    o_plain = make_oracle(capi.default_params(w, h, 1, patch_size=8), m, f.pose(-1))
+    o = make_oracle(capi.default_params(w, h, 1, use_sbi=1, **kw), m, f.pose(-1))
+    o_plain = make_oracle(capi.default_params(w, h, 1, **kw), m, f.pose(-1))
     changed = False
     prev_l3 = None
     for t in range(8):
@@ -384,11 +385,10 @@ def test_small_blurry_image_rotation_prior():
         wsmall, wtmpl = orc.sbi_make(l3)
         assert np.array_equal(small, wsmall) and np.array_equal(tmpl, wtmpl), t          # same float expressions, same order
         wrot, wscore = orc.sbi_rotation(l3, prev_l3 if prev_l3 is not None else l3, vp.cam[:])
-        assert np.abs(rot - wrot).max() < 1e-10 and abs(score - wscore) <= 1e-9 * max(1.0, wscore), (t, rot, wrot)
+        # sample positions accumulated and the ESM sums taken in the reference's order: the prior and its score are ==
+        assert np.array_equal(rot, wrot) and score == wscore, (t, rot, wrot, score, wscore)
         prev_l3 = l3
-        # the ESM sums of CalcSBIRotation are wave reductions: the prior agrees to 1e-10, the tracking that starts from it is held to the
-        # north_star tolerance (observed 1e-12 .. 3e-5)
-        assert_tracker_close(o, g, 0, "sbi frame %d" % t)
+        assert_tracker_exact(o, g, 0, "sbi frame %d" % t)                               # ... and so is the tracking that starts from it
         changed |= pose_err(o.state().pose, o_plain.state().pose) > 0
     assert changed
     g.close()

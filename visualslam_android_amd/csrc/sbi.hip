@@ -5,13 +5,21 @@
 //   IteratePosRelToTarget (:98-222)                                6 ESM iterations aligning this frame's SBI to the last one's
 //   SE3fromSE2 (:249-333) + Tracker::CalcSBIRotation (jni/Tracker.cc:885-893)   -> mv6SBIRot, read by k_pvs (ApplyMotionModel)
 // cv::resize / cv::GaussianBlur / Eigen's 4x4 inverse are third-party arithmetic, restated exactly as in oracle/sbi.cpp
-// (same float expressions in the same order: the template is bit-exact with the oracle; the ESM sums differ only in the
-// order of their fp64 reductions).
+// (same float expressions in the same order).  The whole stage is bit-exact with the oracle: the sample positions of
+// transform_image are accumulated pixel by pixel by two lanes, and the fifteen ESM sums are taken in the reference's
+// column-major order by fifteen lanes of wave 0 from per-pixel records the other threads stage in LDS.
 #include "vslam_internal.h"
 
 #define SBI_THREADS 256
 #define SBI_WAVES (SBI_THREADS / 64)
 #define SBI_MAX_PIX 4096          // (w/16) * (h/16) small-image pixels: 1200 at 640x480, 3600 at 1280x720
+#define SBI_REC 15                // per-pixel record: dDiff*J[0..3], the ten triangle products, dDiff^2
+#define SBI_CHUNK 128              // pixels staged per round of the sequential sums (two buffers: one filled while the other is added)
+// dynamic LDS: t0[N] t1[N] floats, then max(2N sample positions, two chunks of records) doubles
+static size_t sbi_lds_bytes(int N) {
+  const size_t a = (size_t)2 * N * sizeof(float), pos = (size_t)2 * N * sizeof(double), rec = (size_t)2 * SBI_CHUNK * SBI_REC * sizeof(double);
+  return ((a + 7) & ~(size_t)7) + (pos > rec ? pos : rec);
+}
 
 struct SbiArgs {
   const uint8_t* l3; size_t l3_sstride; int l3_pitch, w3, h3;
@@ -40,14 +48,16 @@ DEVFN Se2 se2_inverse(const Se2& a) {                              // :506-511
 DEVFN int clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
 
 __global__ __launch_bounds__(SBI_THREADS) void k_sbi(SbiArgs a) {
-  __shared__ float t0[SBI_MAX_PIX];      // zero-mean small image, later the warped template
-  __shared__ float t1[SBI_MAX_PIX];      // row pass, later this frame's template
-  __shared__ double red[SBI_WAVES][16];
+  extern __shared__ double sbi_dyn[];
+  __shared__ double sums[16];
   __shared__ unsigned int isum[SBI_WAVES];
   __shared__ Se2 shX;
   __shared__ double sh_mean_off;
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int W = a.w3 / 2, H = a.h3 / 2, N = W * H;
+  float* t0 = (float*)sbi_dyn;           // zero-mean small image, later the warped template
+  float* t1 = t0 + N;                    // row pass, later this frame's template
+  double* wk = sbi_dyn + (2 * N + 1) / 2;   // sample positions [N][2], then the records [2][SBI_CHUNK][SBI_REC]
   const uint8_t* l3 = a.l3 + (size_t)s * a.l3_sstride;
   uint8_t* small = a.small + (size_t)s * N;
   float* tmpl = a.tmpl + (size_t)s * N;
@@ -111,16 +121,24 @@ __global__ __launch_bounds__(SBI_THREADS) void k_sbi(SbiArgs a) {
   for (int it = 0; it < 6; it++) {
     if (tid == 0) shX = se2_mul(se2_mul(WfromC, CtoC), se2_inverse(WfromC));
     __syncthreads();
-    // transform_image<float> (jni/vision/ImageHandler.cpp:21-113).  The reference accumulates the sample position pixel by
-    // pixel (p += across, carriage return per row); here every pixel evaluates p0 + i * down + j * across directly, which
-    // differs from the accumulated value by a few ulp (1e-15 px) -- far inside the 1e-10 agreement of the rotation prior
-    // with the oracle, and it removes a 1200-long dependent chain from each of the six iterations.
+    // transform_image<float> (jni/vision/ImageHandler.cpp:21-113): the reference accumulates the sample position pixel by
+    // pixel (p += across, a carriage return per row); lane 0 walks x and lane 1 walks y exactly so, the rest sample.
+    const double mean_off = sh_mean_off;
+    if (tid < 2) {
+      const double across = tid ? shX.R[2] : shX.R[0], down = tid ? shX.R[3] : shX.R[1];
+      const double cr = down - W * across;
+      double p = shX.t[tid];
+      double* o = wk + tid;
+      for (int i = 0; i < H; i++, p += cr) {
+#pragma unroll 8
+        for (int j = 0; j < W; j++, p += across, o += 2) *o = p;
+      }
+    }
+    __syncthreads();
     {
-      const double ax = shX.R[0], ay = shX.R[2], dx = shX.R[1], dy = shX.R[3];
       const float x_bound = (float)(W - 1), y_bound = (float)(H - 1);
       for (int idx = tid; idx < N; idx += SBI_THREADS) {
-        const int i = idx / W, j = idx - i * W;
-        const double px = shX.t[0] + (i * dx + j * ax), py = shX.t[1] + (i * dy + j * ay);
+        const double px = wk[2 * idx], py = wk[2 * idx + 1];
         float v = -9e20f;
         if (0 <= px && 0 <= py && px < x_bound && py < y_bound) {
           double x = px, y = py;
@@ -133,32 +151,77 @@ __global__ __launch_bounds__(SBI_THREADS) void k_sbi(SbiArgs a) {
       }
     }
     __syncthreads();
-    double acc[16];
+    // the sums of :133-176 in the reference's order (columns outer, rows inner): the upper two waves stage one pixel's
+    // fifteen products each (zeros for a skipped pixel: x + 0.0 == x) into one record buffer while lanes 0..14 of wave 0
+    // add the other buffer's records one after the other; the template operands of a chunk are fetched a round ahead
+    const int nch = (N + SBI_CHUNK - 1) / SBI_CHUNK;
+    const bool producer = tid >= SBI_THREADS - SBI_CHUNK;
+    const int pt = tid - (SBI_THREADS - SBI_CHUNK);
+    double acc = 0.0;
+    float ltn = 0.f, j0n = 0.f, j1n = 0.f;
+    auto interior = [&](int q, int& i, int& j, int& idx) {
+      i = q / H; j = q - i * H; idx = j * W + i;
+      return q < N && i >= 1 && j >= 1 && i < W - 1 && j < H - 1;
+    };
+    auto fetch = [&](int c) {
+      int i, j, idx;
+      ltn = j0n = j1n = 0.f;
+      if (interior(c * SBI_CHUNK + pt, i, j, idx)) { ltn = ltmpl[idx]; j0n = ljacs[2 * idx]; j1n = ljacs[2 * idx + 1]; }
+    };
+    if (producer) fetch(0);
+    for (int c = 0; c <= nch; c++) {
+      if (producer) {
+        if (c < nch) {
+          const float lt = ltn, lj0 = j0n, lj1 = j1n;
+          fetch(c + 1);
+          const int q = c * SBI_CHUNK + pt;
+          int i, j, idx;
+          const bool in = interior(q, i, j, idx);
+          double r[SBI_REC];
 #pragma unroll
-    for (int k = 0; k < 16; k++) acc[k] = 0.0;
-    const double mean_off = sh_mean_off;
-    for (int idx = tid; idx < N; idx += SBI_THREADS) {
-      const int j = idx / W, i = idx - j * W;
-      if (!(i >= 1 && j >= 1 && i < W - 1 && j < H - 1)) continue;
-      const float l = t0[idx - 1], r = t0[idx + 1], u = t0[idx - W], d = t0[idx + W], here = t0[idx];
-      if (l + r + u + d + here < -9999.9) continue;
-      const double g0 = r - l, g1 = d - u;
-      const double s0 = 0.25 * (g0 + ljacs[2 * idx]), s1 = 0.25 * (g1 + ljacs[2 * idx + 1]);
-      const double J0 = s0, J1 = s1, J2 = -((double)j - cy) * s0 + ((double)i - cx) * s1;
-      const double dDiff = here - ltmpl[idx] + mean_off;
-      acc[14] += dDiff * dDiff;
-      acc[0] += dDiff * J0; acc[1] += dDiff * J1; acc[2] += dDiff * J2; acc[3] += dDiff;
-      acc[4] += J0 * J0; acc[5] += J1 * J0; acc[6] += J1 * J1; acc[7] += J2 * J0; acc[8] += J2 * J1; acc[9] += J2 * J2;
-      acc[10] += J0; acc[11] += J1; acc[12] += J2; acc[13] += 1.0;
+          for (int k = 0; k < SBI_REC; k++) r[k] = 0.0;
+          if (in) {
+            const float l = t0[idx - 1], rr = t0[idx + 1], u = t0[idx - W], d = t0[idx + W], here = t0[idx];
+            if (!(l + rr + u + d + here < -9999.9)) {
+              const double g0 = rr - l, g1 = d - u;
+              const double s0 = 0.25 * (g0 + lj0), s1 = 0.25 * (g1 + lj1);
+              const double J0 = s0, J1 = s1, J2 = -((double)j - cy) * s0 + ((double)i - cx) * s1;
+              const double dDiff = here - lt + mean_off;
+              r[14] = dDiff * dDiff;
+              r[0] = dDiff * J0; r[1] = dDiff * J1; r[2] = dDiff * J2; r[3] = dDiff;
+              r[4] = J0 * J0; r[5] = J1 * J0; r[6] = J1 * J1; r[7] = J2 * J0; r[8] = J2 * J1; r[9] = J2 * J2;
+              r[10] = J0; r[11] = J1; r[12] = J2; r[13] = 1.0;
+            }
+          }
+          if (q < N) {
+            double* o = wk + ((c & 1) * SBI_CHUNK + pt) * SBI_REC;
+#pragma unroll
+            for (int k = 0; k < SBI_REC; k++) o[k] = r[k];
+          }
+        }
+      } else if (tid < SBI_REC && c > 0) {
+        const int cnt = min(SBI_CHUNK, N - (c - 1) * SBI_CHUNK);
+        const double* rp = wk + ((c - 1) & 1) * SBI_CHUNK * SBI_REC + tid;
+        if (cnt == SBI_CHUNK) {
+#pragma unroll
+          for (int g = 0; g < SBI_CHUNK / 8; g++) {
+            double x[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) x[k] = rp[(g * 8 + k) * SBI_REC];
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc += x[k];
+          }
+        } else {
+          for (int p = 0; p < cnt; p++) acc += rp[p * SBI_REC];
+        }
+      }
+      __syncthreads();
     }
-    {
-      const double tot = wave_multi_sum<16>(acc);
-      if ((lane & 3) == 0) red[wave][wave_multi_index<16>(lane)] = tot;
-    }
+    if (tid < SBI_REC) sums[tid] = acc;
     __syncthreads();
     if (tid == 0) {
       double v[16];
-      for (int k = 0; k < 16; k++) { double x = 0.0; for (int w = 0; w < SBI_WAVES; w++) x += red[w][k]; v[k] = x; }
+      for (int k = 0; k < SBI_REC; k++) v[k] = sums[k];
       double m4[16], upd[4] = {v[0], v[1], v[2], v[3]};
       int q = 4;
       for (int j = 0; j < 4; j++) for (int i = 0; i <= j; i++) { m4[j * 4 + i] = v[q]; m4[i * 4 + j] = v[q]; q++; }
@@ -238,7 +301,9 @@ int fe_sbi(vslam_system* sys, const FrameDev& last) {
     for (int i = 0; i < 9; i++) a.k[i] = (float)(a.k[i] * sum);
   }
   cam_fill(a.cam, sys->p.cam, W, H, sys->p.quirks);
-  hipLaunchKernelGGL(k_sbi, dim3(sys->S), dim3(SBI_THREADS), 0, sys->fe_stream, a);
+  const size_t lds = sbi_lds_bytes(W * H);
+  if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_sbi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_sbi, dim3(sys->S), dim3(SBI_THREADS), lds, sys->fe_stream, a);
   HIPCHK(hipGetLastError());
   return VSLAM_OK;
 }
