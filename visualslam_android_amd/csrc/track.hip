@@ -641,24 +641,24 @@ DEVFN void item_store(const PoseItem& it, const PoseWs& w, int e, bool all) {   
 // turn (:736-768, jni/myWLS.h:39-50), every one of the 27 sums (21 of the upper triangle of C, 6 of v) a chain of
 // 2 nf dependent additions that starts from add_prior's value (:734).  fp addition does not associate, and PTAM's
 // templates are trunc(bilinear): a pose that differs in the last bit flips template pixels on flat image regions, so a
-// tree reduction would not do.  The workgroup is two wavefronts: wavefront 1 PRODUCES -- one lane per measurement, both
-// add_mJ calls: weight, Jacobian, 13 doubles per call (w J[0..5], J[0..5], m) -- a chunk ahead into LDS (the median's
-// sort buffer is free by then); lane q of wavefront 0 walks sum q through the chunk, per call two LDS reads at immediate
-// offsets, one product, one dependent addition.  Four such workgroups share a CU (one chain per SIMD).
-#define POSE_CHUNK 64                 // measurements per chunk: one per producer lane
-#define POSE_REC 13                   // doubles per add_mJ call
-#define POSE_ENT 27                   // doubles per measurement in LDS: two calls + one of padding (bank spread of the producer's stores)
+// tree reduction would not do.  The workgroup is two wavefronts: wavefront 1 PRODUCES -- one lane per add_mJ call (two
+// lanes per measurement): weight, its row of the Jacobian and the call's 27 products (w J[r]) * J[c] and m * (w J[k]) --
+// a chunk ahead into LDS (the median's sort buffer is free by then); lane q of wavefront 0 walks sum q through the
+// chunk: one LDS read per two calls (immediate offsets) and one dependent addition per call.  Four such workgroups share
+// a CU (one chain per SIMD).
+#define POSE_CHUNK 32                 // measurements per chunk: two producer lanes each
+#define POSE_ENT 27                   // doubles per add_mJ call in LDS: its 27 products (odd stride: bank spread of the producer's stores)
 #define POSE_GRP 8                    // add_mJ calls per register set of the chain (two sets alternate)
-static_assert(2 * POSE_CHUNK * POSE_ENT + (POSE_GRP / 2) * POSE_ENT <= SORT_CAP, "two record buffers (and the chain's one group of read-ahead) in the sort buffer");
-static_assert(POSE_THREADS == 128 && POSE_CHUNK == 64 && POSE_GRP % 2 == 0, "wavefront 0 chains, wavefront 1 produces");
+static_assert(2 * 2 * POSE_CHUNK * POSE_ENT + POSE_GRP * POSE_ENT + 64 <= SORT_CAP, "two record buffers (and the chain's one group of read-ahead) in the sort buffer");
+static_assert(POSE_THREADS == 128 && POSE_CHUNK == 32 && POSE_GRP % 2 == 0, "wavefront 0 chains, wavefront 1 produces");
 
-DEVFN void pose_chain_load(double (&va)[POSE_GRP], double (&vb)[POSE_GRP], const double* pa, const double* pb) {
+DEVFN void pose_chain_load(double (&v)[POSE_GRP], const double* p) {
 #pragma unroll
-  for (int u = 0; u < POSE_GRP; u++) { const int o = (u >> 1) * POSE_ENT + (u & 1) * POSE_REC; va[u] = pa[o]; vb[u] = pb[o]; }
+  for (int u = 0; u < POSE_GRP; u++) v[u] = p[u * POSE_ENT];
 }
-DEVFN void pose_chain_add(double& acc, const double (&va)[POSE_GRP], const double (&vb)[POSE_GRP]) {
+DEVFN void pose_chain_add(double& acc, const double (&v)[POSE_GRP]) {
 #pragma unroll
-  for (int u = 0; u < POSE_GRP; u++) acc += va[u] * vb[u];
+  for (int u = 0; u < POSE_GRP; u++) acc += v[u];
 }
 
 DEVFN void calc_pose_update(const PoseWs& ws, MapPointDev* pts, int nf, const TrackParams& tp,
@@ -680,18 +680,14 @@ DEVFN void calc_pose_update(const PoseWs& ws, MapPointDev* pts, int nf, const Tr
   POSE_STAMP(3);
   const bool qint = (tp.quirks & VSLAM_Q_POSE_INT_RESIDUAL) != 0;
   const int nchunks = (nf + POSE_CHUNK - 1) / POSE_CHUNK;
-  constexpr int BUF = POSE_CHUNK * POSE_ENT;
+  constexpr int BUF = 2 * POSE_CHUNK * POSE_ENT;
   const bool producer = wave == 1;
   // sum q of the chain: upper triangle of C row by row (0..20), then v (21..26); the diagonal starts at the prior
   double acc = 0.0;
-  int ia = 0, ib = 0;                                               // this lane's two operands inside a record
-  {
-    int q = 0;
-    for (int r = 0; r < 6; r++) for (int c = r; c < 6; c++) { if (q == lane) { ia = r; ib = 6 + c; } q++; }
-    if (lane >= 21 && lane < 27) { ia = 12; ib = lane - 21; }
-    if (lane == 0 || lane == 6 || lane == 11 || lane == 15 || lane == 18 || lane == 20) acc = 0.0 + tp.wls_prior;   // add_prior, :734
-  }
-  // one measurement -> its two records; a measurement past the end, or one the reference skips (weight 0), is zeros: x + 0 * 0 = x
+  if (lane == 0 || lane == 6 || lane == 11 || lane == 15 || lane == 18 || lane == 20) acc = 0.0 + tp.wls_prior;   // add_prior, :734
+  // producer lane = (measurement, row): the products of one add_mJ call; a measurement past the end, or one the reference
+  // skips (weight 0), is a record of zeros: x + 0 = x
+  const int row = lane & 1, pm = lane >> 1;
   auto produce = [&](const PoseItem& t, int e, double* buf) {
     double* dst = buf + lane * POSE_ENT;
     double w = 0.0, err[2] = {0.0, 0.0};
@@ -699,54 +695,63 @@ DEVFN void calc_pose_update(const PoseWs& ws, MapPointDev* pts, int nf, const Tr
       err[0] = (t.vfound[0] - t.image[0]) * t.sqrt_inv_noise; err[1] = (t.vfound[1] - t.image[1]) * t.sqrt_inv_noise;
       const double es = err[0] * err[0] + err[1] * err[1];
       w = tukey_weight(es, sigma2);
-      if (bMarkOutliers) { if (w == 0.0) pts[t.idx].n_out++; else pts[t.idx].n_in++; }   // :749-756
+      if (bMarkOutliers && row == 0) { if (w == 0.0) pts[t.idx].n_out++; else pts[t.idx].n_in++; }   // :749-756
     }
     if (w == 0.0) {
 #pragma unroll
-      for (int k = 0; k < 2 * POSE_REC; k++) dst[k] = 0.0;
+      for (int k = 0; k < POSE_ENT; k++) dst[k] = 0.0;
       return;
     }
-    double jac[12];
-    td_calc_jacobian(t, jac);                                        // CalcJacobian, jni/TrackerData.h:107-122
+    // this row of CalcJacobian (jni/TrackerData.h:107-122), then wls.add_mJ(v2(row), sqrt_inv_noise * J.row(row), w), :760-767
+    const double ooz = 1.0 / t.cam[2];
+    const double c[3] = {t.cam[0], t.cam[1], t.cam[2]};
+    const double da = row ? t.derivs[2] : t.derivs[0], db = row ? t.derivs[3] : t.derivs[1];
+    double J[6], wJ[6];
 #pragma unroll
-    for (int row = 0; row < 2; row++) {
-#pragma unroll
-      for (int k = 0; k < 6; k++) {
-        const double J = t.sqrt_inv_noise * jac[6 * row + k];        // wls.add_mJ(v2(row), sqrt_inv_noise * J.row(row), w), :760-767
-        dst[row * POSE_REC + k] = w * J; dst[row * POSE_REC + 6 + k] = J;
-      }
-      dst[row * POSE_REC + 12] = qint ? (double)(int)err[row] : err[row];
+    for (int m = 0; m < 6; m++) {
+      double f0, f1;
+      se3_generator_motion(m, c, ooz, f0, f1);
+      J[m] = t.sqrt_inv_noise * (da * f0 + db * f1);
+      wJ[m] = w * J[m];
     }
+    const double e_ = row ? err[1] : err[0];
+    const double mm = qint ? (double)(int)e_ : e_;
+    int q = 0;
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int cc = r; cc < 6; cc++) dst[q++] = wJ[r] * J[cc];
+#pragma unroll
+    for (int k = 0; k < 6; k++) dst[21 + k] = mm * wJ[k];
   };
   PoseItem cur, nx;
   if (producer) {
-    item_load(cur, ws, lane < nf ? lane : nf - 1);
-    item_load(nx, ws, POSE_CHUNK + lane < nf ? POSE_CHUNK + lane : nf - 1);
+    item_load(cur, ws, pm < nf ? pm : nf - 1);
+    item_load(nx, ws, POSE_CHUNK + pm < nf ? POSE_CHUNK + pm : nf - 1);
   }
   __syncthreads();                                                  // the median has left the sort buffer
-  if (producer) produce(cur, lane, sortbuf);
+  if (producer) produce(cur, pm, sortbuf);
   __syncthreads();
   for (int k = 0; k < nchunks; k++) {
     if (producer) {
       if (k + 1 < nchunks) {
         cur = nx;
-        const int e2 = (k + 2) * POSE_CHUNK + lane;
+        const int e2 = (k + 2) * POSE_CHUNK + pm;
         item_load(nx, ws, e2 < nf ? e2 : nf - 1);
-        produce(cur, (k + 1) * POSE_CHUNK + lane, sortbuf + ((k + 1) & 1) * BUF);
+        produce(cur, (k + 1) * POSE_CHUNK + pm, sortbuf + ((k + 1) & 1) * BUF);
       }
     } else {
       const int left = nf - k * POSE_CHUNK;
       const int ng = (2 * (left < POSE_CHUNK ? left : POSE_CHUNK) + POSE_GRP - 1) / POSE_GRP;    // groups of calls in this chunk (the tail is zero records)
-      constexpr int GSTR = (POSE_GRP / 2) * POSE_ENT;
-      const double* pa = sortbuf + (k & 1) * BUF + ia;
-      const double* pb = sortbuf + (k & 1) * BUF + ib;
-      double a0[POSE_GRP], b0[POSE_GRP], a1[POSE_GRP], b1[POSE_GRP];
-      pose_chain_load(a0, b0, pa, pb);
+      constexpr int GSTR = POSE_GRP * POSE_ENT;
+      const double* rp = sortbuf + (k & 1) * BUF + lane;
+      double x0[POSE_GRP], x1[POSE_GRP];
+      pose_chain_load(x0, rp);
       for (int g = 0; g < ng; g += 2) {                              // the read-ahead past the last group stays inside the sort buffer
-        pose_chain_load(a1, b1, pa + (g + 1) * GSTR, pb + (g + 1) * GSTR);
-        pose_chain_add(acc, a0, b0);
-        pose_chain_load(a0, b0, pa + (g + 2) * GSTR, pb + (g + 2) * GSTR);
-        if (g + 1 < ng) pose_chain_add(acc, a1, b1);
+        pose_chain_load(x1, rp + (g + 1) * GSTR);
+        pose_chain_add(acc, x0);
+        pose_chain_load(x0, rp + (g + 2) * GSTR);
+        if (g + 1 < ng) pose_chain_add(acc, x1);
       }
     }
     __syncthreads();
