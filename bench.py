@@ -174,7 +174,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("VSLAM_BENCH_STREAMS", 1024)), help="sequences per GPU")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("VSLAM_BENCH_STREAMS", 2048)), help="sequences per GPU")
     ap.add_argument("--systems", type=int, default=int(os.environ.get("VSLAM_BENCH_SYSTEMS", 1)),
                     help="split the streams over this many vslam_system handles (one HIP stream each) so their kernels overlap")
     ap.add_argument("--width", type=int, default=640)
@@ -184,7 +184,7 @@ def main():
     ap.add_argument("--ba-delay", type=int, default=int(os.environ.get("VSLAM_BENCH_BA_DELAY", 16)),
                     help="vslam_params.ba_delay_frames: 0 = synchronous map-maker; D > 0 = Bundle::Compute on its own HIP stream, applied D frames later")
     ap.add_argument("--ba-batch", type=int, default=int(os.environ.get("VSLAM_BENCH_BA_BATCH", 0)),
-                    help="vslam_params.ba_batch_frames: the keyframes of this many consecutive frames share one Bundle::Compute launch (0 = chosen so that a launch carries about two problems per compute unit)")
+                    help="vslam_params.ba_batch_frames: the keyframes of this many consecutive frames share one Bundle::Compute launch (0 = chosen so that a launch carries about four problems per compute unit)")
     ap.add_argument("--ba-window", type=int, default=5, help="vslam_params.ba_window (jni/MapMaker.cc:812-820: 5; BASELINE configs[3]: 10)")
     ap.add_argument("--max-keyframes", type=int, default=32)
     ap.add_argument("--corners-per-level", type=str, default="", help="map points per pyramid level of the synthetic map, e.g. 1400,420,130,40 (default: the feeder's)")
@@ -197,6 +197,7 @@ def main():
     ap.add_argument("--diag-kf-dist-mult", type=float, default=None,
                     help="DIAGNOSTIC ONLY (not the metric): overrides vslam_params.max_kf_dist_wiggle_mult, e.g. 1e9 = no keyframes, no BA")
     ap.add_argument("--no-events", action="store_true", help="skip the per-stage HIP events in the timed region")
+    ap.add_argument("--no-all-cores", action="store_true", help="skip the all-host-cores leg of cpu_baseline (one oracle process per core)")
     ap.add_argument("--no-flat-out", action="store_true", help="skip the flat-out bundle-adjustment round measured after the timed region")
     ap.add_argument("--parity-check", type=int, default=1, help="1: compare stream 0's final pose with the oracle run on the same frames")
     args = ap.parse_args()
@@ -205,6 +206,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank, world, local_rank = dist_env()
+    t_prog = time.perf_counter()
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the torch.distributed world has %d ranks" % (args.gpus, world))
 
@@ -274,9 +276,9 @@ def main():
     ba_batch = args.ba_batch
     if args.ba_delay <= 0:
         ba_batch = 1
-    elif ba_batch <= 0:                        # about two problems per compute unit per launch, and done well inside the delay window
+    elif ba_batch <= 0:                        # about four problems per compute unit per launch, and done well inside the delay window
         per_frame = Sk / float(stagger) if stagger else float(Sk)
-        ba_batch = int(max(1, min(args.ba_delay - 6, (2 * ncu) // max(1.0, per_frame))))
+        ba_batch = int(max(1, min(args.ba_delay - 6, (4 * ncu) // max(1.0, per_frame))))
     vp_kw = dict(patch_size=args.patch, ba_delay_frames=args.ba_delay, use_sbi=args.use_sbi, grow_map=args.grow_map, ba_window=args.ba_window,
                  max_keyframes=args.max_keyframes)
     vpk = capi.default_params(W, H, Sk, device=local_rank, ba_batch_frames=ba_batch, **vp_kw)
@@ -317,6 +319,10 @@ def main():
         sy, ls = sys_of(s)
         return sy.state(ls)
 
+    def note(msg):                              # progress on stderr: a long run must not look hung to the box's watchdog
+        if rank == 0:
+            print("[bench] %s (%.0f s)" % (msg, time.perf_counter() - t_prog), file=sys.stderr, flush=True)
+    note("set-up done")
     # ---- warm-up, then the timed region ---------------------------------------------------------------------------------
     for t in range(Wm):
         step(t)
@@ -367,6 +373,7 @@ def main():
 
     # ---- a flat-out round of the bundle adjustment: every stream's BundleAdjustRecent in ONE launch, nothing beside it ------
     flat = None
+    note("timed region done")
     if not args.no_flat_out and args.diag_kf_dist_mult is None:
         try:
             sync_all()
@@ -453,10 +460,14 @@ def main():
             o.close()
         n_seq = 400                             # frames per oracle sequence: 19 keyframes, under the 32-keyframe capacity of the device path
         job = (vp_kw, 900000, W, H, n_seq, args.cpu_seconds, map_kw)
+        note("gpu side done, cpu_baseline starts")
         n_cpu, cpu_s, cpu_kf = cpu_worker(job)
+        note("cpu_baseline (1 core) done")
         ncores = os.cpu_count() or 1
         all_cores = None
-        try:                                    # the same on every host core at once (independent sequences, one process each)
+        try:
+            if args.no_all_cores:
+                raise RuntimeError("skipped (--no-all-cores)")                                    # the same on every host core at once (independent sequences, one process each)
             import multiprocessing as mp
             with mp.get_context("spawn").Pool(ncores) as pool:
                 t_a = time.perf_counter()

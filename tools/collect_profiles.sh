@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 python3 bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
 echo "bench done"
 rm -rf /tmp/prof1
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof1 -o $TAG -- python3 bench.py > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_rp1.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof1 -o $TAG -- python3 bench.py --no-all-cores --cpu-seconds 3 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_rp1.err
 cp "$(find /tmp/prof1 -name '*kernel_stats.csv' | head -1)" $OUT/${TAG}_bench_kernel_stats.csv
 python3 tools/trace_summary.py --min-grid 60000 "$(find /tmp/prof1 -name '*kernel_trace.csv' | head -1)" > $OUT/${TAG}_bench_kernel_stats_batched.csv
 python3 tools/timeline.py "$(find /tmp/prof1 -name '*kernel_trace.csv' | head -1)" --steps 50 > $OUT/${TAG}_timeline.txt
