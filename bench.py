@@ -440,7 +440,9 @@ def main():
 
             # the dominant kernel = the largest summed HIP-event time over the timed region among the kernels with a byte model
             cands = [n for n in ("ba_compute", "front_end", "search_fine", "pose_fine") if n in stage_ms and stage_bytes(n) > 0]
-            ranked = sorted(cands, key=lambda n: -stage_ms[n])
+            # (the front end is three kernels in a row -- level 0 + pyramid, levels 1-3, compaction: it ranks by its longest one)
+            fe_longest = max(stage_ms.get("pyr_fast0", 0.0), stage_ms.get("fast_lvl", 0.0), stage_ms.get("compact", 0.0))
+            ranked = sorted(cands, key=lambda n: -(fe_longest if n == "front_end" else stage_ms[n]))
             if ranked:
                 roof = roofline_of(ranked[0])
                 roof["others"] = [roofline_of(n) for n in ranked[1:]]

@@ -22,7 +22,10 @@ poses = [x for x in rows if x[2].startswith("k_pose") and x[4] >= a.min_grid]
 ends = [x[1] for x in poses]
 per = 2 if len(poses) >= 2 * a.steps + 2 and (poses[-1][0] - poses[-2][0]) < (poses[-2][0] - poses[-3][0]) else 1
 first = poses[-a.steps * per - 1][1] if len(poses) > a.steps * per else rows[0][0]
-t0, t1 = first, poses[-1][1]
+# (between the warm-up and the timed region bench.py reads every stream's state: a run of small copies that is not part of the window)
+rows = [x for x in rows if not x[2].startswith("__amd_rocclr_copyBuffer")]
+t0 = min([x[0] for x in rows if x[0] >= first] or [first])
+t1 = poses[-1][1]
 print("window %.3f ms, %d steps -> %.3f ms/step" % ((t1 - t0) / 1e6, a.steps, (t1 - t0) / 1e6 / a.steps))
 acc = collections.defaultdict(lambda: [0, 0]); q = collections.defaultdict(list)
 ev = []
@@ -44,3 +47,15 @@ for n, (d, c) in sorted(acc.items(), key=lambda kv: -kv[1][0]):
     print("%-44s %6d launches %9.3f ms/step %6.1f %% of window" % (n[:44], c, d / 1e6 / a.steps, 100.0 * d / (t1 - t0)))
 for qu, iv in q.items():
     print("queue %s busy %.1f %%" % (qu, 100.0 * sum(e - s for s, e in iv) / (t1 - t0)))
+# the idle gaps of the window (no kernel in flight): how many, how long, and what ran before / after the longest ones
+inw = sorted((max(s, t0), min(e, t1), n, qu) for s, e, n, qu, g in rows if min(e, t1) > max(s, t0))
+gaps = []; cur_end = t0; last_n = ("-", "-")
+for s, e, n, qu in inw:
+    if s > cur_end: gaps.append((s - cur_end, cur_end - t0, last_n, (n, qu)))
+    if e > cur_end: cur_end = e; last_n = (n, qu)
+tot_gap = sum(g[0] for g in gaps)
+print("idle gaps: %d, %.3f ms in all (%.1f %% of the window), median %.1f us" % (len(gaps), tot_gap / 1e6, 100.0 * tot_gap / (t1 - t0), sorted(g[0] for g in gaps)[len(gaps) // 2] / 1e3 if gaps else 0.0))
+byk = collections.defaultdict(lambda: [0, 0])
+for d, at, a_, b_ in gaps: byk[(a_[0][:28], b_[0][:28])][0] += d; byk[(a_[0][:28], b_[0][:28])][1] += 1
+for (ka, kb), (d, c) in sorted(byk.items(), key=lambda kv: -kv[1][0])[:12]:
+    print("  after %-28s before %-28s %5d gaps %8.3f ms" % (ka, kb, c, d / 1e6))

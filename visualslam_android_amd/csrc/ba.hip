@@ -55,14 +55,23 @@ __host__ __device__ inline BaView ba_view(const BaPool& b, int n) {
 __global__ __launch_bounds__(BA_THREADS) __attribute__((amdgpu_waves_per_eu(VSLAM_BA_WPE, VSLAM_BA_WPE))) void k_ba_compute(BaPool pool, BaConfig cfg, int slot) {
   // slot < 0: one workgroup per problem of the pool (synchronous map-maker, stand-alone Bundle); slot >= 0: the grid walks the
   // work list of one frame (asynchronous map-maker)
+  // (the persistent workgroups of an asynchronous launch draw their next list entry from a counter: the long and the short
+  // adjustments of a batch balance themselves instead of leaving the workgroups that drew two long ones alone at the end)
   const int count = slot < 0 ? pool.N : pool.work_n[slot];
-  for (int i = blockIdx.x; i < count; i += gridDim.x) {
+  __shared__ int s_next;
+  int i = blockIdx.x;
+  while (i < count) {
     const int n = slot < 0 ? i : pool.work[(size_t)slot * pool.N + i];
     const BaView v = ba_view(pool, n);
-    if (!v.res->active || v.res->computed) continue;
-    ba_compute(v, cfg);
-    if (threadIdx.x == 0) v.res->computed = 1;
+    if (v.res->active && !v.res->computed) {
+      ba_compute(v, cfg);
+      if (threadIdx.x == 0) v.res->computed = 1;
+    }
+    if (slot < 0) break;                                            // one workgroup per problem
     __syncthreads();
+    if (threadIdx.x == 0) s_next = (int)gridDim.x + atomicAdd(&pool.work_n[pool.work_slots + slot], 1);
+    __syncthreads();
+    i = s_next;
   }
 }
 
@@ -92,7 +101,7 @@ static int pool_create(BaPool& b, std::vector<void*>& allocs, hipStream_t st, in
   PALLOC(S, n * F * F); PALLOC(E, n * F); PALLOC(cam_up, n * F);
   PALLOC(scratch, n * M); PALLOC(outl, n * M * 2); PALLOC(free_cams, n * C); PALLOC(id_view, n * C); PALLOC(id_point, n * P);
   b.work_slots = work_slots > 0 ? work_slots : 1;
-  PALLOC(work, n * b.work_slots); PALLOC(work_n, (size_t)b.work_slots); PALLOC(view_of_kf, n * BA_MAX_KF);
+  PALLOC(work, n * b.work_slots); PALLOC(work_n, (size_t)2 * b.work_slots);   /* work_n[work_slots + slot]: the launch's draw counter */ PALLOC(view_of_kf, n * BA_MAX_KF);
   return VSLAM_OK;
 }
 
@@ -707,6 +716,7 @@ int ba_run(vslam_system* sys, int mode) {
     HIPCHK(hipStreamWaitEvent(bs, sys->ev_asm[es], 0));
     if (sys->ba_batch_fill == 0)
       HIPCHK(hipMemsetAsync(ws->pool.work_n + slot, 0, sizeof(int), bs));   // the launch that read this slot R batches ago was waited for (ba_frame_start)
+    if (sys->ba_batch_fill == 0) HIPCHK(hipMemsetAsync(ws->pool.work_n + ws->pool.work_slots + slot, 0, sizeof(int), bs));
     hipLaunchKernelGGL(k_ba_assemble, dim3(sys->S), dim3(BA_THREADS), 0, bs, sys->map, sys->tp, ws->pool, mode, slot);
     sys->frame_batch[(size_t)(sys->frame_no % (long)sys->frame_batch.size())] = sys->ba_batch_id;
     sys->ba_batch_fill++;
