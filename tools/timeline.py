@@ -26,7 +26,16 @@ first = poses[-a.steps * per - 1][1] if len(poses) > a.steps * per else rows[0][
 rows = [x for x in rows if not x[2].startswith("__amd_rocclr_copyBuffer")]
 t0 = min([x[0] for x in rows if x[0] >= first] or [first])
 t1 = poses[-1][1]
-print("window %.3f ms, %d steps -> %.3f ms/step" % ((t1 - t0) / 1e6, a.steps, (t1 - t0) / 1e6 / a.steps))
+# pauses of the whole device longer than 5 ms are the host's (bench.py reading every stream's state around the timed region): they
+# are taken out of the window
+_iv = sorted((max(s, t0), min(e, t1)) for s, e, n, qu, g in rows if min(e, t1) > max(s, t0))
+pauses = []; _ce = t0
+for s_, e_ in _iv:
+    if s_ - _ce > 5_000_000: pauses.append((_ce, s_))
+    _ce = max(_ce, e_)
+paused = sum(b - a_ for a_, b in pauses)
+WIN = (t1 - t0) - paused
+print("window %.3f ms (%d host pauses of %.1f ms in all taken out), %d steps -> %.3f ms/step" % (WIN / 1e6, len(pauses), paused / 1e6, a.steps, WIN / 1e6 / a.steps))
 acc = collections.defaultdict(lambda: [0, 0]); q = collections.defaultdict(list)
 ev = []
 for s, e, n, qu, g in rows:
@@ -40,21 +49,22 @@ for t, d in ev:
     hist[depth] += t - last
     depth += d; last = t
 hist[0] += t1 - last
-print("some kernel running: %.1f %% of the window; concurrency histogram (kernels in flight: %% of time): %s" % (100.0 * busy / (t1 - t0), {k: round(100.0 * v / (t1 - t0), 1) for k, v in sorted(hist.items())}))
+hist[0] -= paused
+print("some kernel running: %.1f %% of the window; concurrency histogram (kernels in flight: %% of time): %s" % (100.0 * busy / WIN, {k: round(100.0 * v / WIN, 1) for k, v in sorted(hist.items())}))
 tot = sum(v[0] for v in acc.values())
-print("sum of kernel durations / window = %.2f" % (tot / (t1 - t0)))
+print("sum of kernel durations / window = %.2f" % (tot / WIN))
 for n, (d, c) in sorted(acc.items(), key=lambda kv: -kv[1][0]):
-    print("%-44s %6d launches %9.3f ms/step %6.1f %% of window" % (n[:44], c, d / 1e6 / a.steps, 100.0 * d / (t1 - t0)))
+    print("%-44s %6d launches %9.3f ms/step %6.1f %% of window" % (n[:44], c, d / 1e6 / a.steps, 100.0 * d / WIN))
 for qu, iv in q.items():
-    print("queue %s busy %.1f %%" % (qu, 100.0 * sum(e - s for s, e in iv) / (t1 - t0)))
+    print("queue %s busy %.1f %%" % (qu, 100.0 * sum(e - s for s, e in iv) / WIN))
 # the idle gaps of the window (no kernel in flight): how many, how long, and what ran before / after the longest ones
 inw = sorted((max(s, t0), min(e, t1), n, qu) for s, e, n, qu, g in rows if min(e, t1) > max(s, t0))
 gaps = []; cur_end = t0; last_n = ("-", "-")
 for s, e, n, qu in inw:
-    if s > cur_end: gaps.append((s - cur_end, cur_end - t0, last_n, (n, qu)))
+    if s > cur_end and s - cur_end <= 5_000_000: gaps.append((s - cur_end, cur_end - t0, last_n, (n, qu)))
     if e > cur_end: cur_end = e; last_n = (n, qu)
 tot_gap = sum(g[0] for g in gaps)
-print("idle gaps: %d, %.3f ms in all (%.1f %% of the window), median %.1f us" % (len(gaps), tot_gap / 1e6, 100.0 * tot_gap / (t1 - t0), sorted(g[0] for g in gaps)[len(gaps) // 2] / 1e3 if gaps else 0.0))
+print("idle gaps: %d, %.3f ms in all (%.1f %% of the window), median %.1f us" % (len(gaps), tot_gap / 1e6, 100.0 * tot_gap / WIN, sorted(g[0] for g in gaps)[len(gaps) // 2] / 1e3 if gaps else 0.0))
 byk = collections.defaultdict(lambda: [0, 0])
 for d, at, a_, b_ in gaps: byk[(a_[0][:28], b_[0][:28])][0] += d; byk[(a_[0][:28], b_[0][:28])][1] += 1
 for (ka, kb), (d, c) in sorted(byk.items(), key=lambda kv: -kv[1][0])[:12]:
