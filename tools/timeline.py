@@ -69,3 +69,14 @@ byk = collections.defaultdict(lambda: [0, 0])
 for d, at, a_, b_ in gaps: byk[(a_[0][:28], b_[0][:28])][0] += d; byk[(a_[0][:28], b_[0][:28])][1] += 1
 for (ka, kb), (d, c) in sorted(byk.items(), key=lambda kv: -kv[1][0])[:12]:
     print("  after %-28s before %-28s %5d gaps %8.3f ms" % (ka, kb, c, d / 1e6))
+# per queue: where its own idle time goes (the kernel before / after each gap of that queue, pauses excluded)
+for qu, iv in sorted(q.items(), key=lambda kv: -sum(e - s for s, e in kv[1]))[:2]:
+    mine = sorted((max(s, t0), min(e, t1), n) for s, e, n, qq, g in rows if qq == qu and min(e, t1) > max(s, t0))
+    pair = collections.defaultdict(lambda: [0, 0]); ce = None; ln = "-"
+    for s, e, n in mine:
+        if ce is not None and s > ce and s - ce <= 5_000_000: pair[(ln[:26], n[:26])][0] += s - ce; pair[(ln[:26], n[:26])][1] += 1
+        if ce is None or e > ce: ce = e; ln = n
+    tot_q = sum(v[0] for v in pair.values())
+    print("queue %s idle between its own kernels: %.3f ms (%.1f %% of the window)" % (qu, tot_q / 1e6, 100.0 * tot_q / WIN))
+    for (ka, kb), (d, c) in sorted(pair.items(), key=lambda kv: -kv[1][0])[:10]:
+        print("  after %-26s before %-26s %5d gaps %8.3f ms" % (ka, kb, c, d / 1e6))
