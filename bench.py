@@ -337,6 +337,7 @@ def main():
     t0 = time.perf_counter()
     for t in range(Wm, T):
         step(t)
+    enqueue_s = time.perf_counter() - t0        # the host's share: issuing the K steps (launches only, nothing waited for)
     sync_all()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -492,7 +493,8 @@ def main():
                        "patches_attempted_per_frame": round(att, 1), "patches_found_per_frame": round(fnd, 1),
                        "zmssd_evals_per_frame": round(zm, 1), "keyframes_per_step": round(kf_adds * S / K, 2),
                        "keyframes_added_per_stream": round(kf_adds, 3), "ba_trials_per_stream": round(ba_trials, 3),
-                       "streams_tracking_good": good, "setup_seconds": round(setup_s, 1)},
+                       "streams_tracking_good": good, "setup_seconds": round(setup_s, 1),
+                       "host_enqueue_ms_per_step": round(1e3 * enqueue_s / K, 3)},
             "roofline": roof,
             "cpu_baseline": {"value": round(n_cpu / cpu_s, 2), "unit": "frames/s", "cores": 1, "kind": "port",
                              "sample": "oracle TrackFrame+BA (oracle/, -O3, one thread) over %d frames of synthetic sequences of the same workload (own seeds; %d keyframes with their bundle adjustment), %.1f s" % (n_cpu, cpu_kf, cpu_s),
