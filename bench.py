@@ -234,8 +234,13 @@ def main():
         return out
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    one_gpu = os.environ.get("VSLAM_BENCH_ONE_GPU") == "1"   # rehearsal of the multi-rank path on a one-GPU box: every rank on cuda:0, gloo
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 and one_gpu:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         if dist.get_world_size() != args.gpus:
             raise SystemExit("bench.py: RCCL sees %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
@@ -397,6 +402,7 @@ def main():
     total_t, gathered = aggregate(elapsed, [elapsed, S * K, zm, att, fnd, kf_adds, ba_trials, good], world)
     frames_total = sum(g[1] for g in gathered)
     value = frames_total / total_t
+    good = int(round(sum(g[7] for g in gathered)))        # streams tracking GOOD at the end, all ranks
 
     out = None
     if rank == 0:
@@ -464,11 +470,14 @@ def main():
         n_seq = 400                             # frames per oracle sequence: 19 keyframes, under the 32-keyframe capacity of the device path
         job = (vp_kw, 900000, W, H, n_seq, args.cpu_seconds, map_kw)
         note("gpu side done, cpu_baseline starts")
-        n_cpu, cpu_s, cpu_kf = cpu_worker(job)
+        # (timed at N = 1 only: beside N - 1 ranks waiting at the last barrier it would only lengthen the multi-GPU runs)
+        n_cpu, cpu_s, cpu_kf = cpu_worker(job) if world == 1 else (0, 1.0, 0)
         note("cpu_baseline (1 core) done")
         ncores = os.cpu_count() or 1
         all_cores = None
         try:
+            if world > 1:
+                raise RuntimeError("skipped (measured at N = 1 only)")
             if args.no_all_cores:
                 raise RuntimeError("skipped (--no-all-cores)")                                    # the same on every host core at once (independent sequences, one process each)
             import multiprocessing as mp
@@ -496,7 +505,8 @@ def main():
                        "streams_tracking_good": good, "setup_seconds": round(setup_s, 1),
                        "host_enqueue_ms_per_step": round(1e3 * enqueue_s / K, 3)},
             "roofline": roof,
-            "cpu_baseline": {"value": round(n_cpu / cpu_s, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+            "cpu_baseline": {"skipped": "measured at N = 1 only"} if world > 1 else
+                            {"value": round(n_cpu / cpu_s, 2), "unit": "frames/s", "cores": 1, "kind": "port",
                              "sample": "oracle TrackFrame+BA (oracle/, -O3, one thread) over %d frames of synthetic sequences of the same workload (own seeds; %d keyframes with their bundle adjustment), %.1f s" % (n_cpu, cpu_kf, cpu_s),
                              "all_cores": all_cores},
             "stages": stages,
