@@ -115,8 +115,9 @@ int vslam_eval_transcendental(int fn, int n, const double* x, double* y, int on_
 /* KeyFrame::MakeKeyFrame_Lite (jni/KeyFrame.cc:5-51) for all n_streams frames at once:
  * 4-level pyramid, FAST-10 per level, raster-ordered corner lists and row LUTs, all on device.
  * gray: n_streams images, image s at gray + s*stream_stride, rows row_stride bytes apart;
- * on_device != 0 means gray is device memory (borrowed until the next front-end call).
- * Asynchronous on the system's stream. */
+ * on_device != 0 means gray is device memory (borrowed until the next front-end call; with vslam_params.bootstrap until the
+ * frame AFTER the next has been enqueued and this one's work has finished: the trail tracker reads the previous frame's level 0
+ * in place, jni/Tracker.cc:294-346).  Asynchronous on the system's stream. */
 int vslam_make_keyframe_lite(vslam_system* sys, const uint8_t* gray, size_t row_stride,
                              size_t stream_stride, int on_device);
 

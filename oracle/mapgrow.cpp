@@ -6,7 +6,7 @@
 //   MapPoint::RefreshPixelVectors                 jni/MapPoint.cc:4-29
 //   PatchFinder::MakeTemplateCoarseNoWarp         jni/PatchFinder.cc:130-142
 //   MapMaker::ReFind_Common / ReFindInSingleKeyFrame  jni/MapMaker.cc:967-1056  (grow_map bit 1)
-// Not built (documented in DESIGN.md): ReFindNewlyMade / ReFindFromFailureQueue (run()'s lower-priority jobs).
+//   MapMaker::ReFindNewlyMade / ReFindFromFailureQueue / the idle jobs of run()   jni/MapMaker.cc:94-117, 1061-1100 (below)
 // Third-party arithmetic restated (parity unpinned): Eigen::JacobiSVD of the 4x4 triangulation matrix (two-sided Jacobi on A
 // itself, below; the sign of the vector cancels in the projective division).
 #include "ptam_system.hpp"

@@ -324,7 +324,7 @@ DEVFN double kfdist(const Pose& a, const Pose& b) {   // KeyFrameLinearDist :705
 // the keyframe joins the map (n_kf), which cameras are adjusted (:803-820), the countdown of the asynchronous map-maker --
 // and k_ba_assemble does the long part (point set, fixed set, measurement list), which with the asynchronous map-maker runs
 // on the map-maker's stream beside the following frames: nothing it reads changes while the stream's adjustment is pending.
-__global__ __launch_bounds__(64) void k_ba_select(MapDev m, TrackParams tp, BaPool pool, int mode) {
+__global__ __launch_bounds__(64) void k_ba_select(MapDev m, TrackParams tp, BaPool pool, int mode, int token) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= pool.N) return;
   TrackerState* st = &m.st[s];
@@ -381,16 +381,19 @@ __global__ __launch_bounds__(64) void k_ba_select(MapDev m, TrackParams tp, BaPo
     nadj_out = c; go = c > 0 && c <= 64;                            // the slot layout holds the adjustable cameras of a point in one 64-bit set
     if (c > 64) st->ba_accepted = -3;
   }
-  R->go = go; R->nadj = nadj_out;
+  // The pool record of a stream whose adjustment is pending belongs to that adjustment: its k_ba_assemble runs on a map-maker
+  // stream and may start after this launch (of a LATER frame).  `go` carries the token of the ba_run call that wants the problem,
+  // so an assemble launched for another call never picks it up.
+  if (!in_flight) { R->go = go ? token : 0; R->nadj = nadj_out; }
   if (go && mode == 0 && tp.ba_delay > 0) st->ba_countdown = tp.ba_delay;   // results are applied ba_delay frames from now
 }
 
-__global__ __launch_bounds__(BA_THREADS) void k_ba_assemble(MapDev m, TrackParams tp, BaPool pool, int mode, int slot /* work list to enter, or -1 */) {
+__global__ __launch_bounds__(BA_THREADS) void k_ba_assemble(MapDev m, TrackParams tp, BaPool pool, int mode, int slot /* work list to enter, or -1 */, int token) {
   const int s = blockIdx.x;
   TrackerState* st = &m.st[s];
   const BaView v = ba_view(pool, s);
   BaResult* R = v.res;
-  if (!R->go) return;
+  if (R->go != token) return;
   __shared__ int sh_nc, sh_nm;
   __shared__ int view_of_kf[BA_MAX_KF];      // kf index -> camera id or -1
   __shared__ int ired[BA_WAVES];
@@ -691,6 +694,7 @@ int ba_run(vslam_system* sys, int mode) {
   BaSystemWs* ws = (BaSystemWs*)sys->ba_ws;
   const BaConfig cfg = make_cfg(sys->tp);
   const bool async = mode == 0 && sys->tp.ba_delay > 0;
+  const int token = (int)(++sys->ba_token & 0x3fffffff) + 1;   // names this call's problems (k_ba_select -> k_ba_assemble)
   if (mode == 1 || mode == 2) { int r = ba_drain(sys); if (r) return r; }
   if (mode == 0) {
     KfCopyArgs a; fill_kfcopy(sys, a);
@@ -708,7 +712,7 @@ int ba_run(vslam_system* sys, int mode) {
     // A launch walks exactly its batch's list -- never a problem a later frame's k_ba_assemble is writing beside it.
     const int R = (int)sys->ev_ba.size(), slot = (int)(sys->ba_batch_id % R);
     hipStream_t bs = sys->ba_streams[(size_t)(sys->ba_batch_id % (long)sys->ba_streams.size())];
-    hipLaunchKernelGGL(k_ba_select, dim3((sys->S + 63) / 64), dim3(64), 0, sys->stream, sys->map, sys->tp, ws->pool, mode);
+    hipLaunchKernelGGL(k_ba_select, dim3((sys->S + 63) / 64), dim3(64), 0, sys->stream, sys->map, sys->tp, ws->pool, mode, token);
     // the long part of the assembly leaves the tracker's stream: behind this frame's keyframe copy / map growth, on the batch's
     // map-maker stream (every frame of a batch uses the same stream, so the batch's launch follows all its assemblies)
     const int FBn = (int)sys->frame_batch.size(), es = (int)(sys->frame_no % FBn);
@@ -717,7 +721,7 @@ int ba_run(vslam_system* sys, int mode) {
     if (sys->ba_batch_fill == 0)
       HIPCHK(hipMemsetAsync(ws->pool.work_n + slot, 0, sizeof(int), bs));   // the launch that read this slot R batches ago was waited for (ba_frame_start)
     if (sys->ba_batch_fill == 0) HIPCHK(hipMemsetAsync(ws->pool.work_n + ws->pool.work_slots + slot, 0, sizeof(int), bs));
-    hipLaunchKernelGGL(k_ba_assemble, dim3(sys->S), dim3(BA_THREADS), 0, bs, sys->map, sys->tp, ws->pool, mode, slot);
+    hipLaunchKernelGGL(k_ba_assemble, dim3(sys->S), dim3(BA_THREADS), 0, bs, sys->map, sys->tp, ws->pool, mode, slot, token);
     sys->frame_batch[(size_t)(sys->frame_no % (long)sys->frame_batch.size())] = sys->ba_batch_id;
     sys->ba_batch_fill++;
     if (sys->ba_batch_fill >= sys->tp.ba_batch) { int rl = ba_launch_batch(sys); if (rl) return rl; }
@@ -725,8 +729,8 @@ int ba_run(vslam_system* sys, int mode) {
     HIPCHK(hipGetLastError());
     return VSLAM_OK;
   }
-  hipLaunchKernelGGL(k_ba_select, dim3((sys->S + 63) / 64), dim3(64), 0, sys->stream, sys->map, sys->tp, ws->pool, mode);
-  hipLaunchKernelGGL(k_ba_assemble, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, base, -1);
+  hipLaunchKernelGGL(k_ba_select, dim3((sys->S + 63) / 64), dim3(64), 0, sys->stream, sys->map, sys->tp, ws->pool, mode, token);
+  hipLaunchKernelGGL(k_ba_assemble, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, base, -1, token);
   if (mode == 0) prof_mark(sys, 12);
   hipLaunchKernelGGL(k_ba_compute, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, ws->pool, cfg, -1);
   if (mode == 0) prof_mark(sys, 13);

@@ -20,7 +20,7 @@
 #include <math.h>
 #include "vslam_libm.h"
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define BM_FN __host__ __device__ inline
 #else
 #define BM_FN inline

@@ -816,6 +816,9 @@ int fe_make_keyframe_lite(vslam_system* sys, const uint8_t* gray, size_t row_str
   for (int l = 0; l < NLEV; l++) sys->d_lvl[l] = sys->d_lvl_buf[b][l];
   hipStream_t fs = sys->fe_stream;
   HIPCHK(hipStreamWaitEvent(fs, sys->ev_track_done[b], 0));
+  // map bootstrap: the trail tracker of the frame in flight (k_trail_advance, boot.hip) still reads THIS buffer as its previous
+  // frame (image, corners, row LUT) -- the buffer is free only when that frame has finished too
+  if (sys->p.bootstrap) HIPCHK(hipStreamWaitEvent(fs, sys->ev_track_done[b ^ 1], 0));
   FeArgs a;
   fill_fe_args(sys, a);
   if (on_device) {

@@ -340,12 +340,17 @@ extern "C" int vslam_eval_transcendental(int fn, int n, const double* x, double*
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { vslam_set_error("eval_transcendental: no HIP device visible"); return VSLAM_E_HIP; }
   if (n == 0) return VSLAM_OK;
   double *dx = nullptr, *dy = nullptr;
-  HIPCHK(hipMalloc((void**)&dx, sizeof(double) * n));
-  HIPCHK(hipMalloc((void**)&dy, sizeof(double) * n));
-  HIPCHK(hipMemcpy(dx, x, sizeof(double) * n, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_eval_transcendental, dim3((n + 255) / 256), dim3(256), 0, 0, fn, n, dx, dy);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpy(y, dy, sizeof(double) * n, hipMemcpyDeviceToHost));
-  (void)hipFree(dx); (void)hipFree(dy);
-  return VSLAM_OK;
+  auto run = [&]() -> int {
+    HIPCHK(hipMalloc((void**)&dx, sizeof(double) * n));
+    HIPCHK(hipMalloc((void**)&dy, sizeof(double) * n));
+    HIPCHK(hipMemcpy(dx, x, sizeof(double) * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_eval_transcendental, dim3((n + 255) / 256), dim3(256), 0, 0, fn, n, dx, dy);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(y, dy, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return VSLAM_OK;
+  };
+  const int rc = run();
+  if (dx) (void)hipFree(dx);
+  if (dy) (void)hipFree(dy);
+  return rc;
 }

@@ -186,6 +186,7 @@ struct vslam_system {
   int n_cu = 0;             // compute units of the device (asynchronous map-maker: size of the background BA grid)
   std::vector<hipEvent_t> ev_asm, ev_ba;   // rings of ba_delay + 2 events, indexed by batch number
   long frame_no = 0;
+  long ba_token = 0;           // ba_run calls so far: k_ba_select marks the problems it wants with the call's token, k_ba_assemble takes only those
   // batches of the asynchronous map-maker: the problems assembled in ba_batch consecutive frames share one work list and one launch
   long ba_batch_id = 0;        // the open batch
   int ba_batch_fill = 0;       // frames assembled into it so far

@@ -14,11 +14,11 @@
 //   notice is preserved.
 // Nothing here reads the bits of a double: the "clear the low word" steps of fdlibm are conversions through float.
 // Error about 1 ulp (tan about 2).  Domain of the trigonometric functions: |x| < 8e5 (beyond that the result is that of
-// a plain, inexact reduction); the angles of this path are rotations per frame and image-plane radii.
+// a plain, inexact reduction; NaN from 2^51 on and for infinities); the angles of this path are rotations per frame and image-plane radii.
 #pragma once
 #include <math.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define VLM_FN __host__ __device__ __forceinline__
 #else
 #define VLM_FN inline
@@ -27,6 +27,11 @@
 namespace vlm {
 
 VLM_FN double vabs(double x) { return x < 0.0 ? -x : x; }
+// The NaN of a domain error: a constant (0 / 0 evaluates to the negative default NaN on x86 and to the positive one on gfx950)
+VLM_FN double vnan() { return __builtin_nan(""); }
+// sin / cos / tan of a non-finite argument or of |x| >= 2^51 (where the integer conversions below would be undefined on the host
+// and saturating on the device) are domain errors here: the angles of this path are rotations per frame and image-plane radii
+VLM_FN bool vtrig_domain(double x) { return vabs(x) < 2251799813685248.0; }
 // floor for |x| < 2^51 through the integer conversion (truncation toward zero is exact on both sides)
 VLM_FN double vfloor(double x) { const double t = (double)(long long)x; return t > x ? t - 1.0 : t; }
 
@@ -74,6 +79,7 @@ VLM_FN int rem_pio2(double x, double& y0, double& y1) {
 
 VLM_FN double vsin(double x) {
   if (x != x) return x;
+  if (!vtrig_domain(x)) return vnan();
   if (vabs(x) < 0.78539816339744830962) {
     if (vabs(x) < 7.450580596923828125e-9) return x;             // 2^-27
     return ksin(x, 0.0);
@@ -89,6 +95,7 @@ VLM_FN double vsin(double x) {
 }
 VLM_FN double vcos(double x) {
   if (x != x) return x;
+  if (!vtrig_domain(x)) return vnan();
   if (vabs(x) < 0.78539816339744830962) {
     if (vabs(x) < 7.450580596923828125e-9) return 1.0;
     return kcos(x, 0.0);
@@ -104,6 +111,7 @@ VLM_FN double vcos(double x) {
 }
 VLM_FN double vtan(double x) {
   if (x != x) return x;
+  if (!vtrig_domain(x)) return vnan();
   if (vabs(x) < 7.450580596923828125e-9) return x;
   double y0 = x, y1 = 0.0;
   int n = 0;
@@ -159,7 +167,7 @@ VLM_FN double vasin(double x) {
   const double ax = vabs(x);
   if (ax >= 1.0) {
     if (ax == 1.0) return x * pio2_hi + x * pio2_lo;
-    return (x - x) / (x - x);                                   // NaN
+    return vnan();
   }
   if (ax < 0.5) {
     if (ax < 7.450580596923828125e-9) return x;
@@ -185,7 +193,7 @@ VLM_FN double vacos(double x) {
   if (ax >= 1.0) {
     if (x == 1.0) return 0.0;
     if (x == -1.0) return pi + 2.0 * pio2_lo;
-    return (x - x) / (x - x);
+    return vnan();
   }
   if (ax < 0.5) {
     if (ax <= 6.938893903907228e-18) return pio2_hi + pio2_lo;  // 2^-57
