@@ -91,14 +91,14 @@ def algorithmic_bytes(stage, S, W, H, P, per_stream):
     return S * table.get(stage, 0.0)
 
 
-def ba_bytes_per_trial(ps):
-    return ps["ba_meas"] * 176.0 + ps["ba_cams"] * 312.0 + ps["ba_pts"] * 168.0
-
-
-def ba_flops_per_trial(ps):
-    """F_ba = M*780 + sum_pts C(n_free,2)*216 + (6n)^3/3 per LM trial."""
-    n = ps["ba_free"]
-    return ps["ba_meas"] * 780.0 + ps["ba_pts"] * (n * (n - 1) / 2.0) * 216.0 + (6.0 * n) ** 3 / 3.0
+def ba_counted(st):
+    """SURVEY.md 8(d)'s byte and flop formulas (B_ba = M 176 + N_cam 312 + N_pt 168, F_ba = M 780 + sum_pts C(n_free, 2) 216 +
+    (6 n)^3 / 3 per LM trial) over what k_ba_compute launches actually ran: `st` = the counters the launches themselves accumulate
+    on the device (vslam_profile_ba_stats / vslam_get_mapmaker_timing: LM trials and their trial-weighted problem sizes).
+    -> (algorithmic bytes, flops) of all the launches counted."""
+    b = st["trials_x_meas"] * 176.0 + st["trials_x_cams"] * 312.0 + st["trials_x_points"] * 168.0
+    f = st["trials_x_meas"] * 780.0 + st["trials_x_points_x_pairs"] * 216.0 + st["trials_x_6n_cubed"] / 3.0
+    return b, f
 
 
 def baseline_metric():
@@ -349,6 +349,7 @@ def main():
     if world > 1:
         dist.barrier()
     stage_ms, stage_n, nprof = {}, {}, 0
+    ba_st = {}                                  # what the window's k_ba_compute launches ran, counted by the launches themselves
     if not args.no_events:
         for sy in systems:                      # per-launch durations: summed over systems, averaged below over launches
             ms, n = sy.profile_end()
@@ -357,6 +358,8 @@ def main():
             for k_, v_ in ms.items():
                 stage_ms[k_] = stage_ms.get(k_, 0.0) + v_
                 stage_n[k_] = stage_n.get(k_, 0) + cnt[k_]
+            for k_, v_ in sy.profile_ba_stats().items():
+                ba_st[k_] = ba_st.get(k_, 0) + v_
     st1 = [state(s) for s in range(S)]
 
     # ---- per-stream workload statistics (for the algorithmic-byte formulas) ---------------------------------------------
@@ -373,29 +376,52 @@ def main():
                   "ba_meas": float(np.mean([b["meas"] for b in bss])), "ba_cams": float(np.mean([b["cams"] for b in bss])),
                   "ba_free": float(np.mean([b["free_cams"] for b in bss])), "ba_pts": float(np.mean([b["points"] for b in bss])),
                   "ba_trials_per_problem": float(np.mean([b["trials"] for b in bss]))}
-    ba_launches = max(1, stage_n.get("ba_compute", 0))
-    # LM trials summed over the problems of this GPU that were applied in the window, per k_ba_compute launch of the window
-    trials_per_launch = ba_trials * S / ba_launches
+    # the k_ba_compute launches of the window: LM trials, algorithmic bytes and flops of exactly those launches (device counters),
+    # so that they and the launches' HIP-event time describe the same work (round 2 divided the trials APPLIED in the window --
+    # adjustments launched ba_delay frames earlier -- by the launches IN the window)
+    ba_launches = max(1, ba_st.get("launches", 0))
+    trials_per_launch = ba_st.get("trials", 0) / ba_launches
+    ba_bytes_launch, ba_flops_launch = (x / ba_launches for x in ba_counted(ba_st)) if ba_st else (0.0, 0.0)
 
     # ---- a flat-out round of the bundle adjustment: every stream's BundleAdjustRecent in ONE launch, nothing beside it ------
     flat = None
     note("timed region done")
     if not args.no_flat_out and args.diag_kf_dist_mult is None:
+        # Every stream makes its current frame a keyframe NOW (vslam_add_keyframe: MapMaker::AddKeyFrame + BundleAdjustRecent, the
+        # same problems as the timed region's, all 2048 in one synchronous launch after the adjustments in flight were collected),
+        # timed with HIP events on the system's stream around select + assemble / k_ba_compute / write-back
+        # (vslam_get_mapmaker_timing).  Twice: the second round adds the frame once more (a camera more per problem).  Bytes and
+        # flops are those the launch counted on the device.  (Round 2 of the review: this used to be a BundleAdjustRecent of maps
+        # adjusted a moment ago -- one LM trial per problem -- timed by the host's clock together with the drain of the pending
+        # asynchronous adjustments, whose LM trials it also counted: 11-25 ms and "14,094 trials" depending on what was in flight.)
         try:
-            sync_all()
-            tr0 = [state(s).n_ba_trials for s in range(S)]
-            t_f = time.perf_counter()
-            for sy in systems:
-                sy.lib.vslam_bundle_adjust_recent(sy.h)
-            sync_all()
-            flat_s = time.perf_counter() - t_f
-            tr1 = [state(s).n_ba_trials for s in range(S)]
-            flat_trials = float(sum(b - a for a, b in zip(tr0, tr1)))
-            fb = flat_trials * ba_bytes_per_trial(per_stream)
-            flat = {"problems": S, "lm_trials": flat_trials, "ms": round(1e3 * flat_s, 3), "algorithmic_bytes": round(fb),
-                    "achieved_GBps": round(fb / flat_s / 1e9, 2), "frac": round(fb / flat_s / 1e9 / HBM_PEAK_GBS, 5),
-                    "fp64_TFLOPs": round(flat_trials * ba_flops_per_trial(per_stream) / flat_s / 1e12, 3),
-                    "timing": "host wall clock around vslam_bundle_adjust_recent + synchronize (assemble + compute + write-back of every stream, one launch each)"}
+            rounds = []
+            for _round in range(2):
+                sync_all()
+                t_f = time.perf_counter()
+                for sy in systems:
+                    capi._check(sy.lib.vslam_add_keyframe(sy.h, -1))
+                sync_all()
+                wall_s = time.perf_counter() - t_f
+                ms3 = {"assemble": 0.0, "compute": 0.0, "writeback": 0.0}
+                cst = {}
+                for sy in systems:
+                    m3, c8 = sy.mapmaker_timing()
+                    for k_ in ms3:
+                        ms3[k_] = max(ms3[k_], m3[k_])
+                    for k_, v_ in c8.items():
+                        cst[k_] = cst.get(k_, 0) + v_
+                fb, ff = ba_counted(cst)
+                cs = max(1e-9, ms3["compute"] * 1e-3)
+                rounds.append({"problems": cst["problems"], "lm_trials": cst["trials"], "ms_assemble": round(ms3["assemble"], 3),
+                               "ms_compute": round(ms3["compute"], 3), "ms_writeback": round(ms3["writeback"], 3), "ms_host_wall": round(1e3 * wall_s, 3),
+                               "algorithmic_bytes": round(fb), "achieved_GBps": round(fb / cs / 1e9, 2), "frac": round(fb / cs / 1e9 / HBM_PEAK_GBS, 5),
+                               "fp64_TFLOPs": round(ff / cs / 1e12, 3)})
+            flat = dict(rounds[0])
+            flat["round2"] = rounds[1]
+            flat["timing"] = ("HIP events on the system's stream around k_ba_compute alone (ms_compute; achieved / frac use it), select + assemble and "
+                              "write-back beside it; ms_host_wall = the host's clock around the call + synchronize; every stream's AddKeyFrame + "
+                              "BundleAdjustRecent in ONE synchronous launch, nothing beside it")
         except Exception as e:                 # noqa: BLE001 - extra information only
             flat = {"error": str(e)}
 
@@ -415,7 +441,7 @@ def main():
 
             def stage_bytes(name):
                 if name == "ba_compute":
-                    return trials_per_launch * ba_bytes_per_trial(per_stream)
+                    return ba_bytes_launch
                 return algorithmic_bytes(name, Sk, W, H, args.patch, per_stream)
 
             for name, ms in stage_ms.items():
@@ -432,9 +458,11 @@ def main():
                       "frac": round(ach_ / HBM_PEAK_GBS, 6), "traffic": None, "ms_per_launch": round(ms_, 5),
                       "launches": stage_n.get(name, nprof), "algorithmic_bytes": round(ab_)}
                 if name == "ba_compute":        # supplementary: the same launch against the fp64 vector/matrix peak (78.6 TFLOP/s)
-                    tf = trials_per_launch * ba_flops_per_trial(per_stream) / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0
+                    tf = ba_flops_launch / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0
                     r_["fp64"] = {"achieved": round(tf, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP64_PEAK_TFLOPS, 5)}
                     r_["lm_trials_per_launch"] = round(trials_per_launch, 1)
+                    r_["problems_per_launch"] = round(ba_st.get("problems", 0) / ba_launches, 1)
+                    r_["counted"] = "LM trials, bytes and flops of exactly these launches, accumulated on the device by k_ba_compute (vslam_profile_ba_stats)"
                     r_["flat_out_round"] = flat
                 tr = pmc_traffic({"ba_compute": "k_ba_compute", "front_end": "k_front_end"}.get(name, name))
                 if tr:                          # counters per unit of work (profiles/), scaled to this run's launch mix

@@ -299,6 +299,15 @@ int vslam_profile_end(vslam_system* sys, double* stage_ms, int* n_frames);
 /* launches[VSLAM_N_STAGES] = how many launches of each stage the last vslam_profile_begin/end pair recorded (every frame for all stages
  * but ba_compute with the asynchronous map-maker, which is launched once per batch of frames) */
 int vslam_profile_launches(vslam_system* sys, int* launches);
+/* What the Bundle::Compute launches (k_ba_compute) of the last vslam_profile_begin/end window actually ran, counted on the device by
+ * the launches themselves: stats[0] problems, [1] LM trials (Do_LM_Step's inner trials, jni/Bundle.cc:327-501), and the
+ * trial-weighted sums SURVEY.md 8(d)'s formulas need -- [2] trials x measurements, [3] trials x cameras, [4] trials x points,
+ * [5] trials x points x C(adjustable cameras, 2), [6] trials x (6 x adjustable cameras)^3 -- [7] launches.  After vslam_profile_end. */
+int vslam_profile_ba_stats(vslam_system* sys, unsigned long long stats[8]);
+/* HIP-event time of the last host-driven vslam_bundle_adjust_recent / vslam_bundle_adjust_all on the system's stream:
+ * ms[0] selection + assembly (k_ba_select, k_ba_assemble), ms[1] Bundle::Compute (k_ba_compute, one workgroup per stream's
+ * problem), ms[2] write-back + HandleBadPoints; stats (may be NULL): the launch's counters as vslam_profile_ba_stats. Synchronises. */
+int vslam_get_mapmaker_timing(vslam_system* sys, double ms[3], unsigned long long stats[8]);
 
 /* ---- mapping ------------------------------------------------------------------------------- */
 /* MapMaker::BundleAdjustRecent / BundleAdjustAll (jni/MapMaker.cc:801-851, 776-798) on every stream, followed by
@@ -307,7 +316,9 @@ int vslam_bundle_adjust_recent(vslam_system* sys);
 int vslam_bundle_adjust_all(vslam_system* sys);
 /* MapMaker::AddKeyFrame (jni/MapMaker.cc:470-478) called from the host: the current frame of `stream` (all streams
  * if stream < 0) becomes a keyframe now, followed by the same BundleAdjustRecent + HandleBadPoints as the
- * tracker-driven path.  Needs a tracked current frame. */
+ * tracker-driven path -- on the system's own stream, finished before the next frame, also with the asynchronous map-maker
+ * (whose adjustments in flight are collected first).  Timed like vslam_bundle_adjust_recent (vslam_get_mapmaker_timing).
+ * Needs a tracked current frame. */
 int vslam_add_keyframe(vslam_system* sys, int stream);
 
 /* ---- stand-alone Bundle (jni/Bundle.h:111-121), batched: n_problems independent problems ---- */

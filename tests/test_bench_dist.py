@@ -47,8 +47,11 @@ def test_aggregate_single_process():
     ps = {"corners": 1000, "patches": 1000, "zmssd": 8000, "found": 500, "ba_meas": 1500, "ba_cams": 5, "ba_free": 4, "ba_pts": 300}
     assert bench.algorithmic_bytes("front_end", 2, 640, 480, 8, ps) == 2 * 415600     # 408,000 + 4,000 + 3,600 per frame
     assert bench.algorithmic_bytes("search_fine", 1, 640, 480, 8, ps) == 624000      # 8(d) example: P = 8, N_p = 1000, K = 8 per patch
-    assert bench.ba_bytes_per_trial(ps) == 315960                                     # 8(d) config 3: 1500 * 176 + 5 * 312 + 300 * 168 (quoted there as 316,000)
-    assert abs(bench.ba_flops_per_trial(ps) - 1.56e6) < 0.01e6                        # ~1.56 MFLOP per trial
+    # 8(d) config 3 through the device counters' form: one problem, one LM trial, 1500 measurements, 5 cameras (4 adjustable), 300 points
+    st = {"trials": 1, "trials_x_meas": 1500, "trials_x_cams": 5, "trials_x_points": 300, "trials_x_points_x_pairs": 300 * 6, "trials_x_6n_cubed": 24 ** 3}
+    b, f = bench.ba_counted(st)
+    assert b == 315960                                                                # 1500 * 176 + 5 * 312 + 300 * 168 (quoted there as 316,000)
+    assert abs(f - 1.56e6) < 0.01e6                                                   # ~1.56 MFLOP per trial
 
 
 def _run_bench(args, env_extra):

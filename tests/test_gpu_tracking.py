@@ -231,6 +231,71 @@ def test_asynchronous_mapmaker_streams_keyframing_on_different_frames():
     g.close()
 
 
+def test_asynchronous_mapmaker_without_host_synchronisation():
+    """with the asynchronous map-maker nothing but HIP events orders a frame's k_ba_select (tracker's stream) against
+    an earlier frame's k_ba_assemble (map-maker's stream).  192 streams with staggered keyframe phases, ba_delay_frames = 16,
+    batches of 4 frames, the frames enqueued back to back from device memory WITHOUT any host synchronisation (the bench's
+    pattern; the other tests read the state after every frame, which hides such races) against the same run synchronised after
+    every frame: keyframe counts, LM trial counts, keyframe poses and final poses must be identical bits -- the schedule may
+    not change a result, and no keyframe's adjustment may be dropped."""
+    import torch
+    w, h, S, n, D = 320, 240, 192, 45, 16
+    base = [scene(w, h, 700 + k, n, per_level=(120, 50, 20, 8)) for k in range(3)]
+    frames = torch.empty((n, S, h, w), dtype=torch.uint8, device="cuda")
+    for s in range(S):
+        frames[:, s].copy_(torch.from_numpy(base[s % 3][2]))
+    torch.cuda.synchronize()
+
+    def run(sync_every_frame):
+        g = capi.System(capi.default_params(w, h, S, ba_delay_frames=D, ba_batch_frames=4))
+        for s in range(S):
+            f, m, _fr = base[s % 3]
+            g.load_map(s, m); g.set_pose(s, f.pose(-1))
+            g.set_last_keyframe_dropped(s, -20 + (s * 21) // S)
+        for t in range(n):
+            g.track_frame_device(frames[t].data_ptr(), w, h * w)
+            if sync_every_frame:
+                g.synchronize()
+        g.synchronize()
+        g.bundle_adjust_recent()                         # collects whatever is still in flight (ba_drain), then one more adjustment
+        out = []
+        for s in range(0, S, 5):
+            st = g.state(s)
+            out.append((st.n_keyframes, st.n_ba_trials, st.ba_accepted, tuple(st.pose[:]), tuple(tuple(g.keyframe_pose(s, k)) for k in range(st.n_keyframes))))
+        g.close()
+        return out
+
+    a, b = run(False), run(True)
+    assert all(x[0] >= len(base[0][1]["keyframes"]) + 2 and x[1] > 0 for x in a)      # two keyframes and their adjustments per stream
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert x[:3] == y[:3], (i, x[:3], y[:3])
+        assert x[3] == y[3] and x[4] == y[4], i
+
+
+def test_bundle_launch_counters_and_mapmaker_timing():
+    """vslam_profile_ba_stats / vslam_get_mapmaker_timing (the bench's roofline inputs): what k_ba_compute counts on the device for
+    the launches of a profile window equals what the streams' own counters say those launches ran."""
+    w, h, S, n = 320, 240, 2, 4
+    sc = [scene(w, h, 500 + s, n, per_level=(120, 50, 20, 8)) for s in range(S)]
+    g = capi.System(capi.default_params(w, h, S))
+    for s, (f, m, _fr) in enumerate(sc):
+        g.load_map(s, m); g.set_pose(s, f.pose(-1))
+    g.profile_begin(n)
+    for t in range(n):
+        g.track_frame(np.stack([x[2][t] for x in sc]))
+    g.profile_end()
+    st = g.profile_ba_stats()
+    trials = sum(g.state(s).n_ba_trials for s in range(S))
+    assert st["launches"] == n and st["problems"] == S and st["trials"] == trials > 0, (st, trials)    # frame 0 is a keyframe frame for both streams
+    bs = [g.bundle_stats(s) for s in range(S)]
+    assert st["trials_x_meas"] == sum(b["trials"] * b["meas"] for b in bs) and st["trials_x_points"] == sum(b["trials"] * b["points"] for b in bs), (st, bs)
+    g.bundle_adjust_recent()
+    ms, c = g.mapmaker_timing()
+    assert c["problems"] == S and c["trials"] == sum(g.state(s).n_ba_trials for s in range(S)) - trials > 0
+    assert all(v > 0 for v in ms.values()), ms
+    g.close()
+
+
 def test_independent_streams_in_one_batch():
     w, h, S, n = 320, 240, 3, 5
     scenes = [scene(w, h, 500 + s, n, per_level=(120, 50, 20, 8)) for s in range(S)]

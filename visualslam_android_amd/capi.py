@@ -114,6 +114,8 @@ SYMBOLS = {
     "vslam_profile_begin": (_i, [_sys, _i]),
     "vslam_profile_end": (_i, [_sys, _vp, _ip]),
     "vslam_profile_launches": (_i, [_sys, _vp]),
+    "vslam_profile_ba_stats": (_i, [_sys, _vp]),
+    "vslam_get_mapmaker_timing": (_i, [_sys, _vp, _vp]),
     "vslam_bundle_adjust_recent": (_i, [_sys]),
     "vslam_bundle_adjust_all": (_i, [_sys]),
     "vslam_bundle_create": (_i, [C.POINTER(Params), _i, _i, _i, _i, C.POINTER(_vp)]),
@@ -514,6 +516,21 @@ class System:
         c = np.zeros(N_STAGES, np.int32)
         _check(self.lib.vslam_profile_launches(self.h, c.ctypes.data))
         return {self.lib.vslam_stage_name(k).decode(): int(c[k]) for k in range(N_STAGES)}
+
+    BA_STAT_KEYS = ("problems", "trials", "trials_x_meas", "trials_x_cams", "trials_x_points", "trials_x_points_x_pairs", "trials_x_6n_cubed", "launches")
+
+    def profile_ba_stats(self):
+        """-> what the k_ba_compute launches of the last profile window ran, counted on the device (vslam_profile_ba_stats)"""
+        st = np.zeros(8, np.uint64)
+        _check(self.lib.vslam_profile_ba_stats(self.h, st.ctypes.data))
+        return {k: int(v) for k, v in zip(self.BA_STAT_KEYS, st)}
+
+    def mapmaker_timing(self):
+        """-> ({"assemble": ms, "compute": ms, "writeback": ms}, counters) of the last bundle_adjust_recent / bundle_adjust_all (HIP events)"""
+        ms = np.zeros(3)
+        st = np.zeros(8, np.uint64)
+        _check(self.lib.vslam_get_mapmaker_timing(self.h, ms.ctypes.data, st.ctypes.data))
+        return {"assemble": float(ms[0]), "compute": float(ms[1]), "writeback": float(ms[2])}, {k: int(v) for k, v in zip(self.BA_STAT_KEYS, st)}
 
     def bundle_adjust_recent(self):
         _check(self.lib.vslam_bundle_adjust_recent(self.h))

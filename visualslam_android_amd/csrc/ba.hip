@@ -27,7 +27,13 @@ struct BaPool {            // device arrays for N problems
   // main stream) is still writing.
   int* work; int* work_n; int work_slots;
   int* view_of_kf;               // [N][BA_MAX_KF] keyframe index -> camera id of the problem being assembled, or -1 (k_ba_select -> k_ba_assemble)
+  // measurement: what every k_ba_compute launch of a system actually ran, one record of BA_LSTAT_N counters per launch in a ring
+  // (problems, LM trials, and the trial-weighted sums of measurements, cameras, points, points x pairs of adjustable cameras,
+  // (6 n_free)^3 that SURVEY.md 8(d)'s byte and flop formulas need); null for the stand-alone Bundle
+  unsigned long long* lstat;
 };
+#define BA_LSTAT_N 8
+#define BA_LSTAT_RING 1024
 
 __host__ __device__ inline BaView ba_view(const BaPool& b, int n) {
   BaView v;
@@ -52,7 +58,7 @@ __host__ __device__ inline BaView ba_view(const BaPool& b, int n) {
 #ifndef VSLAM_BA_WPE
 #define VSLAM_BA_WPE 2
 #endif
-__global__ __launch_bounds__(BA_THREADS) __attribute__((amdgpu_waves_per_eu(VSLAM_BA_WPE, VSLAM_BA_WPE))) void k_ba_compute(BaPool pool, BaConfig cfg, int slot) {
+__global__ __launch_bounds__(BA_THREADS) __attribute__((amdgpu_waves_per_eu(VSLAM_BA_WPE, VSLAM_BA_WPE))) void k_ba_compute(BaPool pool, BaConfig cfg, int slot, int lrec /* record of the launch in pool.lstat, or -1 */) {
   // slot < 0: one workgroup per problem of the pool (synchronous map-maker, stand-alone Bundle); slot >= 0: the grid walks the
   // work list of one frame (asynchronous map-maker)
   // (the persistent workgroups of an asynchronous launch draw their next list entry from a counter: the long and the short
@@ -65,7 +71,16 @@ __global__ __launch_bounds__(BA_THREADS) __attribute__((amdgpu_waves_per_eu(VSLA
     const BaView v = ba_view(pool, n);
     if (v.res->active && !v.res->computed) {
       ba_compute(v, cfg);
-      if (threadIdx.x == 0) v.res->computed = 1;
+      if (threadIdx.x == 0) {
+        v.res->computed = 1;
+        if (lrec >= 0 && pool.lstat) {                                // the work this launch did, for the roofline of THIS launch
+          unsigned long long* L = pool.lstat + (size_t)lrec * BA_LSTAT_N;
+          const unsigned long long t = (unsigned long long)v.res->trials, nf = (unsigned long long)v.res->n_free;
+          atomicAdd(&L[0], 1ull); atomicAdd(&L[1], t);
+          atomicAdd(&L[2], t * (unsigned long long)v.res->n_meas); atomicAdd(&L[3], t * (unsigned long long)v.res->n_cams); atomicAdd(&L[4], t * (unsigned long long)v.res->n_pts);
+          atomicAdd(&L[5], t * (unsigned long long)v.res->n_pts * (nf * (nf > 0 ? nf - 1 : 0) / 2)); atomicAdd(&L[6], t * (6 * nf) * (6 * nf) * (6 * nf));
+        }
+      }
     }
     if (slot < 0) break;                                            // one workgroup per problem
     __syncthreads();
@@ -102,6 +117,7 @@ static int pool_create(BaPool& b, std::vector<void*>& allocs, hipStream_t st, in
   PALLOC(scratch, n * M); PALLOC(outl, n * M * 2); PALLOC(free_cams, n * C); PALLOC(id_view, n * C); PALLOC(id_point, n * P);
   b.work_slots = work_slots > 0 ? work_slots : 1;
   PALLOC(work, n * b.work_slots); PALLOC(work_n, (size_t)2 * b.work_slots);   /* work_n[work_slots + slot]: the launch's draw counter */ PALLOC(view_of_kf, n * BA_MAX_KF);
+  b.lstat = nullptr;
   return VSLAM_OK;
 }
 
@@ -213,7 +229,7 @@ extern "C" int vslam_bundle_compute(vslam_bundle* b) {
     HIPCHK(hipStreamSynchronize(b->stream));   // host vectors go out of scope
   }
   b->uploaded = true;
-  hipLaunchKernelGGL(k_ba_compute, dim3(P.N), dim3(BA_THREADS), 0, b->stream, b->pool, b->cfg, -1);
+  hipLaunchKernelGGL(k_ba_compute, dim3(P.N), dim3(BA_THREADS), 0, b->stream, b->pool, b->cfg, -1, -1);
   HIPCHK(hipGetLastError());
   return VSLAM_OK;
 }
@@ -616,7 +632,25 @@ int ba_alloc(vslam_system* sys) {
   // worst case of BundleAdjust: every keyframe a camera, every point, every (kf, point) slot a measurement
   size_t M = (size_t)K * P;
   if (M > 65536) M = 65536;
-  return pool_create(ws->pool, sys->allocs, sys->stream, sys->S, K, P, (int)M, sys->p.ba_delay_frames > 0 ? sys->p.ba_delay_frames + 2 : 1);
+  int r = pool_create(ws->pool, sys->allocs, sys->stream, sys->S, K, P, (int)M, sys->p.ba_delay_frames > 0 ? sys->p.ba_delay_frames + 2 : 1);
+  if (r) return r;
+  r = pool_alloc(sys->allocs, sys->stream, &ws->pool.lstat, (size_t)BA_LSTAT_RING * BA_LSTAT_N);
+  if (r) return r;
+  // One launch of the full synchronous grid over the still empty pool (every problem inactive: the workgroups return at once).
+  // k_ba_compute needs scratch memory, and the runtime sizes that lazily, at the first launch of a grid this large: paid here,
+  // at creation, not by the first BundleAdjustRecent / BundleAdjustAll a caller times.
+  hipLaunchKernelGGL(k_ba_compute, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, ws->pool, make_cfg(sys->tp), -1, -1);
+  HIPCHK(hipGetLastError());
+  return VSLAM_OK;
+}
+
+// the next record of the ring, zeroed on the stream that launches k_ba_compute
+static int ba_next_launch_record(vslam_system* sys, hipStream_t st, int* rec, int* ordinal) {
+  BaSystemWs* ws = (BaSystemWs*)sys->ba_ws;
+  *ordinal = (int)(sys->ba_launch_no & 0x3fffffff);
+  *rec = (int)(sys->ba_launch_no++ % BA_LSTAT_RING);
+  HIPCHK(hipMemsetAsync(ws->pool.lstat + (size_t)*rec * BA_LSTAT_N, 0, sizeof(unsigned long long) * BA_LSTAT_N, st));
+  return VSLAM_OK;
 }
 
 static void fill_kfcopy(vslam_system* sys, KfCopyArgs& a) {
@@ -635,14 +669,16 @@ static int ba_launch_batch(vslam_system* sys) {
   const BaConfig cfg = make_cfg(sys->tp);
   const int R = (int)sys->ev_ba.size(), slot = (int)(sys->ba_batch_id % R);
   sys->ba_stream = sys->ba_streams[(size_t)(sys->ba_batch_id % (long)sys->ba_streams.size())];
+  int lrec = -1, lord = 0;
+  { int rr = ba_next_launch_record(sys, sys->ba_stream, &lrec, &lord); if (rr) return rr; }
   prof_mark(sys, 12);                                  // the batch's assemblies precede on this very stream
   // one workgroup per problem up to two per compute unit; the grid walks the batch's work list
   static const int per_cu_x2 = getenv("VSLAM_BA_WG_PER_CU_X2") ? atoi(getenv("VSLAM_BA_WG_PER_CU_X2")) : 4;   // diagnostic: background workgroups per CU, in halves
   const int cap = per_cu_x2 * (sys->n_cu > 0 ? sys->n_cu : 256) / 2;
   const int ba_grid = sys->S < cap ? sys->S : cap;
-  hipLaunchKernelGGL(k_ba_compute, dim3(ba_grid), dim3(BA_THREADS), 0, sys->ba_stream, ws->pool, cfg, slot);
+  hipLaunchKernelGGL(k_ba_compute, dim3(ba_grid), dim3(BA_THREADS), 0, sys->ba_stream, ws->pool, cfg, slot, lrec);
   prof_mark(sys, PROF_BA_END);
-  if (sys->prof_on && sys->prof_frame < sys->prof_cap && sys->prof_frame < (int)sys->prof_ba_launched.size()) sys->prof_ba_launched[sys->prof_frame] = 1;
+  if (sys->prof_on && sys->prof_frame < sys->prof_cap && sys->prof_frame < (int)sys->prof_ba_launched.size()) sys->prof_ba_launched[sys->prof_frame] = lord + 1;
   HIPCHK(hipEventRecord(sys->ev_ba[slot], sys->ba_stream));
   HIPCHK(hipGetLastError());
   sys->ba_batch_id++;
@@ -688,12 +724,12 @@ static int ba_drain(vslam_system* sys) {
 
 // mode 0: tracker-driven AddKeyFrame + BundleAdjustRecent; 1: BundleAdjustRecent; 2: BundleAdjustAll; 3 / 4: the same two as idle jobs of
 // MapMaker::run, for the streams whose adjustment has not converged (gated on device)
-int ba_run(vslam_system* sys, int mode) {
+int ba_run(vslam_system* sys, int mode, bool host_driven_keyframe) {
   const int base = mode == 3 ? 1 : (mode == 4 || mode >= 5 ? 2 : mode);   // what the assembly does; 5 / 6: InitFromStereo's BundleAdjustAll (boot.hip)
   const int wb = mode >= 5 ? 5 : base;                                    // ... and the write-back
   BaSystemWs* ws = (BaSystemWs*)sys->ba_ws;
   const BaConfig cfg = make_cfg(sys->tp);
-  const bool async = mode == 0 && sys->tp.ba_delay > 0;
+  const bool async = mode == 0 && sys->tp.ba_delay > 0 && !host_driven_keyframe;
   const int token = (int)(++sys->ba_token & 0x3fffffff) + 1;   // names this call's problems (k_ba_select -> k_ba_assemble)
   if (mode == 1 || mode == 2) { int r = ba_drain(sys); if (r) return r; }
   if (mode == 0) {
@@ -729,12 +765,25 @@ int ba_run(vslam_system* sys, int mode) {
     HIPCHK(hipGetLastError());
     return VSLAM_OK;
   }
-  hipLaunchKernelGGL(k_ba_select, dim3((sys->S + 63) / 64), dim3(64), 0, sys->stream, sys->map, sys->tp, ws->pool, mode, token);
-  hipLaunchKernelGGL(k_ba_assemble, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, base, -1, token);
+  // host-driven calls (BundleAdjustRecent / BundleAdjustAll / AddKeyFrame on request): HIP events around the three parts, read by
+  // vslam_get_mapmaker_timing.  A host-driven AddKeyFrame is adjusted here and now even when the tracker-driven ones run on the
+  // map-maker streams (the pending ones were collected by the caller): the kernels see ba_delay = 0.
+  const bool timed = (mode == 1 || mode == 2 || host_driven_keyframe) && sys->ev_mm[0];
+  TrackParams tps = sys->tp;
+  if (host_driven_keyframe) tps.ba_delay = 0;
+  int lrec = -1, lord = 0;
+  { int rr = ba_next_launch_record(sys, sys->stream, &lrec, &lord); if (rr) return rr; }
+  if (timed) HIPCHK(hipEventRecord(sys->ev_mm[0], sys->stream));
+  hipLaunchKernelGGL(k_ba_select, dim3((sys->S + 63) / 64), dim3(64), 0, sys->stream, sys->map, tps, ws->pool, mode, token);
+  hipLaunchKernelGGL(k_ba_assemble, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, tps, ws->pool, base, -1, token);
   if (mode == 0) prof_mark(sys, 12);
-  hipLaunchKernelGGL(k_ba_compute, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, ws->pool, cfg, -1);
+  if (timed) HIPCHK(hipEventRecord(sys->ev_mm[1], sys->stream));
+  hipLaunchKernelGGL(k_ba_compute, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, ws->pool, cfg, -1, lrec);
   if (mode == 0) prof_mark(sys, 13);
-  hipLaunchKernelGGL(k_ba_writeback, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp, ws->pool, wb);
+  if (timed) HIPCHK(hipEventRecord(sys->ev_mm[2], sys->stream));
+  hipLaunchKernelGGL(k_ba_writeback, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, tps, ws->pool, wb);
+  if (timed) { HIPCHK(hipEventRecord(sys->ev_mm[3], sys->stream)); sys->mm_lrec = lrec; }
+  if (mode == 0 && sys->prof_on && sys->prof_frame < sys->prof_cap && sys->prof_frame < (int)sys->prof_ba_launched.size()) sys->prof_ba_launched[sys->prof_frame] = lord + 1;
   HIPCHK(hipGetLastError());
   return VSLAM_OK;
 }
@@ -746,15 +795,15 @@ int ba_launch_add_keyframe(vslam_system* sys) {
   return VSLAM_OK;
 }
 
-int ba_add_keyframe_and_adjust(vslam_system* sys) { return ba_run(sys, 0); }
+int ba_add_keyframe_and_adjust(vslam_system* sys) { return ba_run(sys, 0, false); }
 
 // vslam_params.idle_iterations passes through the idle jobs of MapMaker::run (jni/MapMaker.cc:94-117), every stream deciding on
 // device which of them it runs: BundleAdjustRecent until converged, ReFindNewlyMade, BundleAdjustAll until converged, every 20th
 // time ReFindFromFailureQueue, HandleBadPoints (the tail of the write-back kernels).  Synchronous map-maker only.
 int mm_idle_job(vslam_system* sys, int job) {
   if (job < 0 || job > 3) { vslam_set_error("mapmaker_idle_job: job must be 0..3"); return VSLAM_E_INVALID; }
-  if (job == 0) return ba_run(sys, 3);                 // the write-back ends with HandleBadPoints
-  if (job == 2) return ba_run(sys, 4);
+  if (job == 0) return ba_run(sys, 3, false);                 // the write-back ends with HandleBadPoints
+  if (job == 2) return ba_run(sys, 4, false);
   const int r = grow_idle_refind(sys, job == 1 ? 0 : 1);
   if (r) return r;
   hipLaunchKernelGGL(k_handle_bad_points, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, sys->tp);   // :117
@@ -775,6 +824,40 @@ extern "C" int vslam_get_bundle_stats(vslam_system* sys, int s, int out[6]) {
   BaResult r;
   HIPCHK(hipMemcpy(&r, ws->pool.res + s, sizeof(r), hipMemcpyDeviceToHost));
   out[0] = r.n_cams; out[1] = r.n_free; out[2] = r.n_pts; out[3] = r.n_meas; out[4] = r.counter; out[5] = r.accepted;
+  return VSLAM_OK;
+}
+
+// ---- measurement ----------------------------------------------------------------------------------------------------
+static int ba_read_launch_record(vslam_system* sys, int rec, unsigned long long out[BA_LSTAT_N]) {
+  BaSystemWs* ws = (BaSystemWs*)sys->ba_ws;
+  HIPCHK(hipMemcpy(out, ws->pool.lstat + (size_t)rec * BA_LSTAT_N, sizeof(unsigned long long) * BA_LSTAT_N, hipMemcpyDeviceToHost));
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_profile_ba_stats(vslam_system* sys, unsigned long long stats[8]) {
+  if (!sys || !stats || !sys->ba_ws) { vslam_set_error("profile_ba_stats: bad argument"); return VSLAM_E_INVALID; }
+  if (sys->prof_on) { vslam_set_error("profile_ba_stats: call vslam_profile_end first"); return VSLAM_E_STATE; }
+  for (int k = 0; k < BA_LSTAT_N; k++) stats[k] = 0;
+  int launches = 0;
+  for (int f = 0; f < sys->prof_frame && f < (int)sys->prof_ba_launched.size(); f++) {
+    if (!sys->prof_ba_launched[f]) continue;
+    const long ord = sys->prof_ba_launched[f] - 1;
+    if ((sys->ba_launch_no & 0x3fffffff) - ord > BA_LSTAT_RING) { vslam_set_error("profile_ba_stats: the window's launch records have been overwritten (more than %d launches since)", BA_LSTAT_RING); return VSLAM_E_CAPACITY; }
+    unsigned long long r[BA_LSTAT_N];
+    int rc = ba_read_launch_record(sys, (int)(ord % BA_LSTAT_RING), r); if (rc) return rc;
+    for (int k = 0; k < BA_LSTAT_N; k++) stats[k] += r[k];
+    launches++;
+  }
+  stats[7] = (unsigned long long)launches;
+  return VSLAM_OK;
+}
+
+extern "C" int vslam_get_mapmaker_timing(vslam_system* sys, double ms[3], unsigned long long stats[8]) {
+  if (!sys || !ms || !sys->ba_ws) { vslam_set_error("get_mapmaker_timing: bad argument"); return VSLAM_E_INVALID; }
+  if (sys->mm_lrec < 0 || !sys->ev_mm[0]) { vslam_set_error("get_mapmaker_timing: no vslam_bundle_adjust_recent / _all call yet"); return VSLAM_E_STATE; }
+  HIPCHK(hipStreamSynchronize(sys->stream));
+  for (int k = 0; k < 3; k++) { float t = 0.f; HIPCHK(hipEventElapsedTime(&t, sys->ev_mm[k], sys->ev_mm[k + 1])); ms[k] = t; }
+  if (stats) { int rc = ba_read_launch_record(sys, sys->mm_lrec, stats); if (rc) return rc; stats[7] = 1; }
   return VSLAM_OK;
 }
 
@@ -799,6 +882,7 @@ __global__ void k_request_keyframe(MapDev m, TrackParams tp, int S, int stream) 
 extern "C" int vslam_add_keyframe(vslam_system* sys, int stream) {
   if (!sys || stream >= sys->S) { vslam_set_error("add_keyframe: bad argument"); return VSLAM_E_INVALID; }
   if (!sys->have_frame) { vslam_set_error("add_keyframe: no current frame"); return VSLAM_E_STATE; }
+  { int r = ba_drain(sys); if (r) return r; }        // asynchronous map-maker: collect the adjustments in flight first
   hipLaunchKernelGGL(k_request_keyframe, dim3((sys->S + 63) / 64), dim3(64), 0, sys->stream, sys->map, sys->tp, sys->S, stream);
-  return ba_run(sys, 0);
+  return ba_run(sys, 0, true);
 }

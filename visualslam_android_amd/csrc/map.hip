@@ -362,7 +362,6 @@ extern "C" int vslam_touch(vslam_system* sys) {
   return sys->p.bootstrap ? vslam_press_spacebar(sys, -1) : VSLAM_OK;
 }
 
-int ba_run(vslam_system* sys, int mode);
 extern "C" int vslam_bundle_adjust_recent(vslam_system* sys) { if (!sys) return VSLAM_E_INVALID; return ba_run(sys, 1); }
 extern "C" int vslam_bundle_adjust_all(vslam_system* sys) { if (!sys) return VSLAM_E_INVALID; return ba_run(sys, 2); }
 

@@ -103,6 +103,8 @@ extern "C" int vslam_create(const vslam_params* p, vslam_system** out) {
     if (hipEventCreateWithFlags(&sys->ev_fe_done[b], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&sys->ev_track_done[b], hipEventDisableTiming) != hipSuccess) { vslam_set_error("create: hipEventCreate failed"); vslam_destroy(sys); return VSLAM_E_HIP; }
   }
+  for (int k = 0; k < 4; k++)
+    if (hipEventCreate(&sys->ev_mm[k]) != hipSuccess) { vslam_set_error("create: hipEventCreate failed"); vslam_destroy(sys); return VSLAM_E_HIP; }
   for (int l = 0; l < NLEV; l++) {
     LevelGeom& g = sys->geom[l];
     g.w = p->width >> l; g.h = p->height >> l;
@@ -183,6 +185,7 @@ extern "C" int vslam_destroy(vslam_system* sys) {
   for (hipStream_t st : sys->ba_streams) (void)hipStreamDestroy(st);
   for (void* p : sys->allocs) (void)hipFree(p);
   for (hipEvent_t e : sys->prof_ev) (void)hipEventDestroy(e);
+  for (int k = 0; k < 4; k++) if (sys->ev_mm[k]) (void)hipEventDestroy(sys->ev_mm[k]);
   for (int b = 0; b < 2; b++) { if (sys->ev_fe_done[b]) (void)hipEventDestroy(sys->ev_fe_done[b]); if (sys->ev_track_done[b]) (void)hipEventDestroy(sys->ev_track_done[b]); }
   if (sys->fe_stream) (void)hipStreamDestroy(sys->fe_stream);
   if (sys->stream) (void)hipStreamDestroy(sys->stream);

@@ -191,7 +191,10 @@ struct vslam_system {
   long ba_batch_id = 0;        // the open batch
   int ba_batch_fill = 0;       // frames assembled into it so far
   std::vector<long> frame_batch;   // ring [ba_delay + 2]: the batch a frame's keyframes were assembled into
-  std::vector<char> prof_ba_launched;   // per profiled frame: did it launch k_ba_compute
+  std::vector<int> prof_ba_launched;    // per profiled frame: 0, or 1 + the launch record (BaPool::lstat) of the k_ba_compute it launched
+  long ba_launch_no = 0;       // k_ba_compute launches of this system so far (ring index of the launch records)
+  hipEvent_t ev_mm[4] = {nullptr, nullptr, nullptr, nullptr};   // host-driven BundleAdjustRecent / All: before select+assemble, compute, write-back, after
+  int mm_lrec = -1;            // launch record of the last host-driven call
   std::vector<void*> allocs;   // everything to hipFree
   bool have_frame;
   bool frame_open = false;  // stage-wise TrackFrame (vslam_patch_search ... vslam_finish_frame) in progress
@@ -249,7 +252,7 @@ int trk_pose_stage(vslam_system* sys, int stage);
 // ba.hip
 int ba_alloc(vslam_system* sys);
 int ba_add_keyframe_and_adjust(vslam_system* sys);
-int ba_run(vslam_system* sys, int mode);
+int ba_run(vslam_system* sys, int mode, bool host_driven_keyframe = false);
 int ba_frame_start(vslam_system* sys);
 int ba_sync_streams(vslam_system* sys);   // launches an open batch first, then   // host wait for every map-maker stream   // asynchronous map-maker: apply the results that are due at this frame
 // map.hip
