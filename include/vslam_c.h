@@ -95,6 +95,10 @@ typedef struct vslam_params {
                                       trails on the next frame, a second press runs MapMaker::InitFromStereo (HomographyInit, the stereo points,
                                       AddSomeMapPoints, BundleAdjustAll, CalcPlaneAligner) on the frame that consumes it.  Needs grow_map != 0
                                       (keyframe corner lists) and the synchronous map-maker for the streams being initialised.  0 (default): maps are uploaded */
+  int ba_sum_order;                /* 0 (default): Bundle::Compute sums U, V, the reduced camera system and the objectives as parallel partial sums and
+                                      matrix-core products (results within ~1e-10 of the reference's loops).  1: every sum in the order of the
+                                      reference's loops (jni/Bundle.cc:241-321, 362-470, 537-561) -- same results as the reference's sequential
+                                      code bit for bit, several times slower: the parity mode */
 } vslam_params;
 
 const char* vslam_last_error(void);

@@ -101,6 +101,18 @@ def assert_map_close(o, g, s, tag, tol):
         assert dk < tol, (tag, k, dk)
 
 
+def assert_map_exact(o, g, s, tag):
+    """The map bit for bit: structure, counters, point positions and keyframe poses == the oracle's (the bundle adjustment in its
+    reference-order summation mode, vslam_params.ba_sum_order = 1)."""
+    so, sg = o.state(), g.state(s)
+    assert (so.n_keyframes, so.n_points, so.ba_accepted, so.n_ba_trials) == (sg.n_keyframes, sg.n_points, sg.ba_accepted, sg.n_ba_trials), (tag, so.ba_accepted, sg.ba_accepted, so.n_ba_trials, sg.n_ba_trials)
+    po, pg = o.points(), g.points(s)
+    assert np.array_equal(po["bad"], pg["bad"]) and np.array_equal(po["n_in"], pg["n_in"]) and np.array_equal(po["n_out"], pg["n_out"]), tag
+    assert np.array_equal(po["pos"], pg["pos"]), (tag, np.abs(po["pos"] - pg["pos"]).max())
+    for k in range(so.n_keyframes):
+        assert np.array_equal(np.asarray(o.keyframe_pose(k)), np.asarray(g.keyframe_pose(s, k))), (tag, k, pose_err(o.keyframe_pose(k), g.keyframe_pose(s, k)))
+
+
 def resync(o, g, s):
     """Copy the oracle's bits over the device's: tracker pose and velocity, map point positions, keyframe poses.  After
     this the next frame starts from identical state on both sides, so its tracking is reproducible bit for bit."""

@@ -32,6 +32,58 @@ def check(o, g, problem, tol=1e-8, exact_outliers=True):
         assert np.array_equal(o.outlier_points(), g.outlier_points(problem))
 
 
+def check_exact(o, g, problem):
+    """vslam_params.ba_sum_order = 1: every sum of Bundle::Compute in the reference's order -> the same BITS as the oracle's
+    sequential loops: cameras, points, sigma, lambda, LM trial counts, the outlier lists in erase order."""
+    acc = o.compute()
+    r = g.result(problem)
+    s2, lam, trials = o.stats()
+    assert (r["accepted"], r["converged"], r["trials"]) == (acc, o.converged(), trials), (r, acc, trials)
+    assert r["sigma2"] == s2 and r["lambda"] == lam, (r, s2, lam)
+    assert np.array_equal(o.cameras(), g.cameras(problem)), np.abs(o.cameras() - g.cameras(problem)).max()
+    assert np.array_equal(o.points(), g.points(problem)), np.abs(o.points() - g.points(problem)).max()
+    assert np.array_equal(o.outlier_meas(), g.outlier_meas(problem)) and np.array_equal(o.outlier_points(), g.outlier_points(problem))
+
+
+@pytest.mark.parametrize("max_it,n_fixed", [(5, 1), (10, 2), (10, 1), (20, 1)])
+def test_config3_local_ba_5x300_reference_order_is_bit_exact(max_it, n_fixed):
+    """BASELINE.json configs[2] at its exact setting ([10-1]: 5 cameras, ONE fixed, 300 points, M = 1500, 10 LM iterations, Tukey) and
+    its neighbours, in the reference-order summation mode: == the oracle, far inside BASELINE.md's 1e-6, outlier lists included
+    (VERDICT r2 weak #3: the fast mode holds this case to 1e-4 because lambda has decayed to 0.3^10 and the gauge is free)."""
+    sc = ba_scene(n_cams=5, n_pts=300, pixel_noise=0.5, outlier_frac=0.05, seed=1, n_fixed=n_fixed)
+    vp = capi.default_params(640, 480, 1, ba_max_iterations=max_it, ba_sum_order=1)
+    o = orc.OracleBundle(CAM, 640, 480, max_iterations=max_it)
+    g = capi.Bundle(vp, 1, 8, 512, 4096)
+    load(o, sc); load(g, sc)
+    g.compute()
+    check_exact(o, g, 0)
+    assert g.result(0)["accepted"] > 0 and len(g.outlier_meas(0)) > 0
+    g.close()
+
+
+def test_reference_order_batched_shuffled_lists_and_window_sizes():
+    """The parity mode over everything the fast mode's tests cover: several problems in one launch, 1 to 9 adjustable cameras (the
+    register, LDS and global forms of the solve), fixed cameras interleaved, and measurement lists in a SHUFFLED AddMeas order (the
+    reference's sums follow the list, not the camera or point index)."""
+    rng = np.random.default_rng(7)
+    scs = [ba_scene(n_cams=4, n_pts=80, seed=11), ba_scene(n_cams=6, n_pts=200, pixel_noise=0.3, seed=12),
+           ba_scene(n_cams=10, n_pts=400, visibility=0.6, seed=13), ba_scene(n_cams=2, n_pts=23, pixel_noise=0.3, outlier_frac=0.03, seed=42),
+           ba_scene(n_cams=7, n_pts=100, pixel_noise=0.3, outlier_frac=0.03, seed=47, n_fixed=3), ba_scene(n_cams=12, n_pts=150, visibility=0.8, seed=48, n_fixed=1)]
+    for k in (1, 2, 4):                                                # three of them with their lists shuffled
+        scs[k]["meas"] = [scs[k]["meas"][i] for i in rng.permutation(len(scs[k]["meas"]))]
+    vp = capi.default_params(640, 480, 1, ba_max_iterations=8, ba_sum_order=1)
+    g = capi.Bundle(vp, len(scs), 12, 512, 8192)
+    os_ = []
+    for n, sc in enumerate(scs):
+        o = orc.OracleBundle(CAM, 640, 480, max_iterations=8)
+        load(o, sc); load(g, sc, problem=n)
+        os_.append(o)
+    g.compute()
+    for n, o in enumerate(os_):
+        check_exact(o, g, n)
+    g.close()
+
+
 @pytest.mark.parametrize("max_it,n_fixed,tol,exact", [(5, 1, 1e-8, True), (10, 2, 1e-6, True), (10, 1, 1e-4, False)])
 def test_config3_local_ba_5x300(max_it, n_fixed, tol, exact):
     # BASELINE.json configs[2]: 5 keyframes x 300 points, Tukey, 10 LM iterations, 0.5 px noise, 5 % +-20 px outliers.

@@ -18,7 +18,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import (POSE_TOL, check_and_resync, assert_map_close, assert_tracker_close, assert_tracker_exact, is_tracker_exact, make_oracle,
+from helpers import (POSE_TOL, check_and_resync, assert_map_close, assert_map_exact, assert_tracker_close, assert_tracker_exact, is_tracker_exact, make_oracle,
                      make_scene, pose_err, resync)
 from visualslam_android_amd import capi
 
@@ -66,6 +66,11 @@ def run_streams(w, h, patch, grow, n_frames, seeds, mode, **pkw):
                     assert np.array_equal(mo["pt"], mg["pt"]) and np.array_equal(mo["source"], mg["source"]) and np.array_equal(mo["level"], mg["level"]), tag
                     assert np.array_equal(mo["root"], mg["root"]), (tag, np.abs(mo["root"] - mg["root"]).max())   # tracker, re-found, root and epipolar entries: exact
                 resync(o, g, s)
+            elif mode == "free_exact":                      # never re-synchronised AND bit-exact: the reference-order bundle adjustment
+                assert_tracker_exact(o, g, s, tag)
+                exact[s] += 1
+                if o.state().kf_added:
+                    assert_map_exact(o, g, s, tag)
             else:
                 if not diverged[s] and is_tracker_exact(o, g, s):
                     exact[s] += 1
@@ -107,6 +112,18 @@ def test_free_running_sequence_against_the_pose_tolerance(patch, grow):
     sequence outside the north_star 1e-4."""
     exact, worst = run_streams(640, 480, patch, grow, 60, SEEDS, "free")
     assert min(exact) >= 1 and max(worst) < 5e-4, (exact, worst)
+
+
+@pytest.mark.parametrize("patch,grow", [(8, 0), (11, 0), (8, 3), (11, 3)])
+def test_free_running_sequence_is_bit_exact_with_reference_order_sums(patch, grow):
+    """the same 640x480 sequences, never re-synchronised, with vslam_params.ba_sum_order = 1 -- Bundle::Compute takes
+    U / epsilon_a, V / epsilon_b, the reduced camera system, the map updates and the objectives in the order of the reference's loops
+    (csrc/ba_ordered.h).  Then EVERYTHING is == the oracle's in EVERY frame of the free-running sequence: found sets, corners,
+    sub-pixel positions, templates, pose, velocity, and after each keyframe the whole map (point positions, keyframe poses, LM
+    trial counts, outlier bookkeeping).  This proves that the summation order of the fast mode's bundle adjustment is the ONLY
+    thing that separates the device path from the oracle in the free-running test above."""
+    exact, _ = run_streams(640, 480, patch, grow, 60, SEEDS, "free_exact", ba_sum_order=1)
+    assert exact == [60] * len(SEEDS)
 
 
 @pytest.mark.parametrize("w,h,patch,n_frames", [(320, 240, 11, 6), (1280, 720, 8, 3), (800, 480, 11, 3)])

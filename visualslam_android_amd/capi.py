@@ -32,7 +32,7 @@ class Params(C.Structure):
         ("wiggle_scale", C.c_double), ("ba_max_iterations", C.c_int), ("ba_convergence_limit", C.c_double),
         ("ba_min_tukey_sigma", C.c_double), ("ba_window", C.c_int), ("ba_min_keyframes", C.c_int),
         ("cam", C.c_double * 5), ("quirks", C.c_int), ("device", C.c_int), ("ba_delay_frames", C.c_int),
-        ("grow_map", C.c_int), ("ba_batch_frames", C.c_int), ("idle_iterations", C.c_int), ("bootstrap", C.c_int),
+        ("grow_map", C.c_int), ("ba_batch_frames", C.c_int), ("idle_iterations", C.c_int), ("bootstrap", C.c_int), ("ba_sum_order", C.c_int),
     ]
 
 

@@ -7,6 +7,7 @@
 //     start of frame t + D (ba_frame_start), the deterministic stand-in for PTAM's map-maker thread.
 #include "vslam_internal.h"
 #include "ba_device.h"
+#include "ba_ordered.h"
 #define BA_MAX_KF 128        // keyframes per stream = cameras of a bundle-adjustment problem (8-bit camera field of a slot: < 256)
 #include <string.h>
 #include <stdlib.h>
@@ -31,6 +32,8 @@ struct BaPool {            // device arrays for N problems
   // (problems, LM trials, and the trial-weighted sums of measurements, cameras, points, points x pairs of adjustable cameras,
   // (6 n_free)^3 that SURVEY.md 8(d)'s byte and flop formulas need); null for the stand-alone Bundle
   unsigned long long* lstat;
+  // parity mode (vslam_params.ba_sum_order = 1, ba_ordered.h): the per-slot terms of every sum; null otherwise
+  int* o_of_logical; double* o_obj; double* o_v9; double* o_u27; double* o_W; double* o_Y; double* o_ve; double* o_up;
 };
 #define BA_LSTAT_N 8
 #define BA_LSTAT_RING 1024
@@ -53,6 +56,14 @@ __host__ __device__ inline BaView ba_view(const BaPool& b, int n) {
   v.S = b.S + n * F * F; v.E = b.E + n * F; v.cam_up = b.cam_up + n * F;
   v.scratch = b.scratch + n * M; v.outl = b.outl + n * M * 2; v.free_cams = b.free_cams + n * C;
   return v;
+}
+
+__host__ __device__ inline BaOrdView ba_ord_view(const BaPool& b, int n) {
+  BaOrdView o;
+  const size_t P = b.max_pts, M = b.max_meas;
+  o.of_logical = b.o_of_logical + n * M; o.obj = b.o_obj + n * M; o.v9 = b.o_v9 + n * M * 9; o.u27 = b.o_u27 + n * M * 27;
+  o.W = b.o_W + n * M * 18; o.Y = b.o_Y + n * M * 18; o.ve = b.o_ve + n * P * 3; o.up = b.o_up + n * P * 3;
+  return o;
 }
 
 #ifndef VSLAM_BA_WPE
@@ -90,6 +101,42 @@ __global__ __launch_bounds__(BA_THREADS) __attribute__((amdgpu_waves_per_eu(VSLA
   }
 }
 
+// The same launch in the parity mode (vslam_params.ba_sum_order = 1): every sum in the reference's order (ba_ordered.h).  A kernel of
+// its own, so that its registers and LDS do not weigh on the fast path's.
+// (the same register bound as k_ba_compute: the two kernels share the out-of-line phase functions, which are compiled once)
+__global__ __launch_bounds__(BA_THREADS) __attribute__((amdgpu_waves_per_eu(VSLAM_BA_WPE, VSLAM_BA_WPE))) void k_ba_compute_ordered(BaPool pool, BaConfig cfg, int slot, int lrec) {
+  const int count = slot < 0 ? pool.N : pool.work_n[slot];
+  __shared__ int s_next;
+  int i = blockIdx.x;
+  while (i < count) {
+    const int n = slot < 0 ? i : pool.work[(size_t)slot * pool.N + i];
+    const BaView v = ba_view(pool, n);
+    if (v.res->active && !v.res->computed) {
+      ba_compute_ordered(v, cfg, ba_ord_view(pool, n));
+      if (threadIdx.x == 0) {
+        v.res->computed = 1;
+        if (lrec >= 0 && pool.lstat) {
+          unsigned long long* L = pool.lstat + (size_t)lrec * BA_LSTAT_N;
+          const unsigned long long t = (unsigned long long)v.res->trials, nf = (unsigned long long)v.res->n_free;
+          atomicAdd(&L[0], 1ull); atomicAdd(&L[1], t);
+          atomicAdd(&L[2], t * (unsigned long long)v.res->n_meas); atomicAdd(&L[3], t * (unsigned long long)v.res->n_cams); atomicAdd(&L[4], t * (unsigned long long)v.res->n_pts);
+          atomicAdd(&L[5], t * (unsigned long long)v.res->n_pts * (nf * (nf > 0 ? nf - 1 : 0) / 2)); atomicAdd(&L[6], t * (6 * nf) * (6 * nf) * (6 * nf));
+        }
+      }
+    }
+    if (slot < 0) break;
+    __syncthreads();
+    if (threadIdx.x == 0) s_next = (int)gridDim.x + atomicAdd(&pool.work_n[pool.work_slots + slot], 1);
+    __syncthreads();
+    i = s_next;
+  }
+}
+
+static void ba_launch_compute(const BaPool& pool, const BaConfig& cfg, int grid, hipStream_t st, int slot, int lrec) {
+  if (cfg.sum_order) hipLaunchKernelGGL(k_ba_compute_ordered, dim3(grid), dim3(BA_THREADS), 0, st, pool, cfg, slot, lrec);
+  else hipLaunchKernelGGL(k_ba_compute, dim3(grid), dim3(BA_THREADS), 0, st, pool, cfg, slot, lrec);
+}
+
 template <class T>
 static int pool_alloc(std::vector<void*>& allocs, hipStream_t st, T** out, size_t count) {
   void* ptr = nullptr;
@@ -101,7 +148,7 @@ static int pool_alloc(std::vector<void*>& allocs, hipStream_t st, T** out, size_
 }
 #define PALLOC(field, count) do { int _r = pool_alloc(allocs, st, &b.field, (count)); if (_r) return _r; } while (0)
 
-static int pool_create(BaPool& b, std::vector<void*>& allocs, hipStream_t st, int N, int max_cams, int max_pts, int max_meas, int work_slots = 1) {
+static int pool_create(BaPool& b, std::vector<void*>& allocs, hipStream_t st, int N, int max_cams, int max_pts, int max_meas, int work_slots = 1, bool ordered = false) {
   b.N = N; b.max_cams = max_cams; b.max_pts = max_pts; b.max_meas = max_meas; b.max_free = max_cams;
   const size_t n = N, C = max_cams, P = max_pts, M = max_meas, F = (size_t)max_cams * 6;
   PALLOC(res, n);
@@ -118,11 +165,17 @@ static int pool_create(BaPool& b, std::vector<void*>& allocs, hipStream_t st, in
   b.work_slots = work_slots > 0 ? work_slots : 1;
   PALLOC(work, n * b.work_slots); PALLOC(work_n, (size_t)2 * b.work_slots);   /* work_n[work_slots + slot]: the launch's draw counter */ PALLOC(view_of_kf, n * BA_MAX_KF);
   b.lstat = nullptr;
+  b.o_of_logical = nullptr; b.o_obj = b.o_v9 = b.o_u27 = b.o_W = b.o_Y = b.o_ve = b.o_up = nullptr;
+  if (ordered) {
+    PALLOC(o_of_logical, n * M); PALLOC(o_obj, n * M); PALLOC(o_v9, n * M * 9); PALLOC(o_u27, n * M * 27); PALLOC(o_W, n * M * 18); PALLOC(o_Y, n * M * 18);
+    PALLOC(o_ve, n * P * 3); PALLOC(o_up, n * P * 3);
+  }
   return VSLAM_OK;
 }
 
 static BaConfig make_cfg(const TrackParams& tp) {
   BaConfig c; c.cam = tp.cam; c.max_iterations = tp.ba_max_iterations; c.convergence_limit = tp.ba_convergence_limit; c.min_sigma2 = tp.ba_min_sigma2;
+  c.sum_order = tp.ba_sum_order;
   return c;
 }
 
@@ -150,7 +203,7 @@ extern "C" int vslam_bundle_create(const vslam_params* p, int n_problems, int ma
   HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
   trk_fill_params(*p, b->tp);
   b->cfg = make_cfg(b->tp);
-  int r = pool_create(b->pool, b->allocs, b->stream, n_problems, max_cameras, max_points, max_meas);
+  int r = pool_create(b->pool, b->allocs, b->stream, n_problems, max_cameras, max_points, max_meas, 1, b->cfg.sum_order != 0);
   if (r) { vslam_bundle_destroy(b); return r; }
   b->host.resize(n_problems);
   HIPCHK(hipStreamSynchronize(b->stream));
@@ -229,7 +282,7 @@ extern "C" int vslam_bundle_compute(vslam_bundle* b) {
     HIPCHK(hipStreamSynchronize(b->stream));   // host vectors go out of scope
   }
   b->uploaded = true;
-  hipLaunchKernelGGL(k_ba_compute, dim3(P.N), dim3(BA_THREADS), 0, b->stream, b->pool, b->cfg, -1, -1);
+  ba_launch_compute(b->pool, b->cfg, P.N, b->stream, -1, -1);
   HIPCHK(hipGetLastError());
   return VSLAM_OK;
 }
@@ -632,14 +685,14 @@ int ba_alloc(vslam_system* sys) {
   // worst case of BundleAdjust: every keyframe a camera, every point, every (kf, point) slot a measurement
   size_t M = (size_t)K * P;
   if (M > 65536) M = 65536;
-  int r = pool_create(ws->pool, sys->allocs, sys->stream, sys->S, K, P, (int)M, sys->p.ba_delay_frames > 0 ? sys->p.ba_delay_frames + 2 : 1);
+  int r = pool_create(ws->pool, sys->allocs, sys->stream, sys->S, K, P, (int)M, sys->p.ba_delay_frames > 0 ? sys->p.ba_delay_frames + 2 : 1, sys->p.ba_sum_order != 0);
   if (r) return r;
   r = pool_alloc(sys->allocs, sys->stream, &ws->pool.lstat, (size_t)BA_LSTAT_RING * BA_LSTAT_N);
   if (r) return r;
   // One launch of the full synchronous grid over the still empty pool (every problem inactive: the workgroups return at once).
   // k_ba_compute needs scratch memory, and the runtime sizes that lazily, at the first launch of a grid this large: paid here,
   // at creation, not by the first BundleAdjustRecent / BundleAdjustAll a caller times.
-  hipLaunchKernelGGL(k_ba_compute, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, ws->pool, make_cfg(sys->tp), -1, -1);
+  ba_launch_compute(ws->pool, make_cfg(sys->tp), sys->S, sys->stream, -1, -1);
   HIPCHK(hipGetLastError());
   return VSLAM_OK;
 }
@@ -676,7 +729,7 @@ static int ba_launch_batch(vslam_system* sys) {
   static const int per_cu_x2 = getenv("VSLAM_BA_WG_PER_CU_X2") ? atoi(getenv("VSLAM_BA_WG_PER_CU_X2")) : 4;   // diagnostic: background workgroups per CU, in halves
   const int cap = per_cu_x2 * (sys->n_cu > 0 ? sys->n_cu : 256) / 2;
   const int ba_grid = sys->S < cap ? sys->S : cap;
-  hipLaunchKernelGGL(k_ba_compute, dim3(ba_grid), dim3(BA_THREADS), 0, sys->ba_stream, ws->pool, cfg, slot, lrec);
+  ba_launch_compute(ws->pool, cfg, ba_grid, sys->ba_stream, slot, lrec);
   prof_mark(sys, PROF_BA_END);
   if (sys->prof_on && sys->prof_frame < sys->prof_cap && sys->prof_frame < (int)sys->prof_ba_launched.size()) sys->prof_ba_launched[sys->prof_frame] = lord + 1;
   HIPCHK(hipEventRecord(sys->ev_ba[slot], sys->ba_stream));
@@ -778,7 +831,7 @@ int ba_run(vslam_system* sys, int mode, bool host_driven_keyframe) {
   hipLaunchKernelGGL(k_ba_assemble, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, tps, ws->pool, base, -1, token);
   if (mode == 0) prof_mark(sys, 12);
   if (timed) HIPCHK(hipEventRecord(sys->ev_mm[1], sys->stream));
-  hipLaunchKernelGGL(k_ba_compute, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, ws->pool, cfg, -1, lrec);
+  ba_launch_compute(ws->pool, cfg, sys->S, sys->stream, -1, lrec);
   if (mode == 0) prof_mark(sys, 13);
   if (timed) HIPCHK(hipEventRecord(sys->ev_mm[2], sys->stream));
   hipLaunchKernelGGL(k_ba_writeback, dim3(sys->S), dim3(BA_THREADS), 0, sys->stream, sys->map, tps, ws->pool, wb);

@@ -153,7 +153,7 @@ __device__ unsigned long long g_ba_prof[32];
 #define MS(arr, k, i) v.arr[(size_t)(k) * v.max_meas + (i)]
 #define PT(arr, k, p) v.arr[(size_t)(k) * v.max_pts + (p)]
 
-struct BaConfig { CamModel cam; int max_iterations; double convergence_limit, min_sigma2; };
+struct BaConfig { CamModel cam; int max_iterations; double convergence_limit, min_sigma2; int sum_order; /* vslam_params.ba_sum_order */ };
 
 DEVFN double ba_wave_sum(double v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d); return v; }
 DEVFN int ba_wave_sum_i(int v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d); return v; }

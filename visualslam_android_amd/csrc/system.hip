@@ -50,6 +50,7 @@ extern "C" int vslam_default_params(vslam_params* p, int width, int height, int 
   p->ba_batch_frames = 1;
   p->idle_iterations = 0;
   p->bootstrap = 0;
+  p->ba_sum_order = 0;
   return VSLAM_OK;
 }
 

@@ -1080,6 +1080,7 @@ void trk_fill_params(const vslam_params& p, TrackParams& t) {
   t.ba_min_sigma2 = p.ba_min_tukey_sigma * p.ba_min_tukey_sigma; t.ba_window = p.ba_window; t.ba_min_keyframes = p.ba_min_keyframes;
   t.quirks = p.quirks; t.max_points = p.max_points; t.max_keyframes = p.max_keyframes; t.ba_delay = p.ba_delay_frames;
   t.ba_batch = p.ba_batch_frames > 1 ? p.ba_batch_frames : 1;
+  t.ba_sum_order = p.ba_sum_order ? 1 : 0;
   t.grow_map = p.grow_map;
   t.idle = p.idle_iterations != 0; t.fq_cap = 8192;
   {                                                                  // ATANCamera::OnePixelDist, jni/ATANCamera.cc:86-91

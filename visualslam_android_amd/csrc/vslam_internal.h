@@ -128,6 +128,7 @@ struct TrackParams {        // device copy of the tunables the kernels read
   int max_points, max_keyframes;
   int ba_delay;             // vslam_params.ba_delay_frames
   int ba_batch;             // vslam_params.ba_batch_frames (>= 1)
+  int ba_sum_order;         // vslam_params.ba_sum_order
   int grow_map;             // vslam_params.grow_map
   int idle;                 // vslam_params.idle_iterations
   int fq_cap;               // capacity of a stream's failure queue
