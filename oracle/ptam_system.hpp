@@ -185,6 +185,11 @@ struct System {
   SE3 CalcPlaneAligner(); void ApplyGlobalTransformationToMap(const SE3& new_from_old);
 };
 
+// map bootstrap mathematics (homography.cpp): HomographyMatch / HomographyDecomposition of jni/HomographyInit.h, HomographyInit::Compute, CalcPlaneAligner
+struct HMatch { double first[2], second[2], jac[4]; };           // v2CamPlaneFirst, v2CamPlaneSecond, m2PixelProjectionJac (row-major)
+struct HDecomposition { double Rp[9], Tp[3], n[3], d; double R[9], t[3]; int score; };
+bool homography_init_compute(const std::vector<HMatch>& m, double max_pixel_error, unsigned seed, SE3& second_from_first, int* n_inliers);
+bool calc_plane_aligner(const std::vector<V3>& points, unsigned seed, SE3& aligner);
 void make_keyframe_lite(KeyFrame& k, const uint8_t* gray, int w, int h, int stride, const int thr[4]);
 void make_keyframe_rest_nonmax(KeyFrame& k, int barrier, bool quirk);
 void make_keyframe_rest_candidates(KeyFrame& k, double min_score);
