@@ -10,7 +10,9 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, "_build", "libptam_oracle.so")
+# ORC_ORACLE_VARIANT=stdlibm selects the variant built on glibc's transcendentals instead of the product's libm-free ones (one process
+# loads one variant; tests/test_oracle_tracker.py runs the variant in a child process)
+LIB = os.path.join(HERE, "_build", "libptam_oracle_stdlibm.so" if os.environ.get("ORC_ORACLE_VARIANT") == "stdlibm" else "libptam_oracle.so")
 REF_MEST = os.path.join(HERE, "_ref", "libref_mestimator.so")
 LEVELS = 4
 _lib = None

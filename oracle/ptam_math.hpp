@@ -11,6 +11,29 @@
 
 namespace orc {
 
+// The transcendentals of the camera model and the Lie-group maps.  Default: the product's libm-free kernels (csrc/vslam_libm.h), so
+// that the oracle and the gfx950 code evaluate the same bits -- which makes oracle-vs-device bit parity of these functions true BY
+// CONSTRUCTION: it no longer checks the product against the reference's libm.  Two things stand in for that check:
+// tests/test_libm.py holds the kernels within 1-4 ulp of glibc, and the variant build -DORC_STD_LIBM (oracle/_build/
+// libptam_oracle_stdlibm.so: glibc's sin / cos / tan / atan / asin / acos, what a reference build on this host would call) is run
+// against the default build over a tracked sequence by tests/test_oracle_tracker.py, which measures what the substitution does to
+// poses and found sets.
+#ifdef ORC_STD_LIBM
+inline double tsin(double x) { return std::sin(x); }
+inline double tcos(double x) { return std::cos(x); }
+inline double ttan(double x) { return std::tan(x); }
+inline double tatan(double x) { return std::atan(x); }
+inline double tasin(double x) { return std::asin(x); }
+inline double tacos(double x) { return std::acos(x); }
+#else
+inline double tsin(double x) { return vlm::vsin(x); }
+inline double tcos(double x) { return vlm::vcos(x); }
+inline double ttan(double x) { return vlm::vtan(x); }
+inline double tatan(double x) { return vlm::vatan(x); }
+inline double tasin(double x) { return vlm::vasin(x); }
+inline double tacos(double x) { return vlm::vacos(x); }
+#endif
+
 struct V2 { double x, y; };
 struct V3 { double v[3]; double& operator[](int i) { return v[i]; } double operator[](int i) const { return v[i]; } };
 
@@ -77,7 +100,7 @@ inline void so3_exp(const double w[3], double R[9]) {
   double A, B;
   if (theta_sq < 1e-8) { A = 1.0 - one_6th * theta_sq; B = 0.5; }
   else if (theta_sq < 1e-6) { B = 0.5 - 0.25 * one_6th * theta_sq; A = 1.0 - theta_sq * one_6th * (1.0 - one_20th * theta_sq); }
-  else { const double inv_theta = 1.0 / theta; A = vlm::vsin(theta) * inv_theta; B = (1 - vlm::vcos(theta)) * (inv_theta * inv_theta); }
+  else { const double inv_theta = 1.0 / theta; A = tsin(theta) * inv_theta; B = (1 - tcos(theta)) * (inv_theta * inv_theta); }
   rodrigues(w, A, B, R);
 }
 
@@ -88,12 +111,12 @@ inline V3 so3_ln(const double M[9]) {
   result[0] = (M[7] - M[5]) / 2; result[1] = (M[2] - M[6]) / 2; result[2] = (M[3] - M[1]) / 2;
   double sin_angle_abs = sqrt(dot(result, result));
   if (cos_angle > M_SQRT1_2) {
-    if (sin_angle_abs > 0) result = result * (vlm::vasin(sin_angle_abs) / sin_angle_abs);
+    if (sin_angle_abs > 0) result = result * (tasin(sin_angle_abs) / sin_angle_abs);
   } else if (cos_angle > -M_SQRT1_2) {
-    const double angle = vlm::vacos(cos_angle);
+    const double angle = tacos(cos_angle);
     result = result * (angle / sin_angle_abs);
   } else {
-    const double angle = M_PI - vlm::vasin(sin_angle_abs);
+    const double angle = M_PI - tasin(sin_angle_abs);
     const double d0 = M[0] - cos_angle, d1 = M[4] - cos_angle, d2 = M[8] - cos_angle;
     V3 r2;
     if (d0 * d0 > d1 * d1 && d0 * d0 > d2 * d2) { r2[0] = d0; r2[1] = (M[3] + M[1]) / 2; r2[2] = (M[2] + M[6]) / 2; }
@@ -123,7 +146,7 @@ inline SE3 se3_exp(const double mu[6]) {
   } else {
     double C;
     if (theta_sq < 1e-6) { C = one_6th * (1.0 - one_20th * theta_sq); A = 1.0 - theta_sq * C; B = 0.5 - 0.25 * one_6th * theta_sq; }
-    else { const double inv_theta = 1.0 / theta; A = vlm::vsin(theta) * inv_theta; B = (1 - vlm::vcos(theta)) * (inv_theta * inv_theta); C = (1 - A) * (inv_theta * inv_theta); }
+    else { const double inv_theta = 1.0 / theta; A = tsin(theta) * inv_theta; B = (1 - tcos(theta)) * (inv_theta * inv_theta); C = (1 - A) * (inv_theta * inv_theta); }
     const V3 wc = cross(W, cr);
     for (int i = 0; i < 3; i++) result.t[i] = U[i] + B * cr[i] + C * wc[i];
   }
@@ -136,7 +159,7 @@ inline void se3_ln(const SE3& T, double out[6]) {
   V3 rotv = so3_ln(T.R);
   const double theta = sqrt(dot(rotv, rotv));
   double shtot = 0.5;
-  if (theta > 0.00001) shtot = vlm::vsin(theta / 2) / theta;
+  if (theta > 0.00001) shtot = tsin(theta / 2) / theta;
   const double half[3] = {rotv[0] * -0.5, rotv[1] * -0.5, rotv[2] * -0.5};
   SE3 hr; so3_exp(half, hr.R);
   const V3 tr = v3(T.t[0], T.t[1], T.t[2]);
@@ -167,9 +190,9 @@ struct Camera {
   double largest_radius, max_r;
 
   // jni/ATANCamera.h:145-150
-  double invrtrans(double r) const { if (w == 0.0) return r; return vlm::vtan(r * w) * one_over_2tan; }
+  double invrtrans(double r) const { if (w == 0.0) return r; return ttan(r * w) * one_over_2tan; }
   // jni/ATANCamera.h:136-142
-  double rtrans_factor(double r) const { if (r < 0.001 || w == 0.0) return 1.0; return winv * vlm::vatan(r * two_tan) / r; }
+  double rtrans_factor(double r) const { if (r < 0.001 || w == 0.0) return 1.0; return winv * tatan(r * two_tan) / r; }
 
   // jni/ATANCamera.cc:6-29 + SetImageSize :31-35 + RefreshParams :37-82
   void init(const double p[5], double width, double height, bool quirk_int_radius) {
@@ -179,7 +202,7 @@ struct Camera {
     center[0] = size[0] * params[2] - 0.5; center[1] = size[1] * params[3] - 0.5;
     inv_focal[0] = 1.0 / focal[0]; inv_focal[1] = 1.0 / focal[1];
     w = params[4];
-    if (w != 0.0) { two_tan = 2.0 * vlm::vtan(w / 2.0); one_over_2tan = 1.0 / two_tan; winv = 1.0 / w; distortion_enabled = 1.0; }
+    if (w != 0.0) { two_tan = 2.0 * ttan(w / 2.0); one_over_2tan = 1.0 / two_tan; winv = 1.0 / w; distortion_enabled = 1.0; }
     else { winv = 0.0; two_tan = 0.0; one_over_2tan = 0.0; distortion_enabled = 0.0; }
     double v2[2];
     if (quirk_int_radius) {  // :70-78 stores the operands in int -> both 0 (quirk #5)

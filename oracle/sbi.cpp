@@ -137,7 +137,7 @@ static SE2 sbi_iterate(const SBI& cur, const SBI& other, int nIterations, double
     SE2 U;
     U.t[0] = -upd[0]; U.t[1] = -upd[1];
     const double a = -upd[2];
-    U.R[0] = U.R[3] = vlm::vcos(a); U.R[2] = vlm::vsin(a); U.R[1] = -U.R[2];      // mySO2::exp, jni/RT.h:459-465
+    U.R[0] = U.R[3] = tcos(a); U.R[2] = tsin(a); U.R[1] = -U.R[2];      // mySO2::exp, jni/RT.h:459-465
     se2CtoC = se2_mul(se2CtoC, U);
     dMeanOffset -= upd[3];
   }

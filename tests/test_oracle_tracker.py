@@ -1,9 +1,13 @@
 """CPU test: the oracle's TrackFrame + AddKeyFrame + BundleAdjustRecent on a small synthetic sequence
 (BASELINE.json configs[0]: plumbing of the reference CPU path, no GPU)."""
+import os
+
 import numpy as np
 
 from helpers import make_oracle, make_scene, pose_err
 from visualslam_android_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_oracle_tracks_ground_truth_and_adds_keyframes():
@@ -144,3 +148,38 @@ def test_idle_jobs_of_the_map_maker():
     assert sa["ba_all"] == a.state().n_keyframes - len(m["keyframes"])
     assert seen_queue > 100 and sa["failure_queue"] == 0 and sa["refound_failed"] > seen_queue // 2
     assert sa["refound_new"] > 0
+
+
+def test_std_libm_variant_follows_the_default_build_within_the_free_running_bars():
+    """the oracle evaluates sin / cos / tan / atan / asin / acos with the product's libm-free kernels, so device-vs-oracle bit
+    parity of those functions holds by construction and says nothing about the reference's own libm.  This measures the substitution:
+    the same free-running sequence (45 frames, two keyframes with their bundle adjustments) through the default build and through the
+    variant built on glibc's libm (what a reference build on this host calls; oracle/Makefile, -DORC_STD_LIBM), in a child process.
+    Bars: the north_star pose tolerance in every frame, the same keyframe frames, found counts within 3."""
+    import json
+    import subprocess
+    import sys
+    code = (
+        "import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from helpers import make_scene, make_oracle\n"
+        "from visualslam_android_amd import capi\n"
+        "f, m, frames = make_scene(320, 240, seed=21, n_frames=45, per_level=(120, 50, 20, 8))\n"
+        "o = make_oracle(capi.default_params(320, 240, 1), m, f.pose(-1))\n"
+        "out = []\n"
+        "for i in range(45):\n"
+        "    o.track_frame(frames[i]); st = o.state()\n"
+        "    out.append([list(st.pose), list(st.found), st.kf_added, st.n_keyframes, st.quality])\n"
+        "print(json.dumps(out))\n") % (ROOT, os.path.join(ROOT, "tests"))
+    runs = {}
+    for variant in ("", "stdlibm"):
+        env = dict(os.environ, ORC_ORACLE_VARIANT=variant)
+        runs[variant] = json.loads(subprocess.check_output([sys.executable, "-c", code], env=env, text=True).strip().splitlines()[-1])
+    worst, bits_equal = 0.0, 0
+    for a, b in zip(runs[""], runs["stdlibm"]):
+        d = float(np.abs(np.array(a[0]) - np.array(b[0])).max())
+        worst = max(worst, d)
+        bits_equal += a[0] == b[0]
+        assert d < 1e-4, d
+        assert a[2:] == b[2:] and np.abs(np.array(a[1]) - np.array(b[1])).max() <= 3, (a[1:], b[1:])
+    assert runs[""][-1][3] >= 10                                  # two keyframes were added on top of the map's eight
+    print("std-libm variant: worst pose difference %.3g, %d of %d frames bit-equal" % (worst, bits_equal, len(runs[""])))
