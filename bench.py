@@ -169,6 +169,93 @@ def cpu_worker(job):
     return frames_done, secs, kfs
 
 
+def bench_ba(args, rank, world, local_rank):
+    """--config ba: BASELINE configs[2] / SURVEY.md 8(d) config 3 itself.  N independent problems of 5 cameras (camera 0 fixed) x 300
+    points, all visible (M = 1500), 0.5 px noise, 5 % gross outliers, Tukey, 10 LM iterations, through the stand-alone Bundle of the C ABI
+    (vslam_bundle_*: Bundle::AddCamera / AddPoint / AddMeas / Compute).  Unit of work = one Compute(); a step = one launch over the N
+    problems, their inputs resident in HBM before the launch's first HIP event.  Roofline: 8(d)'s B_ba / F_ba per LM trial (316,000 B and
+    1.56 MFLOP for this size) over the trials the launch itself counted.  cpu_baseline: the oracle's Compute() on one core."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from visualslam_android_amd import capi
+    from visualslam_android_amd.ba_scene import CAM, ba_scene
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    N, K, Wm = args.problems, args.steps, args.warmup
+    n_scenes = min(N, 64)                       # distinct seeded scenes; the N problems cycle through them
+    scenes = [ba_scene(n_cams=5, n_pts=300, pixel_noise=0.5, outlier_frac=0.05, seed=1000 * rank + i, n_fixed=1) for i in range(n_scenes)]
+    vp = capi.default_params(640, 480, 1, ba_max_iterations=10, device=local_rank, ba_sum_order=args.ba_sum_order)
+    g = capi.Bundle(vp, N, 8, 320, 1600)
+    for n in range(N):
+        sc = scenes[n % n_scenes]
+        g.set_problem(n, sc["cams_init"], [int(f) for f in sc["fixed"]], sc["pts_init"], [m[0] for m in sc["meas"]], [m[1] for m in sc["meas"]],
+                      [m[2] for m in sc["meas"]], [m[3] for m in sc["meas"]])
+    ms_steps, st_sum = [], {}
+    for it in range(Wm + K):
+        if it == Wm and world > 1:
+            dist.barrier()
+        g.compute()                              # uploads (untimed), then the launch between two HIP events on the Bundle's stream
+        ms, st = g.timing()
+        if it >= Wm:
+            ms_steps.append(ms)
+            for k_, v_ in st.items():
+                st_sum[k_] = st_sum.get(k_, 0) + v_
+    elapsed = sum(ms_steps) * 1e-3
+    total_t, gathered = aggregate(elapsed, [elapsed, float(N * K)], world)
+    res0 = g.result(0)
+    out = None
+    if rank == 0:
+        from oracle import binding as orc
+        fb, ff = ba_counted(st_sum)
+        ms_launch = 1e3 * elapsed / K
+        ach = fb / K / (ms_launch * 1e-3) / 1e9
+        # CPU: the oracle's Bundle::Compute on one core, the same problems (construction untimed), a bounded sample
+        t_cpu, n_cpu, tr_cpu = 0.0, 0, 0
+        parity = None
+        while t_cpu < args.cpu_seconds:
+            sc = scenes[n_cpu % n_scenes]
+            o = orc.OracleBundle(CAM, 640, 480, max_iterations=10)
+            for pose, fixed in zip(sc["cams_init"], sc["fixed"]):
+                o.add_camera(pose, fixed)
+            for p_ in sc["pts_init"]:
+                o.add_point(p_)
+            for (c_, p_, xy, s2) in sc["meas"]:
+                o.add_meas(c_, p_, xy, s2)
+            t0 = time.perf_counter()
+            acc = o.compute()
+            t_cpu += time.perf_counter() - t0
+            tr_cpu += int(o.stats()[2])
+            if n_cpu == 0:
+                parity = {"accepted": [int(acc), int(res0["accepted"])], "lm_trials": [int(o.stats()[2]), int(res0["trials"])],
+                          "camera_maxdiff": float(np.abs(o.cameras() - g.cameras(0)).max())}
+            n_cpu += 1
+            o.close()
+        out = {"metric": "Bundle::Compute()/sec, BASELINE configs[2]: local BA 5 keyframes x 300 map points, Tukey M-estimator, 10 LM iterations", "value": round(sum(x[1] for x in gathered) / total_t, 2),
+               "unit": "computes/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(1e3 * total_t / K, 4), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[2] (SURVEY.md 8(d) config 3): %d independent problems per GPU of 5 cameras (1 fixed) x 300 points, M = 1500, 0.5 px noise, 5 %% outliers, Tukey, 10 LM iterations; one vslam_bundle_compute launch per step" % N,
+                          "problems_per_gpu": N, "distinct_scenes": n_scenes, "ba_sum_order": args.ba_sum_order,
+                          "lm_trials_per_compute": round(st_sum["trials"] / max(1, st_sum["problems"]), 2), "latency_note": "ms_per_step = the launch of all problems; one Compute() alone on the GPU is latency-bound (a single workgroup)"},
+               "roofline": {"kernel": "k_ba_compute_ordered" if args.ba_sum_order else "k_ba_compute", "bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6),
+                            "traffic": None, "ms_per_launch": round(ms_launch, 4), "launches": K, "algorithmic_bytes": round(fb / K),
+                            "bytes_per_lm_trial": round(fb / max(1, st_sum["trials"]), 1), "flops_per_lm_trial": round(ff / max(1, st_sum["trials"]), 1),
+                            "lm_trials_per_launch": round(st_sum["trials"] / K, 1),
+                            "fp64": {"achieved": round(ff / K / (ms_launch * 1e-3) / 1e12, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ff / K / (ms_launch * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5)},
+                            "counted": "LM trials, bytes and flops of exactly these launches, accumulated on the device (vslam_bundle_get_timing)"},
+               "cpu_baseline": {"value": round(n_cpu / t_cpu, 2), "unit": "computes/s", "cores": 1, "kind": "port", "compute_latency_ms": round(1e3 * t_cpu / n_cpu, 3),
+                                "lm_trials_per_compute": round(tr_cpu / n_cpu, 2),
+                                "sample": "oracle Bundle::Compute (oracle/bundle.cpp, -O3, one thread) on %d of the same problems, %.1f s" % (n_cpu, t_cpu)},
+               "parity_problem0_oracle_vs_device": parity}
+        print(json.dumps(out), flush=True)
+    g.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,7 +287,19 @@ def main():
     ap.add_argument("--no-all-cores", action="store_true", help="skip the all-host-cores leg of cpu_baseline (one oracle process per core)")
     ap.add_argument("--no-flat-out", action="store_true", help="skip the flat-out bundle-adjustment round measured after the timed region")
     ap.add_argument("--parity-check", type=int, default=1, help="1: compare stream 0's final pose with the oracle run on the same frames")
+    ap.add_argument("--config", type=str, default="track", choices=("track", "ba"),
+                    help="track (default): the headline metric, TrackFrame + local BA on synthetic streams; ba: BASELINE configs[2] itself, N x Bundle::Compute of 5 cameras x 300 points")
+    ap.add_argument("--problems", type=int, default=4096, help="--config ba: independent problems per GPU and launch")
+    ap.add_argument("--ba-sum-order", type=int, default=0, help="vslam_params.ba_sum_order: 1 = every sum of Bundle::Compute in the reference's order (the parity mode)")
+    ap.add_argument("--host-frames", action="store_true",
+                    help="PCIe-inclusive variant (never the headline value): the frames stay in host memory and every step is one vslam_update -- upload + TrackFrame, synchronous like native_update, jni/jni_part.cpp:132-145")
+    ap.add_argument("--feeder-rects", type=int, default=0, help="rectangles of the feeder's texture (default 1000: ~1100 FAST corners at level 0 of 640x480; 1500 gives ~2000 at 1280x720, BASELINE configs[3])")
+    ap.add_argument("--n1-value", type=float, default=None, help="with --gpus N: the value of the N = 1 run, to print the scaling efficiency beside the per-rank rates")
     args = ap.parse_args()
+    if args.feeder_rects > 0:
+        os.environ["VSLAM_FEEDER_NRECT"] = str(args.feeder_rects)
+    if any(k.startswith(("ROCPROFILER_", "ROCP_", "ROCPROF")) for k in os.environ):   # under rocprofv3 the profiler attaches to every child process:
+        args.no_all_cores = True                # the 256-process CPU leg is skipped
 
     stub = os.environ.get("VSLAM_BENCH_STUB") == "1"   # CPU test of the launcher / aggregation path: gloo, no GPU, a stubbed step
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -209,6 +308,8 @@ def main():
     t_prog = time.perf_counter()
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the torch.distributed world has %d ranks" % (args.gpus, world))
+    if args.config == "ba" and os.environ.get("VSLAM_BENCH_STUB") != "1":
+        return bench_ba(args, rank, world, local_rank)
 
     import numpy as np
     import torch
@@ -226,7 +327,8 @@ def main():
         if rank == 0:
             out = {"metric": baseline_metric(), "value": round(sum(g[1] for g in gathered) / total_t, 2), "unit": "frames/s", "n_gpus": world,
                    "steps": K, "warmup": args.warmup, "ms_per_step": round(1e3 * total_t / K, 4), "higher_is_better": True, "scaling": "weak",
-                   "vs_baseline": None, "dtype": "f64", "data": "stub", "config": {"workload": "launcher self-test (VSLAM_BENCH_STUB=1): no GPU work"}}
+                   "vs_baseline": None, "dtype": "f64", "data": "stub", "config": {"workload": "launcher self-test (VSLAM_BENCH_STUB=1): no GPU work"},
+                   "per_rank": [{"rank": r, "frames_per_s": round(g[1] / g[0], 2), "ms_per_step": round(1e3 * g[0] / K, 4)} for r, g in enumerate(gathered)]}
             print(json.dumps(out), flush=True)
         if world > 1:
             dist.barrier()
@@ -300,7 +402,8 @@ def main():
         sy.set_pose(ls, feeders[s].pose(-1))
         if stagger:                            # Tracker::mnLastKeyFrameDropped: stream s asks for its first keyframe in frame 1 + phase
             sy.set_last_keyframe_dropped(ls, -20 + (s * stagger) // S)
-    frames_dev = torch.empty((T, S, H, W), dtype=torch.uint8, device="cuda")
+    host_mode = bool(args.host_frames)
+    frames_dev = torch.empty((T, S, H, W), dtype=torch.uint8, device="cpu" if host_mode else "cuda", pin_memory=host_mode)
     host_frames0 = None
     with ThreadPoolExecutor(max(1, nthreads // 4)) as ex:
         for s, fr in enumerate(ex.map(lambda f: f.render(0, T, threads=4), feeders)):
@@ -314,7 +417,10 @@ def main():
 
     def step(t):
         for k, sy in enumerate(systems):
-            sy.track_frame_device(base + t * fstride + k * Sk * H * W, W, H * W)
+            if host_mode:                       # native_update: host gray image in, synchronous (the caller may reuse its buffer)
+                capi._check(sy.lib.vslam_update(sy.h, base + t * fstride + k * Sk * H * W, W, H * W))
+            else:
+                sy.track_frame_device(base + t * fstride + k * Sk * H * W, W, H * W)
 
     def sync_all():
         for sy in systems:
@@ -429,6 +535,10 @@ def main():
     frames_total = sum(g[1] for g in gathered)
     value = frames_total / total_t
     good = int(round(sum(g[7] for g in gathered)))        # streams tracking GOOD at the end, all ranks
+    # per-GPU rates beside the aggregate (each rank's own clock over its own streams); the scaling efficiency
+    # needs the N = 1 value, which a multi-rank run does not have -- the driver computes it from its N = 1 line, or pass --n1-value
+    per_rank = [{"rank": r, "frames_per_s": round(g[1] / g[0], 2), "ms_per_step": round(1e3 * g[0] / K, 4), "streams_tracking_good": int(round(g[7])),
+                 "keyframes_added_per_stream": round(g[5], 3), "efficiency_vs_n1": (round(g[1] / g[0] / args.n1_value, 4) if args.n1_value else None)} for r, g in enumerate(gathered)]
 
     out = None
     if rank == 0:
@@ -521,7 +631,7 @@ def main():
         out = {
             "metric": baseline_metric(), "value": round(value, 2), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(1e3 * total_t / K, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic (frames in host memory, uploaded per step: PCIe-inclusive)" if host_mode else "synthetic",
             "config": {"workload": "BASELINE configs[%d]: %dx%d 4-level FAST-10 + %dx%d PatchFinder ZMSSD search, TrackMap pose update, "
                                    "AddKeyFrame + BundleAdjustRecent (%d-keyframe window) on keyframe frames" % (1 if (W, H) == (640, 480) else 3, W, H, args.patch, args.patch, args.ba_window),
                        "streams_per_gpu": S, "systems_per_gpu": NS, "ba_delay_frames": args.ba_delay, "ba_batch_frames": ba_batch, "ba_window": args.ba_window,
@@ -538,6 +648,11 @@ def main():
                              "sample": "oracle TrackFrame+BA (oracle/, -O3, one thread) over %d frames of synthetic sequences of the same workload (own seeds; %d keyframes with their bundle adjustment), %.1f s" % (n_cpu, cpu_kf, cpu_s),
                              "all_cores": all_cores},
             "stages": stages,
+            "per_rank": per_rank,
+            "scaling_efficiency_vs_n1": (round(value / (world * args.n1_value), 4) if args.n1_value else None),
+            "pcie_inclusive": ({"frames_per_s": round(value, 2), "host_GBps": round(value * W * H / 1e9, 2),
+                                "note": "--host-frames: every step uploads S frames from pinned host memory inside vslam_update (synchronous, like native_update); this line is NOT the headline value"} if host_mode else None),
+            "ba_flat_out": flat,
             "parity_pose_maxdiff_stream0": pose_diff,
         }
         print(json.dumps(out), flush=True)

@@ -334,7 +334,15 @@ int vslam_bundle_add_camera(vslam_bundle* b, int problem, const double pose12[12
 int vslam_bundle_add_point(vslam_bundle* b, int problem, const double pos[3]);                   /* Bundle::AddPoint  */
 int vslam_bundle_add_meas(vslam_bundle* b, int problem, int cam, int point, const double pos[2],
                           double sigma_squared);                                                  /* Bundle::AddMeas   */
-/* Bundle::Compute for every problem (one launch); asynchronous. accepted[problem] read by _get_result. */
+/* Bundle::AddCamera / AddPoint / AddMeas for a whole problem at once, replacing what it held: pose12 n_cams x 12, fixed n_cams,
+ * pos3 n_pts x 3; cam, point, sigma_squared n_meas and xy n_meas x 2 in AddMeas order. */
+int vslam_bundle_set_problem(vslam_bundle* b, int problem, int n_cams, const double* pose12, const int* fixed, int n_pts, const double* pos3,
+                             int n_meas, const int* cam, const int* point, const double* xy, const double* sigma_squared);
+/* HIP-event milliseconds of the last vslam_bundle_compute launch (its inputs were resident before the first event) and the counters
+ * the launch kept on the device (stats[8] as vslam_profile_ba_stats; may be NULL).  Synchronises. */
+int vslam_bundle_get_timing(vslam_bundle* b, double* ms, unsigned long long stats[8]);
+/* Bundle::Compute for every problem (one launch), each from the cameras / points / measurements the caller added -- a second call
+ * starts again from those, not from the first call's result; asynchronous. accepted[problem] read by _get_result. */
 int vslam_bundle_compute(vslam_bundle* b);
 int vslam_bundle_synchronize(vslam_bundle* b);
 int vslam_bundle_get_result(vslam_bundle* b, int problem, int* accepted, int* converged, double* sigma_squared,

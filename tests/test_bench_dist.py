@@ -77,6 +77,8 @@ def test_gpus_n_starts_n_ranks_itself():
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["data"] == "stub"
     assert abs(d["value"] - 2 * 10 * 20 / (d["ms_per_step"] * 20e-3)) < 0.01 * d["value"]
     assert d["ms_per_step"] >= 2.0                                  # rank 1 sleeps 2 ms per step: the max over ranks counts
+    pr = d["per_rank"]                                              # the per-GPU rates beside the aggregate
+    assert [x["rank"] for x in pr] == [0, 1] and pr[0]["frames_per_s"] > 1.5 * pr[1]["frames_per_s"] > 0    # rank 0 sleeps 1 ms per step
 
 
 def test_world_size_must_equal_gpus():

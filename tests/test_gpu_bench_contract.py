@@ -35,3 +35,35 @@ def test_bench_json_line_contract():
     assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["value"] > 0
     assert d["config"]["streams_tracking_good"] == 8
     assert d["parity_pose_maxdiff_stream0"] is not None and d["parity_pose_maxdiff_stream0"] < 1e-4   # north_star pose tolerance
+
+
+def _run(args, timeout=600):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_bench_config_ba_line():
+    """bench.py --config ba: BASELINE configs[2] itself (5 cameras x 300 points, M = 1500, 10 LM iterations) -- SURVEY.md 8(d)'s 316,000 B
+    and 1.56 MFLOP per LM trial in the roofline (from the launch's own device counters), the oracle's Compute() latency on one core, and
+    problem 0 against the oracle."""
+    d = _run(["--config", "ba", "--problems", "64", "--steps", "3", "--warmup", "1", "--cpu-seconds", "2"])
+    assert d["unit"] == "computes/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["config"]["problems_per_gpu"] == 64
+    r = d["roofline"]
+    assert r["kernel"] == "k_ba_compute" and r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
+    assert abs(r["bytes_per_lm_trial"] - 315960) < 1000 and abs(r["flops_per_lm_trial"] - 1.56e6) < 0.02e6      # all points seen by all 5 cameras, 4 adjustable
+    assert abs(d["value"] - 64 * 3 / (d["ms_per_step"] * 3e-3)) < 0.01 * d["value"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["compute_latency_ms"] > 0 and c["unit"] == "computes/s"
+    p = d["parity_problem0_oracle_vs_device"]
+    assert p["accepted"][0] == p["accepted"][1] and p["lm_trials"][0] == p["lm_trials"][1] and p["camera_maxdiff"] < 1e-4
+
+
+def test_bench_host_frames_line():
+    """bench.py --host-frames: the PCIe-inclusive variant through vslam_update (native_update's way); reported apart from the headline."""
+    d = _run(["--host-frames", "--streams", "8", "--steps", "6", "--warmup", "2", "--cpu-seconds", "1", "--no-all-cores", "--no-flat-out"])
+    assert d["pcie_inclusive"] and d["pcie_inclusive"]["frames_per_s"] == d["value"] and "host memory" in d["data"]
+    assert d["config"]["streams_tracking_good"] == 8 and d["parity_pose_maxdiff_stream0"] < 1e-4
+    assert d["per_rank"][0]["rank"] == 0 and abs(d["per_rank"][0]["frames_per_s"] - d["value"]) < 0.01 * d["value"]

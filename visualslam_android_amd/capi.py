@@ -124,6 +124,8 @@ SYMBOLS = {
     "vslam_bundle_add_point": (_i, [_vp, _i, _vp]),
     "vslam_bundle_add_meas": (_i, [_vp, _i, _i, _i, _vp, _d]),
     "vslam_bundle_compute": (_i, [_vp]),
+    "vslam_bundle_set_problem": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "vslam_bundle_get_timing": (_i, [_vp, _vp, _vp]),
     "vslam_bundle_synchronize": (_i, [_vp]),
     "vslam_bundle_get_result": (_i, [_vp, _i, _ip, _ip, C.POINTER(_d), C.POINTER(_d), C.POINTER(C.c_longlong)]),
     "vslam_bundle_get_camera": (_i, [_vp, _i, _i, _vp]),
@@ -573,6 +575,21 @@ class Bundle:
 
     def add_meas(self, cam, pt, pos2, sigma2, problem=0):
         _check(self.lib.vslam_bundle_add_meas(self.h, problem, cam, pt, _f64(pos2).ctypes.data, float(sigma2)))
+
+    def set_problem(self, problem, cams, fixed, pts, meas_cam, meas_pt, meas_xy, meas_sigma2):
+        """the whole problem at once (vslam_bundle_set_problem): cams [n][12], fixed [n], pts [m][3], measurements in AddMeas order"""
+        cams = np.ascontiguousarray(cams, np.float64); fx = np.ascontiguousarray(fixed, np.int32); pts = np.ascontiguousarray(pts, np.float64)
+        mc = np.ascontiguousarray(meas_cam, np.int32); mp = np.ascontiguousarray(meas_pt, np.int32)
+        xy = np.ascontiguousarray(meas_xy, np.float64); s2 = np.ascontiguousarray(meas_sigma2, np.float64)
+        _check(self.lib.vslam_bundle_set_problem(self.h, problem, len(cams), cams.ctypes.data, fx.ctypes.data, len(pts), pts.ctypes.data,
+                                                 len(mc), mc.ctypes.data, mp.ctypes.data, xy.ctypes.data, s2.ctypes.data))
+
+    def timing(self):
+        """-> (HIP-event ms of the last compute launch, the launch's device counters as System.profile_ba_stats)"""
+        ms = C.c_double(0.0)
+        st = np.zeros(8, np.uint64)
+        _check(self.lib.vslam_bundle_get_timing(self.h, C.byref(ms), st.ctypes.data))
+        return ms.value, {k: int(v) for k, v in zip(System.BA_STAT_KEYS, st)}
 
     def compute(self, sync=True):
         _check(self.lib.vslam_bundle_compute(self.h))

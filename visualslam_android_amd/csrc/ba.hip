@@ -133,8 +133,9 @@ __global__ __launch_bounds__(BA_THREADS) __attribute__((amdgpu_waves_per_eu(VSLA
 }
 
 static void ba_launch_compute(const BaPool& pool, const BaConfig& cfg, int grid, hipStream_t st, int slot, int lrec) {
+  static const int dyn_lds = getenv("VSLAM_BA_DYN_LDS") ? atoi(getenv("VSLAM_BA_DYN_LDS")) : 0;   // diagnostic: extra LDS per workgroup, to lower the workgroups per CU
   if (cfg.sum_order) hipLaunchKernelGGL(k_ba_compute_ordered, dim3(grid), dim3(BA_THREADS), 0, st, pool, cfg, slot, lrec);
-  else hipLaunchKernelGGL(k_ba_compute, dim3(grid), dim3(BA_THREADS), 0, st, pool, cfg, slot, lrec);
+  else hipLaunchKernelGGL(k_ba_compute, dim3(grid), dim3(BA_THREADS), dyn_lds, st, pool, cfg, slot, lrec);
 }
 
 template <class T>
@@ -187,6 +188,7 @@ struct HostProblem { std::vector<Pose> cams; std::vector<int> fixed; std::vector
 struct vslam_bundle {
   BaPool pool; std::vector<void*> allocs; hipStream_t stream; BaConfig cfg; TrackParams tp;
   std::vector<HostProblem> host; bool uploaded;
+  hipEvent_t ev[2] = {nullptr, nullptr};      // around the last Bundle::Compute launch (vslam_bundle_get_timing)
 };
 
 
@@ -204,6 +206,8 @@ extern "C" int vslam_bundle_create(const vslam_params* p, int n_problems, int ma
   trk_fill_params(*p, b->tp);
   b->cfg = make_cfg(b->tp);
   int r = pool_create(b->pool, b->allocs, b->stream, n_problems, max_cameras, max_points, max_meas, 1, b->cfg.sum_order != 0);
+  if (!r) r = pool_alloc(b->allocs, b->stream, &b->pool.lstat, (size_t)BA_LSTAT_N);          // one launch record (vslam_bundle_get_timing)
+  if (!r && (hipEventCreate(&b->ev[0]) != hipSuccess || hipEventCreate(&b->ev[1]) != hipSuccess)) { vslam_set_error("bundle_create: hipEventCreate failed"); r = VSLAM_E_HIP; }
   if (r) { vslam_bundle_destroy(b); return r; }
   b->host.resize(n_problems);
   HIPCHK(hipStreamSynchronize(b->stream));
@@ -215,6 +219,7 @@ extern "C" int vslam_bundle_destroy(vslam_bundle* b) {
   if (!b) return VSLAM_OK;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   for (void* p : b->allocs) (void)hipFree(p);
+  for (int k = 0; k < 2; k++) if (b->ev[k]) (void)hipEventDestroy(b->ev[k]);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
   return VSLAM_OK;
@@ -251,39 +256,84 @@ extern "C" int vslam_bundle_add_meas(vslam_bundle* b, int n, int cam, int point,
   return VSLAM_OK;
 }
 
+// Bundle::AddCamera / AddPoint / AddMeas for a whole problem at once (replaces what the problem held): n_cams poses (12 doubles each)
+// and fixed flags, n_pts positions, n_meas measurements (camera, point, position, sigma squared) in AddMeas order.
+extern "C" int vslam_bundle_set_problem(vslam_bundle* b, int n, int n_cams, const double* pose12, const int* fixed, int n_pts, const double* pos3,
+                                        int n_meas, const int* cam, const int* point, const double* xy, const double* sigma_squared) {
+  BCHECK(b && n >= 0 && n < b->pool.N && n_cams >= 0 && n_pts >= 0 && n_meas >= 0, "set_problem: bad argument");
+  BCHECK((n_cams == 0 || (pose12 && fixed)) && (n_pts == 0 || pos3) && (n_meas == 0 || (cam && point && xy && sigma_squared)), "set_problem: null array");
+  if (n_cams > b->pool.max_cams || n_pts > b->pool.max_pts || n_meas > b->pool.max_meas) { vslam_set_error("bundle: set_problem exceeds the capacity"); return VSLAM_E_CAPACITY; }
+  HostProblem& h = b->host[n];
+  h = HostProblem();
+  for (int c = 0; c < n_cams; c++) { Pose p; for (int i = 0; i < 9; i++) p.R[i] = pose12[12 * c + i]; for (int i = 0; i < 3; i++) p.t[i] = pose12[12 * c + 9 + i]; h.cams.push_back(p); h.fixed.push_back(fixed[c] ? 1 : 0); }
+  for (int i = 0; i < n_pts; i++) {
+    double q[3] = {pos3[3 * i], pos3[3 * i + 1], pos3[3 * i + 2]};
+    if (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] != q[0] * q[0] + q[1] * q[1] + q[2] * q[2]) q[0] = q[1] = q[2] = 0;   // NaN guard, jni/Bundle.cc:93-96
+    h.pts.insert(h.pts.end(), q, q + 3);
+  }
+  for (int i = 0; i < n_meas; i++) {
+    BCHECK(cam[i] >= 0 && cam[i] < n_cams && point[i] >= 0 && point[i] < n_pts, "measurement refers to an unknown camera/point");
+    h.mp.push_back(point[i]); h.mc.push_back(cam[i]); h.mfound.push_back(xy[2 * i]); h.mfound.push_back(xy[2 * i + 1]);
+    h.msin.push_back(sqrt(1.0 / sigma_squared[i]));
+  }
+  return VSLAM_OK;
+}
+
 extern "C" int vslam_bundle_compute(vslam_bundle* b) {
   BCHECK(b, "null");
   const BaPool& P = b->pool;
-  for (int n = 0; n < P.N; n++) {
+  // the problems as the caller built them, staged per array for all problems and uploaded with one copy per array (Compute leaves
+  // its result in the cameras and points, so every call starts again from the caller's values)
+  const size_t N = P.N, C = P.max_cams, PP = P.max_pts, M = P.max_meas;
+  std::vector<BaResult> res(N);
+  std::vector<Pose> cams(N * C); std::vector<int> fixed(N * C, 0);
+  std::vector<double> pts(N * PP * 3, 0.0), found(N * M * 2, 0.0), msin(N * M, 0.0);
+  std::vector<int> mp(N * M, 0), mc(N * M, 0), lut(N * C * PP, -1), nmeas(N * PP, 0);
+  for (size_t n = 0; n < N; n++) {
     const HostProblem& h = b->host[n];
-    BaView v = ba_view(P, n);
     BaResult r; memset(&r, 0, sizeof(r));
     r.n_cams = (int)h.cams.size(); r.n_pts = (int)h.pts.size() / 3; r.n_meas = (int)h.mp.size();
     r.active = r.n_cams > 0 && r.n_pts > 0 && r.n_meas > 0;
-    HIPCHK(hipMemcpyAsync(v.res, &r, sizeof(r), hipMemcpyHostToDevice, b->stream));
-    if (!r.active) continue;
-    HIPCHK(hipMemcpyAsync(v.cam_pose, h.cams.data(), sizeof(Pose) * r.n_cams, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipMemcpyAsync(v.cam_fixed, h.fixed.data(), sizeof(int) * r.n_cams, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipMemcpyAsync(v.pt_pos, h.pts.data(), sizeof(double) * 3 * r.n_pts, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipMemcpyAsync(v.ms_p, h.mp.data(), sizeof(int) * r.n_meas, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipMemcpyAsync(v.ms_c, h.mc.data(), sizeof(int) * r.n_meas, hipMemcpyHostToDevice, b->stream));
-    std::vector<double> fx(r.n_meas), fy(r.n_meas);   // component-major on device (ba_device.h MS())
-    for (int i = 0; i < r.n_meas; i++) { fx[i] = h.mfound[2 * i]; fy[i] = h.mfound[2 * i + 1]; }
-    HIPCHK(hipMemcpyAsync(v.ms_found, fx.data(), sizeof(double) * r.n_meas, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipMemcpyAsync(v.ms_found + P.max_meas, fy.data(), sizeof(double) * r.n_meas, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));
-    HIPCHK(hipMemcpyAsync(v.ms_sin, h.msin.data(), sizeof(double) * r.n_meas, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipMemsetAsync(v.ms_state, 0, sizeof(int) * r.n_meas, b->stream));
-    HIPCHK(hipMemsetAsync(v.pt_nout, 0, sizeof(int) * r.n_pts, b->stream));
-    std::vector<int> lut((size_t)P.max_cams * P.max_pts, -1), nmeas(r.n_pts, 0);
-    for (int i = 0; i < r.n_meas; i++) { lut[(size_t)h.mc[i] * P.max_pts + h.mp[i]] = i; nmeas[h.mp[i]]++; }   // GenerateMeasLUTs
-    HIPCHK(hipMemcpyAsync(v.lut, lut.data(), sizeof(int) * lut.size(), hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipMemcpyAsync(v.pt_nmeas, nmeas.data(), sizeof(int) * r.n_pts, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));   // host vectors go out of scope
+    res[n] = r;
+    for (int c = 0; c < r.n_cams; c++) { cams[n * C + c] = h.cams[c]; fixed[n * C + c] = h.fixed[c]; }
+    for (int i = 0; i < 3 * r.n_pts; i++) pts[n * PP * 3 + i] = h.pts[i];
+    for (int i = 0; i < r.n_meas; i++) {
+      mp[n * M + i] = h.mp[i]; mc[n * M + i] = h.mc[i]; msin[n * M + i] = h.msin[i];
+      found[n * M * 2 + i] = h.mfound[2 * i]; found[n * M * 2 + M + i] = h.mfound[2 * i + 1];      // component-major on device (ba_device.h MS())
+      lut[n * C * PP + (size_t)h.mc[i] * PP + h.mp[i]] = i; nmeas[n * PP + h.mp[i]]++;              // GenerateMeasLUTs
+    }
   }
+  HIPCHK(hipMemcpyAsync(P.res, res.data(), sizeof(BaResult) * N, hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(P.cam_pose, cams.data(), sizeof(Pose) * N * C, hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(P.cam_fixed, fixed.data(), sizeof(int) * N * C, hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(P.pt_pos, pts.data(), sizeof(double) * N * PP * 3, hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(P.ms_p, mp.data(), sizeof(int) * N * M, hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(P.ms_c, mc.data(), sizeof(int) * N * M, hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(P.ms_found, found.data(), sizeof(double) * N * M * 2, hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(P.ms_sin, msin.data(), sizeof(double) * N * M, hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemsetAsync(P.ms_state, 0, sizeof(int) * N * M, b->stream));
+  HIPCHK(hipMemsetAsync(P.pt_nout, 0, sizeof(int) * N * PP, b->stream));
+  HIPCHK(hipMemcpyAsync(P.lut, lut.data(), sizeof(int) * N * C * PP, hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(P.pt_nmeas, nmeas.data(), sizeof(int) * N * PP, hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemsetAsync(P.lstat, 0, sizeof(unsigned long long) * BA_LSTAT_N, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));             // the staging vectors go out of scope; the inputs are resident before the timed launch
   b->uploaded = true;
-  ba_launch_compute(b->pool, b->cfg, P.N, b->stream, -1, -1);
+  HIPCHK(hipEventRecord(b->ev[0], b->stream));
+  ba_launch_compute(b->pool, b->cfg, P.N, b->stream, -1, 0);
+  HIPCHK(hipEventRecord(b->ev[1], b->stream));
   HIPCHK(hipGetLastError());
+  return VSLAM_OK;
+}
+
+// HIP-event time of the last vslam_bundle_compute launch (the problems already resident) and what it ran: stats as vslam_profile_ba_stats
+extern "C" int vslam_bundle_get_timing(vslam_bundle* b, double* ms, unsigned long long stats[8]) {
+  BCHECK(b && ms, "get_timing: bad argument");
+  if (!b->uploaded) { vslam_set_error("bundle: compute has not run"); return VSLAM_E_STATE; }
+  HIPCHK(hipStreamSynchronize(b->stream));
+  float t = 0.f;
+  HIPCHK(hipEventElapsedTime(&t, b->ev[0], b->ev[1]));
+  *ms = t;
+  if (stats) { HIPCHK(hipMemcpy(stats, b->pool.lstat, sizeof(unsigned long long) * BA_LSTAT_N, hipMemcpyDeviceToHost)); stats[7] = 1; }
   return VSLAM_OK;
 }
 
