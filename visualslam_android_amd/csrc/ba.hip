@@ -138,41 +138,54 @@ static void ba_launch_compute(const BaPool& pool, const BaConfig& cfg, int grid,
   else hipLaunchKernelGGL(k_ba_compute, dim3(grid), dim3(BA_THREADS), dyn_lds, st, pool, cfg, slot, lrec);
 }
 
-template <class T>
-static int pool_alloc(std::vector<void*>& allocs, hipStream_t st, T** out, size_t count) {
-  void* ptr = nullptr;
-  HIPCHK(hipMalloc(&ptr, count * sizeof(T) + 64));
-  HIPCHK(hipMemsetAsync(ptr, 0, count * sizeof(T) + 64, st));
-  allocs.push_back(ptr);
-  *out = (T*)ptr;
-  return VSLAM_OK;
+// The arrays of a pool are carved out of ONE device allocation (256-byte aligned each): some forty separate allocations, most of them
+// below the 2 MB that earns large page-table fragments, cost a launch over thousands of problems milliseconds of address-translation
+// misses in its first phase (observed: Bundle::Compute of 1024 small problems 4 ms or 26-31 ms from run to run).
+struct PoolArena { char* base; size_t off; };
+template <class T> static void arena_take(PoolArena& a, T** out, size_t count) {
+  a.off = (a.off + 255) & ~(size_t)255;
+  if (a.base) *out = (T*)(a.base + a.off);
+  a.off += count * sizeof(T);
 }
-#define PALLOC(field, count) do { int _r = pool_alloc(allocs, st, &b.field, (count)); if (_r) return _r; } while (0)
+#define PALLOC(field, count) arena_take(a, &b.field, (count))
 
-static int pool_create(BaPool& b, std::vector<void*>& allocs, hipStream_t st, int N, int max_cams, int max_pts, int max_meas, int work_slots = 1, bool ordered = false) {
+static int pool_create(BaPool& b, std::vector<void*>& allocs, hipStream_t st, int N, int max_cams, int max_pts, int max_meas, int work_slots = 1, bool ordered = false, size_t lstat_records = 0) {
   b.N = N; b.max_cams = max_cams; b.max_pts = max_pts; b.max_meas = max_meas; b.max_free = max_cams;
-  const size_t n = N, C = max_cams, P = max_pts, M = max_meas, F = (size_t)max_cams * 6;
-  PALLOC(res, n);
-  PALLOC(cam_pose, n * C); PALLOC(cam_new, n * C); PALLOC(cam_fixed, n * C); PALLOC(cam_row, n * C); PALLOC(cam_U, n * C * 36); PALLOC(cam_ea, n * C * 6);
-  PALLOC(pt_pos, n * P * 3); PALLOC(pt_new, n * P * 3); PALLOC(pt_V, n * P * 6); PALLOC(pt_eb, n * P * 3);
-  PALLOC(pt_nmeas, n * P); PALLOC(pt_nout, n * P);
-  PALLOC(ms_p, n * M); PALLOC(ms_c, n * M); PALLOC(ms_state, n * M); PALLOC(ms_found, n * M * 2); PALLOC(ms_sin, n * M);
-  PALLOC(lut, n * C * P);
-  PALLOC(sl_info, n * M); PALLOC(sl_pt, n * M); PALLOC(sl_logical, n * M); PALLOC(sl_found, n * M * 2); PALLOC(sl_sin, n * M);
-  PALLOC(sl_cm, n * M * 3); PALLOC(sl_d, n * M * 4); PALLOC(sl_eps, n * M * 2);
-  PALLOC(pt_offF, n * (P + 1)); PALLOC(pt_offX, n * (P + 1)); PALLOC(pt_maskF, n * P); PALLOC(chF, n * (P + 2)); PALLOC(chX, n * (P + 2)); PALLOC(ch_n, n * 4);
-  PALLOC(S, n * F * F); PALLOC(E, n * F); PALLOC(cam_up, n * F);
-  PALLOC(scratch, n * M); PALLOC(outl, n * M * 2); PALLOC(free_cams, n * C); PALLOC(id_view, n * C); PALLOC(id_point, n * P);
   b.work_slots = work_slots > 0 ? work_slots : 1;
-  PALLOC(work, n * b.work_slots); PALLOC(work_n, (size_t)2 * b.work_slots);   /* work_n[work_slots + slot]: the launch's draw counter */ PALLOC(view_of_kf, n * BA_MAX_KF);
-  b.lstat = nullptr;
-  b.o_of_logical = nullptr; b.o_obj = b.o_v9 = b.o_u27 = b.o_W = b.o_Y = b.o_ve = b.o_up = nullptr;
-  if (ordered) {
-    PALLOC(o_of_logical, n * M); PALLOC(o_obj, n * M); PALLOC(o_v9, n * M * 9); PALLOC(o_u27, n * M * 27); PALLOC(o_W, n * M * 18); PALLOC(o_Y, n * M * 18);
-    PALLOC(o_ve, n * P * 3); PALLOC(o_up, n * P * 3);
-  }
+  const size_t n = N, C = max_cams, P = max_pts, M = max_meas, F = (size_t)max_cams * 6;
+  auto carve = [&](PoolArena& a) {
+    PALLOC(res, n);
+    PALLOC(cam_pose, n * C); PALLOC(cam_new, n * C); PALLOC(cam_fixed, n * C); PALLOC(cam_row, n * C); PALLOC(cam_U, n * C * 36); PALLOC(cam_ea, n * C * 6);
+    PALLOC(pt_pos, n * P * 3); PALLOC(pt_new, n * P * 3); PALLOC(pt_V, n * P * 6); PALLOC(pt_eb, n * P * 3);
+    PALLOC(pt_nmeas, n * P); PALLOC(pt_nout, n * P);
+    PALLOC(ms_p, n * M); PALLOC(ms_c, n * M); PALLOC(ms_state, n * M); PALLOC(ms_found, n * M * 2); PALLOC(ms_sin, n * M);
+    PALLOC(lut, n * C * P);
+    PALLOC(sl_info, n * M); PALLOC(sl_pt, n * M); PALLOC(sl_logical, n * M); PALLOC(sl_found, n * M * 2); PALLOC(sl_sin, n * M);
+    PALLOC(sl_cm, n * M * 3); PALLOC(sl_d, n * M * 4); PALLOC(sl_eps, n * M * 2);
+    PALLOC(pt_offF, n * (P + 1)); PALLOC(pt_offX, n * (P + 1)); PALLOC(pt_maskF, n * P); PALLOC(chF, n * (P + 2)); PALLOC(chX, n * (P + 2)); PALLOC(ch_n, n * 4);
+    PALLOC(S, n * F * F); PALLOC(E, n * F); PALLOC(cam_up, n * F);
+    PALLOC(scratch, n * M); PALLOC(outl, n * M * 2); PALLOC(free_cams, n * C); PALLOC(id_view, n * C); PALLOC(id_point, n * P);
+    PALLOC(work, n * b.work_slots); PALLOC(work_n, (size_t)2 * b.work_slots);   /* work_n[work_slots + slot]: the launch's draw counter */ PALLOC(view_of_kf, n * BA_MAX_KF);
+    b.lstat = nullptr;
+    if (lstat_records) PALLOC(lstat, lstat_records * BA_LSTAT_N);
+    b.o_of_logical = nullptr; b.o_obj = b.o_v9 = b.o_u27 = b.o_W = b.o_Y = b.o_ve = b.o_up = nullptr;
+    if (ordered) {
+      PALLOC(o_of_logical, n * M); PALLOC(o_obj, n * M); PALLOC(o_v9, n * M * 9); PALLOC(o_u27, n * M * 27); PALLOC(o_W, n * M * 18); PALLOC(o_Y, n * M * 18);
+      PALLOC(o_ve, n * P * 3); PALLOC(o_up, n * P * 3);
+    }
+  };
+  PoolArena a = {nullptr, 0};
+  carve(a);                                                           // sizes only
+  const size_t bytes = a.off + 256;
+  void* ptr = nullptr;
+  HIPCHK(hipMalloc(&ptr, bytes));
+  allocs.push_back(ptr);
+  HIPCHK(hipMemsetAsync(ptr, 0, bytes, st));
+  a.base = (char*)ptr; a.off = 0;
+  carve(a);
   return VSLAM_OK;
 }
+#undef PALLOC
 
 static BaConfig make_cfg(const TrackParams& tp) {
   BaConfig c; c.cam = tp.cam; c.max_iterations = tp.ba_max_iterations; c.convergence_limit = tp.ba_convergence_limit; c.min_sigma2 = tp.ba_min_sigma2;
@@ -189,6 +202,9 @@ struct vslam_bundle {
   BaPool pool; std::vector<void*> allocs; hipStream_t stream; BaConfig cfg; TrackParams tp;
   std::vector<HostProblem> host; bool uploaded;
   hipEvent_t ev[2] = {nullptr, nullptr};      // around the last Bundle::Compute launch (vslam_bundle_get_timing)
+  // Compute() overwrites cameras, points and results; a second Compute() of the same problems restores them from these device-side
+  // copies of what the caller added instead of staging everything from the host again (dirty: the host side has changed since)
+  bool dirty = true; BaResult* res0 = nullptr; Pose* cam0 = nullptr; double* pt0 = nullptr;
 };
 
 
@@ -205,9 +221,15 @@ extern "C" int vslam_bundle_create(const vslam_params* p, int n_problems, int ma
   HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
   trk_fill_params(*p, b->tp);
   b->cfg = make_cfg(b->tp);
-  int r = pool_create(b->pool, b->allocs, b->stream, n_problems, max_cameras, max_points, max_meas, 1, b->cfg.sum_order != 0);
-  if (!r) r = pool_alloc(b->allocs, b->stream, &b->pool.lstat, (size_t)BA_LSTAT_N);          // one launch record (vslam_bundle_get_timing)
+  int r = pool_create(b->pool, b->allocs, b->stream, n_problems, max_cameras, max_points, max_meas, 1, b->cfg.sum_order != 0, 1);   // one launch record (vslam_bundle_get_timing)
   if (!r && (hipEventCreate(&b->ev[0]) != hipSuccess || hipEventCreate(&b->ev[1]) != hipSuccess)) { vslam_set_error("bundle_create: hipEventCreate failed"); r = VSLAM_E_HIP; }
+  if (!r) {
+    void* q = nullptr;
+    if (hipMalloc(&q, sizeof(BaResult) * n_problems + 64) == hipSuccess) { b->res0 = (BaResult*)q; b->allocs.push_back(q); } else r = VSLAM_E_HIP;
+    if (!r && hipMalloc(&q, sizeof(Pose) * (size_t)n_problems * max_cameras + 64) == hipSuccess) { b->cam0 = (Pose*)q; b->allocs.push_back(q); } else if (!r) r = VSLAM_E_HIP;
+    if (!r && hipMalloc(&q, sizeof(double) * 3 * (size_t)n_problems * max_points + 64) == hipSuccess) { b->pt0 = (double*)q; b->allocs.push_back(q); } else if (!r) r = VSLAM_E_HIP;
+    if (r) vslam_set_error("bundle_create: hipMalloc failed");
+  }
   if (r) { vslam_bundle_destroy(b); return r; }
   b->host.resize(n_problems);
   HIPCHK(hipStreamSynchronize(b->stream));
@@ -233,6 +255,7 @@ extern "C" int vslam_bundle_add_camera(vslam_bundle* b, int n, const double pose
   if ((int)h.cams.size() >= b->pool.max_cams) { vslam_set_error("bundle: camera capacity"); return VSLAM_E_CAPACITY; }
   Pose p; for (int i = 0; i < 9; i++) p.R[i] = pose12[i]; for (int i = 0; i < 3; i++) p.t[i] = pose12[9 + i];
   h.cams.push_back(p); h.fixed.push_back(fixed ? 1 : 0);
+  b->dirty = true;
   return (int)h.cams.size() - 1;
 }
 
@@ -243,6 +266,7 @@ extern "C" int vslam_bundle_add_point(vslam_bundle* b, int n, const double pos[3
   double q[3] = {pos[0], pos[1], pos[2]};
   if (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] != q[0] * q[0] + q[1] * q[1] + q[2] * q[2]) q[0] = q[1] = q[2] = 0;   // NaN guard, jni/Bundle.cc:93-96
   h.pts.insert(h.pts.end(), q, q + 3);
+  b->dirty = true;
   return (int)h.pts.size() / 3 - 1;
 }
 
@@ -253,6 +277,7 @@ extern "C" int vslam_bundle_add_meas(vslam_bundle* b, int n, int cam, int point,
   if ((int)h.mp.size() >= b->pool.max_meas) { vslam_set_error("bundle: measurement capacity"); return VSLAM_E_CAPACITY; }
   h.mp.push_back(point); h.mc.push_back(cam); h.mfound.push_back(pos[0]); h.mfound.push_back(pos[1]);
   h.msin.push_back(sqrt(1.0 / sigma_squared));   // :115
+  b->dirty = true;
   return VSLAM_OK;
 }
 
@@ -265,6 +290,7 @@ extern "C" int vslam_bundle_set_problem(vslam_bundle* b, int n, int n_cams, cons
   if (n_cams > b->pool.max_cams || n_pts > b->pool.max_pts || n_meas > b->pool.max_meas) { vslam_set_error("bundle: set_problem exceeds the capacity"); return VSLAM_E_CAPACITY; }
   HostProblem& h = b->host[n];
   h = HostProblem();
+  b->dirty = true;
   for (int c = 0; c < n_cams; c++) { Pose p; for (int i = 0; i < 9; i++) p.R[i] = pose12[12 * c + i]; for (int i = 0; i < 3; i++) p.t[i] = pose12[12 * c + 9 + i]; h.cams.push_back(p); h.fixed.push_back(fixed[c] ? 1 : 0); }
   for (int i = 0; i < n_pts; i++) {
     double q[3] = {pos3[3 * i], pos3[3 * i + 1], pos3[3 * i + 2]};
@@ -282,43 +308,49 @@ extern "C" int vslam_bundle_set_problem(vslam_bundle* b, int n, int n_cams, cons
 extern "C" int vslam_bundle_compute(vslam_bundle* b) {
   BCHECK(b, "null");
   const BaPool& P = b->pool;
-  // the problems as the caller built them, staged per array for all problems and uploaded with one copy per array (Compute leaves
-  // its result in the cameras and points, so every call starts again from the caller's values)
   const size_t N = P.N, C = P.max_cams, PP = P.max_pts, M = P.max_meas;
-  std::vector<BaResult> res(N);
-  std::vector<Pose> cams(N * C); std::vector<int> fixed(N * C, 0);
-  std::vector<double> pts(N * PP * 3, 0.0), found(N * M * 2, 0.0), msin(N * M, 0.0);
-  std::vector<int> mp(N * M, 0), mc(N * M, 0), lut(N * C * PP, -1), nmeas(N * PP, 0);
-  for (size_t n = 0; n < N; n++) {
-    const HostProblem& h = b->host[n];
-    BaResult r; memset(&r, 0, sizeof(r));
-    r.n_cams = (int)h.cams.size(); r.n_pts = (int)h.pts.size() / 3; r.n_meas = (int)h.mp.size();
-    r.active = r.n_cams > 0 && r.n_pts > 0 && r.n_meas > 0;
-    res[n] = r;
-    for (int c = 0; c < r.n_cams; c++) { cams[n * C + c] = h.cams[c]; fixed[n * C + c] = h.fixed[c]; }
-    for (int i = 0; i < 3 * r.n_pts; i++) pts[n * PP * 3 + i] = h.pts[i];
-    for (int i = 0; i < r.n_meas; i++) {
-      mp[n * M + i] = h.mp[i]; mc[n * M + i] = h.mc[i]; msin[n * M + i] = h.msin[i];
-      found[n * M * 2 + i] = h.mfound[2 * i]; found[n * M * 2 + M + i] = h.mfound[2 * i + 1];      // component-major on device (ba_device.h MS())
-      lut[n * C * PP + (size_t)h.mc[i] * PP + h.mp[i]] = i; nmeas[n * PP + h.mp[i]]++;              // GenerateMeasLUTs
+  if (b->dirty) {
+    // the problems as the caller built them, staged per array for all problems and uploaded with one copy per array
+    std::vector<BaResult> res(N);
+    std::vector<Pose> cams(N * C); std::vector<int> fixed(N * C, 0);
+    std::vector<double> pts(N * PP * 3, 0.0), found(N * M * 2, 0.0), msin(N * M, 0.0);
+    std::vector<int> mp(N * M, 0), mc(N * M, 0), lut(N * C * PP, -1), nmeas(N * PP, 0);
+    for (size_t n = 0; n < N; n++) {
+      const HostProblem& h = b->host[n];
+      BaResult r; memset(&r, 0, sizeof(r));
+      r.n_cams = (int)h.cams.size(); r.n_pts = (int)h.pts.size() / 3; r.n_meas = (int)h.mp.size();
+      r.active = r.n_cams > 0 && r.n_pts > 0 && r.n_meas > 0;
+      res[n] = r;
+      for (int c = 0; c < r.n_cams; c++) { cams[n * C + c] = h.cams[c]; fixed[n * C + c] = h.fixed[c]; }
+      for (int i = 0; i < 3 * r.n_pts; i++) pts[n * PP * 3 + i] = h.pts[i];
+      for (int i = 0; i < r.n_meas; i++) {
+        mp[n * M + i] = h.mp[i]; mc[n * M + i] = h.mc[i]; msin[n * M + i] = h.msin[i];
+        found[n * M * 2 + i] = h.mfound[2 * i]; found[n * M * 2 + M + i] = h.mfound[2 * i + 1];      // component-major on device (ba_device.h MS())
+        lut[n * C * PP + (size_t)h.mc[i] * PP + h.mp[i]] = i; nmeas[n * PP + h.mp[i]]++;              // GenerateMeasLUTs
+      }
     }
+    HIPCHK(hipMemcpyAsync(b->res0, res.data(), sizeof(BaResult) * N, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->cam0, cams.data(), sizeof(Pose) * N * C, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->pt0, pts.data(), sizeof(double) * N * PP * 3, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(P.cam_fixed, fixed.data(), sizeof(int) * N * C, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(P.ms_p, mp.data(), sizeof(int) * N * M, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(P.ms_c, mc.data(), sizeof(int) * N * M, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(P.ms_found, found.data(), sizeof(double) * N * M * 2, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(P.ms_sin, msin.data(), sizeof(double) * N * M, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(P.lut, lut.data(), sizeof(int) * N * C * PP, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(P.pt_nmeas, nmeas.data(), sizeof(int) * N * PP, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));           // the staging vectors go out of scope
+    b->dirty = false;
   }
-  HIPCHK(hipMemcpyAsync(P.res, res.data(), sizeof(BaResult) * N, hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(P.cam_pose, cams.data(), sizeof(Pose) * N * C, hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(P.cam_fixed, fixed.data(), sizeof(int) * N * C, hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(P.pt_pos, pts.data(), sizeof(double) * N * PP * 3, hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(P.ms_p, mp.data(), sizeof(int) * N * M, hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(P.ms_c, mc.data(), sizeof(int) * N * M, hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(P.ms_found, found.data(), sizeof(double) * N * M * 2, hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(P.ms_sin, msin.data(), sizeof(double) * N * M, hipMemcpyHostToDevice, b->stream));
+  // Compute leaves its result in the cameras and points: every call starts again from the caller's values (device-to-device)
+  HIPCHK(hipMemcpyAsync(P.res, b->res0, sizeof(BaResult) * N, hipMemcpyDeviceToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(P.cam_pose, b->cam0, sizeof(Pose) * N * C, hipMemcpyDeviceToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(P.pt_pos, b->pt0, sizeof(double) * N * PP * 3, hipMemcpyDeviceToDevice, b->stream));
   HIPCHK(hipMemsetAsync(P.ms_state, 0, sizeof(int) * N * M, b->stream));
   HIPCHK(hipMemsetAsync(P.pt_nout, 0, sizeof(int) * N * PP, b->stream));
-  HIPCHK(hipMemcpyAsync(P.lut, lut.data(), sizeof(int) * N * C * PP, hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(P.pt_nmeas, nmeas.data(), sizeof(int) * N * PP, hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipMemsetAsync(P.lstat, 0, sizeof(unsigned long long) * BA_LSTAT_N, b->stream));
-  HIPCHK(hipStreamSynchronize(b->stream));             // the staging vectors go out of scope; the inputs are resident before the timed launch
   b->uploaded = true;
-  HIPCHK(hipEventRecord(b->ev[0], b->stream));
+  HIPCHK(hipEventRecord(b->ev[0], b->stream));         // everything Compute reads is resident
   ba_launch_compute(b->pool, b->cfg, P.N, b->stream, -1, 0);
   HIPCHK(hipEventRecord(b->ev[1], b->stream));
   HIPCHK(hipGetLastError());
@@ -735,9 +767,7 @@ int ba_alloc(vslam_system* sys) {
   // worst case of BundleAdjust: every keyframe a camera, every point, every (kf, point) slot a measurement
   size_t M = (size_t)K * P;
   if (M > 65536) M = 65536;
-  int r = pool_create(ws->pool, sys->allocs, sys->stream, sys->S, K, P, (int)M, sys->p.ba_delay_frames > 0 ? sys->p.ba_delay_frames + 2 : 1, sys->p.ba_sum_order != 0);
-  if (r) return r;
-  r = pool_alloc(sys->allocs, sys->stream, &ws->pool.lstat, (size_t)BA_LSTAT_RING * BA_LSTAT_N);
+  int r = pool_create(ws->pool, sys->allocs, sys->stream, sys->S, K, P, (int)M, sys->p.ba_delay_frames > 0 ? sys->p.ba_delay_frames + 2 : 1, sys->p.ba_sum_order != 0, BA_LSTAT_RING);
   if (r) return r;
   // One launch of the full synchronous grid over the still empty pool (every problem inactive: the workgroups return at once).
   // k_ba_compute needs scratch memory, and the runtime sizes that lazily, at the first launch of a grid this large: paid here,

@@ -329,6 +329,9 @@ DEVFN bool ba_block_solve_lds(const double* S, double* E, int n, double* A, int*
 // back-substitution sums in ascending column order like lu_solve_n.  Every index is a compile-time constant after
 // unrolling.  Called by wavefront 0 only; returns false if singular.  Writes the solution to E.
 #define BA_WSOLVE_N 30
+#ifndef VSLAM_BA_WSOLVE
+#define VSLAM_BA_WSOLVE 1   // measured (tools/ba_phase_profile*.py, 512 problems): 30 x 30 solve 116 kcycles by one wavefront in registers, 160 by the workgroup in LDS; 24 x 24: 103 / 108
+#endif
 DEVFN double ba_readlane_d(double v, int l) {
   const unsigned long long b = (unsigned long long)__double_as_longlong(v);
   const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
@@ -1260,7 +1263,7 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
       __syncthreads();
       BA_STAMP(7);
       bool solved = true;
-      if (nS > 0 && nS <= BA_WSOLVE_N) {                              // one wavefront, registers (the BundleAdjustRecent size)
+      if (nS > 0 && nS <= BA_WSOLVE_N && VSLAM_BA_WSOLVE) {           // one wavefront, registers (the BundleAdjustRecent size)
         if (wave == 0) { const bool okw = ba_solve_wave(v_, nS); if (lane == 0) ired[0] = okw ? 1 : 0; }
         __syncthreads();
         solved = ired[0] != 0;
