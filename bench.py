@@ -362,19 +362,27 @@ def main():
     seeds = [1234 + rank * S + s for s in range(S)]
     with ThreadPoolExecutor(nthreads) as ex:
         feeders = list(ex.map(lambda sd: feeder.Feeder(W, H, seed=sd), seeds))
-    fe = capi.System(capi.default_params(W, H, 1, patch_size=args.patch, device=local_rank))   # front-end used to pick map corners
-
-    fe_lock = threading.Lock()
-
-    def corner_fn(gray):
-        with fe_lock:                          # one front-end system; the renders and the numpy of build_map run in parallel
-            fe.make_keyframe_lite(gray[None])
-            fe.fast_nonmax()
-            return [fe.read_max_corners(0, l)[0] for l in range(4)]
-
+    # The maps' source keyframes: rendered per stream (host threads), their maximal FAST corners from the device front end in batches of
+    # FB images per call (3 + 2 launches per batch: a per-image front end was ~16,000 set-up launches for 2048 streams, which a
+    # profiler pass with counters serialises one by one -- VERDICT r2 weak #11), the maps built from them on the host.
+    NKF = 8
     with ThreadPoolExecutor(nthreads) as ex:
-        maps = list(ex.map(lambda f: feeder.build_map(f, corner_fn, **map_kw), feeders))
+        kf_images = list(ex.map(lambda f: feeder.keyframe_images(f, n_keyframes=NKF), feeders))
+    FB = min(256, S * NKF)
+    fe = capi.System(capi.default_params(W, H, FB, patch_size=args.patch, device=local_rank))
+    flat_imgs = [im for ims in kf_images for im in ims]
+    kf_corners = []
+    for b0 in range(0, len(flat_imgs), FB):
+        chunk = flat_imgs[b0:b0 + FB]
+        batch = np.stack(chunk + [chunk[-1]] * (FB - len(chunk)))
+        fe.make_keyframe_lite(batch)
+        fe.fast_nonmax()
+        for i in range(len(chunk)):
+            kf_corners.append([fe.read_max_corners(i, l)[0] for l in range(4)])
     fe.close()
+    with ThreadPoolExecutor(nthreads) as ex:
+        maps = list(ex.map(lambda s_: feeder.build_map(feeders[s_], None, n_keyframes=NKF, images=kf_images[s_], corners=kf_corners[s_ * NKF:(s_ + 1) * NKF], **map_kw), range(S)))
+    del flat_imgs, kf_corners
     NS = max(1, min(args.systems, S))
     assert S % NS == 0, "--streams must be a multiple of --systems"
     Sk = S // NS
@@ -403,24 +411,26 @@ def main():
         if stagger:                            # Tracker::mnLastKeyFrameDropped: stream s asks for its first keyframe in frame 1 + phase
             sy.set_last_keyframe_dropped(ls, -20 + (s * stagger) // S)
     host_mode = bool(args.host_frames)
-    frames_dev = torch.empty((T, S, H, W), dtype=torch.uint8, device="cpu" if host_mode else "cuda", pin_memory=host_mode)
+    # frame ring, stream-major ([S][T][H][W]: a stream's T frames are one contiguous upload, not T strided pieces)
+    frames_dev = torch.empty((S, T, H, W), dtype=torch.uint8, device="cpu" if host_mode else "cuda", pin_memory=host_mode)
     host_frames0 = None
     with ThreadPoolExecutor(max(1, nthreads // 4)) as ex:
         for s, fr in enumerate(ex.map(lambda f: f.render(0, T, threads=4), feeders)):
-            frames_dev[:, s].copy_(torch.from_numpy(fr))
+            frames_dev[s].copy_(torch.from_numpy(fr))
             if s == 0:
                 host_frames0 = fr
     torch.cuda.synchronize()
     setup_s = time.time() - t_setup
     base = frames_dev.data_ptr()
-    fstride = S * H * W
+    fstride = H * W                             # frame t of stream s at base + (s * T + t) * H * W
+    sstride = T * H * W
 
     def step(t):
         for k, sy in enumerate(systems):
             if host_mode:                       # native_update: host gray image in, synchronous (the caller may reuse its buffer)
-                capi._check(sy.lib.vslam_update(sy.h, base + t * fstride + k * Sk * H * W, W, H * W))
+                capi._check(sy.lib.vslam_update(sy.h, base + t * fstride + k * Sk * sstride, W, sstride))
             else:
-                sy.track_frame_device(base + t * fstride + k * Sk * H * W, W, H * W)
+                sy.track_frame_device(base + t * fstride + k * Sk * sstride, W, sstride)
 
     def sync_all():
         for sy in systems:
@@ -430,6 +440,12 @@ def main():
         sy, ls = sys_of(s)
         return sy.state(ls)
 
+    def all_states():                           # one copy per system: polling 2048 streams one by one idles the GPU for ~50 ms, long
+        out = []                                # enough for its clocks to drop before the timed region starts
+        for sy in systems:
+            out.extend(sy.states())
+        return out
+
     def note(msg):                              # progress on stderr: a long run must not look hung to the box's watchdog
         if rank == 0:
             print("[bench] %s (%.0f s)" % (msg, time.perf_counter() - t_prog), file=sys.stderr, flush=True)
@@ -438,7 +454,7 @@ def main():
     for t in range(Wm):
         step(t)
     sync_all()
-    st0 = [state(s) for s in range(S)]
+    st0 = all_states()
     if not args.no_events:
         for sy in systems:
             sy.profile_begin(K)
@@ -466,7 +482,11 @@ def main():
                 stage_n[k_] = stage_n.get(k_, 0) + cnt[k_]
             for k_, v_ in sy.profile_ba_stats().items():
                 ba_st[k_] = ba_st.get(k_, 0) + v_
-    st1 = [state(s) for s in range(S)]
+    st1 = all_states()
+    ba_totals = {}                              # every k_ba_compute launch of the process (for profiler passes: their counters cover the whole run)
+    for sy in systems:
+        for k_, v_ in sy.ba_launch_totals().items():
+            ba_totals[k_] = ba_totals.get(k_, 0) + v_
 
     # ---- per-stream workload statistics (for the algorithmic-byte formulas) ---------------------------------------------
     zm = float(np.mean([(b.n_zmssd - a.n_zmssd) / K for a, b in zip(st0, st1)]))
@@ -640,6 +660,7 @@ def main():
                        "patches_attempted_per_frame": round(att, 1), "patches_found_per_frame": round(fnd, 1),
                        "zmssd_evals_per_frame": round(zm, 1), "keyframes_per_step": round(kf_adds * S / K, 2),
                        "keyframes_added_per_stream": round(kf_adds, 3), "ba_trials_per_stream": round(ba_trials, 3),
+                       "map_points_per_stream": round(float(np.mean([b.n_points for b in st1])), 1),
                        "streams_tracking_good": good, "setup_seconds": round(setup_s, 1),
                        "host_enqueue_ms_per_step": round(1e3 * enqueue_s / K, 3)},
             "roofline": roof,
@@ -652,6 +673,7 @@ def main():
             "scaling_efficiency_vs_n1": (round(value / (world * args.n1_value), 4) if args.n1_value else None),
             "pcie_inclusive": ({"frames_per_s": round(value, 2), "host_GBps": round(value * W * H / 1e9, 2),
                                 "note": "--host-frames: every step uploads S frames from pinned host memory inside vslam_update (synchronous, like native_update); this line is NOT the headline value"} if host_mode else None),
+            "ba_launch_totals_whole_run": ba_totals, "frames_whole_run": T,
             "ba_flat_out": flat,
             "parity_pose_maxdiff_stream0": pose_diff,
         }

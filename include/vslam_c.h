@@ -172,6 +172,10 @@ int vslam_minipatch_find(vslam_system* sys, int stream, int n, const uint8_t* pa
  * Builds the keyframe's pyramid on device.  Returns the keyframe index (>= 0) or a negative error. */
 int vslam_map_add_keyframe(vslam_system* sys, int stream, const double pose12[12], int fixed, const uint8_t* gray,
                            size_t row_stride, double depth_mean, double depth_sigma);
+/* the same for n keyframes of the stream at once: pose12 n x 12, fixed n, gray n images image_stride bytes apart, depth_mean_sigma n x 2.
+ * Returns the index of the first one. */
+int vslam_map_add_keyframes(vslam_system* sys, int stream, int n, const double* pose12, const int* fixed, const uint8_t* gray, size_t row_stride,
+                            size_t image_stride, const double* depth_mean_sigma);
 /* MapPoint (jni/MapPoint.h:22-69). Returns the point index or a negative error. */
 int vslam_map_add_point(vslam_system* sys, int stream, const double pos[3], int src_keyframe, int src_level,
                         int ir_x, int ir_y, const double pixel_right_w[3], const double pixel_down_w[3]);
@@ -237,6 +241,8 @@ int vslam_update(vslam_system* sys, const uint8_t* gray, size_t row_stride, size
 int vslam_touch(vslam_system* sys);
 
 int vslam_get_state(vslam_system* sys, int stream, vslam_track_state* out);
+/* the same for the streams [first, first + n): out[n], one device-to-host copy */
+int vslam_get_states(vslam_system* sys, int first, int n, vslam_track_state* out);
 /* MapMaker::NeedNewKeyFrame (jni/MapMaker.cc:761-773: distance to the closest keyframe, scaled by the scene depth, against
  * max_kf_dist_wiggle_mult * mdWiggleScaleDepthNormalized) and MapMaker::IsDistanceToNearestKeyFrameExcessive (:1098-1101: > 10 * wiggle
  * scale) for the stream's current pose.  The tracker takes both decisions on device; these are the reference's public members. */
@@ -308,6 +314,8 @@ int vslam_profile_launches(vslam_system* sys, int* launches);
  * trial-weighted sums SURVEY.md 8(d)'s formulas need -- [2] trials x measurements, [3] trials x cameras, [4] trials x points,
  * [5] trials x points x C(adjustable cameras, 2), [6] trials x (6 x adjustable cameras)^3 -- [7] launches.  After vslam_profile_end. */
 int vslam_profile_ba_stats(vslam_system* sys, unsigned long long stats[8]);
+/* the same counters over every Bundle::Compute launch of the system since its creation (the last 1024); stats[7] = launches that ran a problem */
+int vslam_get_ba_launch_totals(vslam_system* sys, unsigned long long stats[8]);
 /* HIP-event time of the last host-driven vslam_bundle_adjust_recent / vslam_bundle_adjust_all on the system's stream:
  * ms[0] selection + assembly (k_ba_select, k_ba_assemble), ms[1] Bundle::Compute (k_ba_compute, one workgroup per stream's
  * problem), ms[2] write-back + HandleBadPoints; stats (may be NULL): the launch's counters as vslam_profile_ba_stats. Synchronises. */

@@ -74,6 +74,7 @@ SYMBOLS = {
     "vslam_minipatch_find": (_i, [_sys, _i, _i, _vp, _vp, _i, _i, _vp]),
     "vslam_add_keyframe": (_i, [_sys, _i]),
     "vslam_map_add_keyframe": (_i, [_sys, _i, _vp, _i, _vp, _sz, _d, _d]),
+    "vslam_map_add_keyframes": (_i, [_sys, _i, _i, _vp, _vp, _vp, _sz, _sz, _vp]),
     "vslam_map_add_point": (_i, [_sys, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "vslam_map_add_points": (_i, [_sys, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vslam_map_add_measurement": (_i, [_sys, _i, _i, _i, _i, _vp, _i, _i]),
@@ -91,6 +92,7 @@ SYMBOLS = {
     "vslam_map_set_keyframe_pose": (_i, [_sys, _i, _i, _vp]),
     "vslam_touch": (_i, [_sys]),
     "vslam_get_state": (_i, [_sys, _i, C.POINTER(TrackState)]),
+    "vslam_get_states": (_i, [_sys, _i, _i, _vp]),
     "vslam_get_message": (_i, [_sys, _i, C.c_char_p, _sz]),
     "vslam_need_new_keyframe": (_i, [_sys, _i, _ip]),
     "vslam_distance_to_nearest_keyframe_excessive": (_i, [_sys, _i, _ip]),
@@ -115,6 +117,7 @@ SYMBOLS = {
     "vslam_profile_end": (_i, [_sys, _vp, _ip]),
     "vslam_profile_launches": (_i, [_sys, _vp]),
     "vslam_profile_ba_stats": (_i, [_sys, _vp]),
+    "vslam_get_ba_launch_totals": (_i, [_sys, _vp]),
     "vslam_get_mapmaker_timing": (_i, [_sys, _vp, _vp]),
     "vslam_bundle_adjust_recent": (_i, [_sys]),
     "vslam_bundle_adjust_all": (_i, [_sys]),
@@ -316,8 +319,14 @@ class System:
 
     def load_map(self, stream, m):
         """m: dict from visualslam_android_amd.feeder.build_map"""
-        for k in m["keyframes"]:
-            self.add_keyframe(stream, k["pose"], k["fixed"], k["image"], k["depth_mean"], k["depth_sigma"])
+        kfs = m["keyframes"]
+        if kfs:                                  # all keyframes in one call: one pyramid launch per level
+            img = np.ascontiguousarray(np.stack([k["image"] for k in kfs]), np.uint8)
+            poses = np.ascontiguousarray(np.stack([np.asarray(k["pose"], np.float64) for k in kfs]))
+            fixed = np.array([1 if k["fixed"] else 0 for k in kfs], np.int32)
+            depth = np.array([[k["depth_mean"], k["depth_sigma"]] for k in kfs], np.float64)
+            _check(self.lib.vslam_map_add_keyframes(self.h, stream, len(kfs), poses.ctypes.data, fixed.ctypes.data, img.ctypes.data, img.shape[2],
+                                                    img.shape[1] * img.shape[2], depth.ctypes.data))
         pk = m.get("packed") if hasattr(m, "get") else None
         if pk is not None and "points" not in dict.keys(m) and "meas" not in dict.keys(m):   # untouched build_map output: no per-item Python
             pos, right, down = (np.ascontiguousarray(pk[k_], np.float64) for k_ in ("pos", "right", "down"))
@@ -378,6 +387,13 @@ class System:
 
     def set_keyframe_pose(self, stream, kf, pose12):
         _check(self.lib.vslam_map_set_keyframe_pose(self.h, stream, int(kf), _f64(pose12).ctypes.data))
+
+    def states(self, first=0, n=None):
+        """-> list of TrackState of the streams [first, first + n) with one copy (vslam_get_states)"""
+        n = self.params.n_streams - first if n is None else n
+        arr = (TrackState * n)()
+        _check(self.lib.vslam_get_states(self.h, first, n, C.cast(arr, C.c_void_p)))
+        return list(arr)
 
     def state(self, stream):
         s = TrackState()
@@ -525,6 +541,12 @@ class System:
         """-> what the k_ba_compute launches of the last profile window ran, counted on the device (vslam_profile_ba_stats)"""
         st = np.zeros(8, np.uint64)
         _check(self.lib.vslam_profile_ba_stats(self.h, st.ctypes.data))
+        return {k: int(v) for k, v in zip(self.BA_STAT_KEYS, st)}
+
+    def ba_launch_totals(self):
+        """-> the device counters of every k_ba_compute launch since the system was created, summed (vslam_get_ba_launch_totals)"""
+        st = np.zeros(8, np.uint64)
+        _check(self.lib.vslam_get_ba_launch_totals(self.h, st.ctypes.data))
         return {k: int(v) for k, v in zip(self.BA_STAT_KEYS, st)}
 
     def mapmaker_timing(self):

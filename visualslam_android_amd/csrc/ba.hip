@@ -985,6 +985,23 @@ extern "C" int vslam_profile_ba_stats(vslam_system* sys, unsigned long long stat
   return VSLAM_OK;
 }
 
+// every k_ba_compute launch of the system since its creation (the last BA_LSTAT_RING of them), summed: for profiler passes, whose
+// per-kernel counters cover the whole process and not a window
+extern "C" int vslam_get_ba_launch_totals(vslam_system* sys, unsigned long long stats[8]) {
+  if (!sys || !stats || !sys->ba_ws) { vslam_set_error("get_ba_launch_totals: bad argument"); return VSLAM_E_INVALID; }
+  HIPCHK(hipStreamSynchronize(sys->stream));
+  { int rs = ba_sync_streams(sys); if (rs) return rs; }
+  BaSystemWs* ws = (BaSystemWs*)sys->ba_ws;
+  const long n = sys->ba_launch_no < BA_LSTAT_RING ? sys->ba_launch_no : BA_LSTAT_RING;
+  std::vector<unsigned long long> all((size_t)BA_LSTAT_RING * BA_LSTAT_N);
+  HIPCHK(hipMemcpy(all.data(), ws->pool.lstat, sizeof(unsigned long long) * all.size(), hipMemcpyDeviceToHost));
+  for (int k = 0; k < BA_LSTAT_N; k++) stats[k] = 0;
+  long working = 0;
+  for (long i = 0; i < n; i++) { for (int k = 0; k < 7; k++) stats[k] += all[(size_t)i * BA_LSTAT_N + k]; if (all[(size_t)i * BA_LSTAT_N]) working++; }
+  stats[7] = (unsigned long long)working;               // launches that ran at least one problem
+  return VSLAM_OK;
+}
+
 extern "C" int vslam_get_mapmaker_timing(vslam_system* sys, double ms[3], unsigned long long stats[8]) {
   if (!sys || !ms || !sys->ba_ws) { vslam_set_error("get_mapmaker_timing: bad argument"); return VSLAM_E_INVALID; }
   if (sys->mm_lrec < 0 || !sys->ev_mm[0]) { vslam_set_error("get_mapmaker_timing: no vslam_bundle_adjust_recent / _all call yet"); return VSLAM_E_STATE; }

@@ -56,6 +56,54 @@ extern "C" int vslam_map_add_keyframe(vslam_system* sys, int s, const double pos
   return k;
 }
 
+// the same level for n images at once (blockIdx.z = image; images sstride / dstride bytes apart)
+__global__ void k_halve_batch(const uint8_t* src, int sp, size_t sstride, uint8_t* dst, int dp, size_t dstride, int dw, int dh) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= dw || y >= dh) return;
+  const uint8_t* r0 = src + (size_t)blockIdx.z * sstride + (size_t)(2 * y) * sp + 2 * x;
+  const uint8_t* r1 = r0 + sp;
+  dst[(size_t)blockIdx.z * dstride + (size_t)y * dp + x] = (uint8_t)((r0[0] + r0[1] + r1[0] + r1[1] + 2) >> 2);
+}
+
+// vslam_map_add_keyframe for n keyframes of one stream at once: one pyramid launch per level and one clear of the measurement rows for
+// all of them (a map upload of eight keyframes is 4 kernel launches instead of 32: set-up of thousands of streams, and profiler passes
+// that serialise every dispatch).  gray: n images image_stride bytes apart.  Returns the index of the first new keyframe.
+extern "C" int vslam_map_add_keyframes(vslam_system* sys, int s, int n, const double* pose12, const int* fixed, const uint8_t* gray, size_t row_stride,
+                                       size_t image_stride, const double* depth_mean_sigma) {
+  CHK_STREAM(sys, s);
+  if (n < 1 || !pose12 || !fixed || !gray || !depth_mean_sigma || (int)row_stride < sys->geom[0].w) { vslam_set_error("map_add_keyframes: bad argument"); return VSLAM_E_INVALID; }
+  if (sys->p.grow_map || sys->p.idle_iterations != 0) {                 // keyframe corner lists are made one keyframe at a time
+    int first = -1;
+    for (int i = 0; i < n; i++) {
+      const int k = vslam_map_add_keyframe(sys, s, pose12 + 12 * i, fixed[i], gray + (size_t)i * image_stride, row_stride, depth_mean_sigma[2 * i], depth_mean_sigma[2 * i + 1]);
+      if (k < 0) return k;
+      if (i == 0) first = k;
+    }
+    return first;
+  }
+  TrackerState st;
+  int r = get_state(sys, s, &st); if (r) return r;
+  const int K = sys->p.max_keyframes;
+  if (st.n_kf + n > K) { vslam_set_error("keyframe capacity %d reached", K); return VSLAM_E_CAPACITY; }
+  const int k = st.n_kf;
+  const LevelGeom* g = sys->geom;
+  uint8_t* lvl[NLEV]; size_t ls[NLEV];
+  for (int l = 0; l < NLEV; l++) { ls[l] = (size_t)g[l].pitch * g[l].h; lvl[l] = sys->map.kf_img[l] + ((size_t)s * K + k) * ls[l]; }
+  for (int i = 0; i < n; i++)
+    HIPCHK(hipMemcpy2DAsync(lvl[0] + (size_t)i * ls[0], g[0].pitch, gray + (size_t)i * image_stride, row_stride, g[0].w, g[0].h, hipMemcpyHostToDevice, sys->stream));
+  for (int l = 1; l < NLEV; l++)
+    hipLaunchKernelGGL(k_halve_batch, dim3((g[l].w + 255) / 256, g[l].h, n), dim3(256), 0, sys->stream, lvl[l - 1], g[l - 1].pitch, ls[l - 1], lvl[l], g[l].pitch, ls[l], g[l].w, g[l].h);
+  std::vector<Pose> p((size_t)n); std::vector<int> fx((size_t)n);
+  for (int i = 0; i < n; i++) { for (int q = 0; q < 9; q++) p[i].R[q] = pose12[12 * i + q]; for (int q = 0; q < 3; q++) p[i].t[q] = pose12[12 * i + 9 + q]; fx[i] = fixed[i] ? 1 : 0; }
+  HIPCHK(hipMemcpyAsync(sys->map.kf_pose + (size_t)s * K + k, p.data(), sizeof(Pose) * n, hipMemcpyHostToDevice, sys->stream));
+  HIPCHK(hipMemcpyAsync(sys->map.kf_fixed + (size_t)s * K + k, fx.data(), sizeof(int) * n, hipMemcpyHostToDevice, sys->stream));
+  HIPCHK(hipMemcpyAsync(sys->map.kf_depth + ((size_t)s * K + k) * 2, depth_mean_sigma, sizeof(double) * 2 * n, hipMemcpyHostToDevice, sys->stream));
+  HIPCHK(hipMemsetAsync(sys->map.kf_meas + ((size_t)s * K + k) * sys->p.max_points, 0, sizeof(MeasDev) * sys->p.max_points * (size_t)n, sys->stream));
+  st.n_kf = k + n;
+  r = put_state(sys, s, &st); if (r) return r;         // (synchronises: the host arrays above are done with)
+  return k;
+}
+
 extern "C" int vslam_map_add_point(vslam_system* sys, int s, const double pos[3], int src_keyframe, int src_level, int ir_x,
                                    int ir_y, const double right[3], const double down[3]) {
   CHK_STREAM(sys, s);
@@ -366,11 +414,30 @@ extern "C" int vslam_bundle_adjust_recent(vslam_system* sys) { if (!sys) return 
 extern "C" int vslam_bundle_adjust_all(vslam_system* sys) { if (!sys) return VSLAM_E_INVALID; return ba_run(sys, 2); }
 
 // ---- read-back ------------------------------------------------------------------------------------------------------
+static void export_state(const vslam_system* sys, const TrackerState& st, vslam_track_state* o);
+
 extern "C" int vslam_get_state(vslam_system* sys, int s, vslam_track_state* o) {
   CHK_STREAM(sys, s);
   if (!o) return VSLAM_E_INVALID;
   TrackerState st;
   int r = get_state(sys, s, &st); if (r) return r;
+  export_state(sys, st, o);
+  return VSLAM_OK;
+}
+
+// vslam_get_state for the streams [first, first + n) with one copy (a caller that polls thousands of streams one by one idles the GPU
+// for tens of milliseconds, long enough for its clocks to drop)
+extern "C" int vslam_get_states(vslam_system* sys, int first, int n, vslam_track_state* out) {
+  if (!sys || !out || first < 0 || n < 0 || first + n > sys->S) { vslam_set_error("get_states: bad argument"); return VSLAM_E_INVALID; }
+  if (n == 0) return VSLAM_OK;
+  std::vector<TrackerState> v((size_t)n);
+  HIPCHK(hipMemcpyAsync(v.data(), sys->map.st + first, sizeof(TrackerState) * n, hipMemcpyDeviceToHost, sys->stream));
+  HIPCHK(hipStreamSynchronize(sys->stream));
+  for (int i = 0; i < n; i++) export_state(sys, v[(size_t)i], out + i);
+  return VSLAM_OK;
+}
+
+static void export_state(const vslam_system* sys, const TrackerState& st, vslam_track_state* o) {
   const Pose& T = sys->frame_open ? st.pose_cur : st.pose_final;   // between the stages of a frame: the tracker's current estimate
   for (int i = 0; i < 9; i++) o->pose[i] = T.R[i];
   for (int i = 0; i < 3; i++) o->pose[9 + i] = T.t[i];
@@ -380,7 +447,6 @@ extern "C" int vslam_get_state(vslam_system* sys, int s, vslam_track_state* o) {
   o->quality = st.quality; o->lost_frames = st.lost_frames; o->frame = st.frame; o->did_coarse = st.did_coarse;
   o->kf_added = st.kf_added; o->n_keyframes = st.n_kf; o->n_points = st.n_points; o->ba_accepted = st.ba_accepted;
   o->n_zmssd = (long long)st.n_zmssd; o->n_ba_trials = (long long)st.n_ba_trials;
-  return VSLAM_OK;
 }
 
 // counters of the map-maker's idle jobs (vslam_params.idle_iterations): points re-found by ReFindNewlyMade and by

@@ -120,8 +120,15 @@ def _project_np(cam, w, h, x, y):
     return cx + fx * x * fac, cy + fy * y * fac
 
 
+def keyframe_images(feeder, n_keyframes=8, kf_spacing=20):
+    """The images of build_map's source keyframes (frames -spacing*n .. -spacing): lets a caller extract the corners of many maps'
+    keyframes in one batched front-end call and hand them to build_map (corners=)."""
+    times = [-kf_spacing * (n_keyframes - k) for k in range(n_keyframes)]
+    return [feeder.render_pose(feeder.pose(t), key=1000 + k) for k, t in enumerate(times)]
+
+
 def build_map(feeder, corner_fn, n_keyframes=8, kf_spacing=20, per_level=(260, 90, 32, 12), patch_border=10,
-              point_noise=0.0, pose_noise=(0.0, 0.0), seed=7, cam=REF_CAM):
+              point_noise=0.0, pose_noise=(0.0, 0.0), seed=7, cam=REF_CAM, images=None, corners=None):
     """Ground-truth initial map from `n_keyframes` source keyframes at frames -spacing*n .. -spacing.
 
     corner_fn(gray) -> list of 4 arrays of packed (x | y<<16) maximal FAST corners per level (from the HIP
@@ -142,18 +149,18 @@ def build_map(feeder, corner_fn, n_keyframes=8, kf_spacing=20, per_level=(260, 9
     Rs = [p[:9].reshape(3, 3) for p in poses]
     ts = [p[9:] for p in poses]
     for k in range(n_keyframes):
-        img = feeder.render_pose(poses[k], key=1000 + k)
+        img = images[k] if images is not None else feeder.render_pose(poses[k], key=1000 + k)
         kfs.append({"pose": poses[k].copy(), "fixed": k == 0, "image": img, "depth_mean": 1.0, "depth_sigma": 0.1})
     depth_acc = [[] for _ in range(n_keyframes)]
     n_points = 0
     P = {k_: [] for k_ in ("pos", "right", "down", "src_kf", "level", "ir")}
     M = {k_: [] for k_ in ("kf", "pt", "level", "root", "subpix", "source")}
     for k in range(n_keyframes):
-        corners = corner_fn(kfs[k]["image"])
+        corners_k = corners[k] if corners is not None else corner_fn(kfs[k]["image"])
         R, t = Rs[k], ts[k]
         C = -R.T @ t
         for level in range(4):
-            c = np.asarray(corners[level], np.uint32)
+            c = np.asarray(corners_k[level], np.uint32)
             if len(c) == 0:
                 continue
             xs = (c & 0xFFFF).astype(np.int64)
