@@ -1,18 +1,19 @@
 #!/bin/bash
 # Regenerates the per-round profile set of profiles/README.md on a GPU box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh r02
+#   bash tools/collect_profiles.sh r03 [steps]
 # Writes gpurun_out/<tag>_bench_default.json, <tag>_bench_under_rocprof.json, <tag>_bench_kernel_stats.csv, <tag>_bench_kernel_stats_batched.csv,
 # <tag>_timeline.txt; copy the ones to be judged into profiles/.  PMC counters: tools/collect_pmc.sh (own passes, never together with --stats).
 set -e -o pipefail
 TAG=${1:-r01}
+STEPS=${2:-20}        # the driver's command: python bench.py --gpus 1 --steps 20 --warmup 5
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-python3 bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
+python3 bench.py --steps $STEPS --warmup 5 > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
 echo "bench done"
 rm -rf /tmp/prof1
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof1 -o $TAG -- python3 bench.py --no-all-cores --cpu-seconds 3 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_rp1.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof1 -o $TAG -- python3 bench.py --steps $STEPS --warmup 5 --cpu-seconds 3 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_rp1.err
 cp "$(find /tmp/prof1 -name '*kernel_stats.csv' | head -1)" $OUT/${TAG}_bench_kernel_stats.csv
 python3 tools/trace_summary.py --min-grid 60000 "$(find /tmp/prof1 -name '*kernel_trace.csv' | head -1)" > $OUT/${TAG}_bench_kernel_stats_batched.csv
-python3 tools/timeline.py "$(find /tmp/prof1 -name '*kernel_trace.csv' | head -1)" --steps 50 > $OUT/${TAG}_timeline.txt
+python3 tools/timeline.py "$(find /tmp/prof1 -name '*kernel_trace.csv' | head -1)" --steps $STEPS > $OUT/${TAG}_timeline.txt
 echo "kernel trace done"

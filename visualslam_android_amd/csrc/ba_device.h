@@ -41,7 +41,9 @@
 // 4 waves; with amdgpu_waves_per_eu(2,2) on the kernel two problems share a CU (measured: 512 x 1 -4 %, 128 x 4 -4 %)
 #define BA_LDS_N 60      // reduced camera systems up to 60 x 60 (10 adjustable cameras) are solved in LDS
 #define BA_WAVES (BA_THREADS / 64)
+#ifndef BA_ILP_PROJ
 #define BA_ILP_PROJ 4   // projection passes: 4 measurements in flight (1 -> 4: -31 % on FindNewError once the view pointers were global and scalar; 6 spills: 5x slower)
+#endif
 #define BA_ILP_S 1      // Schur-complement tasks: 36 accumulators + two 6x3 blocks per lane leave no registers for a second point
 #define BA_ILP 4        // independent measurements per thread and loop trip: the loops are memory-latency bound at 2 waves/SIMD
 #define BA_ILP_C 4      // fused weight / derivative pass after an accepted step
