@@ -274,6 +274,7 @@ def main():
                     help="vslam_params.ba_batch_frames: the keyframes of this many consecutive frames share one Bundle::Compute launch (0 = chosen so that a launch carries about four problems per compute unit)")
     ap.add_argument("--ba-window", type=int, default=5, help="vslam_params.ba_window (jni/MapMaker.cc:812-820: 5; BASELINE configs[3]: 10)")
     ap.add_argument("--max-keyframes", type=int, default=32)
+    ap.add_argument("--max-patches", type=int, default=1000, help="vslam_params.max_patches_per_frame (jni/Tracker.cc:518: 1000; SURVEY.md 8(d) config 4 also asks for 2000)")
     ap.add_argument("--corners-per-level", type=str, default="", help="map points per pyramid level of the synthetic map, e.g. 1400,420,130,40 (default: the feeder's)")
     ap.add_argument("--kf-stagger", type=int, default=KF_PERIOD,
                     help="spread the streams' keyframe phases over this many frames (0: all streams in lock-step, one burst of bundle adjustments per period)")
@@ -395,7 +396,7 @@ def main():
         per_frame = Sk / float(stagger) if stagger else float(Sk)
         ba_batch = int(max(1, min(args.ba_delay - 6, (4 * ncu) // max(1.0, per_frame))))
     vp_kw = dict(patch_size=args.patch, ba_delay_frames=args.ba_delay, use_sbi=args.use_sbi, grow_map=args.grow_map, ba_window=args.ba_window,
-                 max_keyframes=args.max_keyframes)
+                 max_keyframes=args.max_keyframes, max_patches_per_frame=args.max_patches, ba_sum_order=args.ba_sum_order)
     vpk = capi.default_params(W, H, Sk, device=local_rank, ba_batch_frames=ba_batch, **vp_kw)
     if args.diag_kf_dist_mult is not None:
         vpk.max_kf_dist_wiggle_mult = args.diag_kf_dist_mult
@@ -655,7 +656,7 @@ def main():
             "config": {"workload": "BASELINE configs[%d]: %dx%d 4-level FAST-10 + %dx%d PatchFinder ZMSSD search, TrackMap pose update, "
                                    "AddKeyFrame + BundleAdjustRecent (%d-keyframe window) on keyframe frames" % (1 if (W, H) == (640, 480) else 3, W, H, args.patch, args.patch, args.ba_window),
                        "streams_per_gpu": S, "systems_per_gpu": NS, "ba_delay_frames": args.ba_delay, "ba_batch_frames": ba_batch, "ba_window": args.ba_window,
-                       "kf_stagger_frames": stagger, "use_sbi": args.use_sbi, "grow_map": args.grow_map,
+                       "kf_stagger_frames": stagger, "use_sbi": args.use_sbi, "grow_map": args.grow_map, "max_patches_per_frame": args.max_patches, "ba_sum_order": args.ba_sum_order,
                        "diagnostic_kf_dist_mult": args.diag_kf_dist_mult, "patch_size": args.patch, "corners_l0_per_frame": ncorn,
                        "patches_attempted_per_frame": round(att, 1), "patches_found_per_frame": round(fnd, 1),
                        "zmssd_evals_per_frame": round(zm, 1), "keyframes_per_step": round(kf_adds * S / K, 2),

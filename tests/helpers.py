@@ -14,8 +14,21 @@ def oracle_corner_fn(thr=(10, 15, 15, 10), barrier=10):
     return fn
 
 
-def make_scene(w=640, h=480, seed=1234, n_frames=30, n_keyframes=8, noise=2, **map_kw):
-    f = feeder.Feeder(w, h, seed=seed, noise=noise)
+def make_scene(w=640, h=480, seed=1234, n_frames=30, n_keyframes=8, noise=2, rects=None, **map_kw):
+    """rects: rectangles of the feeder's texture (VSLAM_FEEDER_NRECT; default 1000 ~ 1100 FAST corners at level 0 of 640x480,
+    1500 ~ 2000 at 1280x720 = BASELINE configs[3])"""
+    import os
+    old = os.environ.get("VSLAM_FEEDER_NRECT")
+    if rects:
+        os.environ["VSLAM_FEEDER_NRECT"] = str(rects)
+    try:
+        f = feeder.Feeder(w, h, seed=seed, noise=noise)
+    finally:
+        if rects:
+            if old is None:
+                os.environ.pop("VSLAM_FEEDER_NRECT", None)
+            else:
+                os.environ["VSLAM_FEEDER_NRECT"] = old
     m = feeder.build_map(f, oracle_corner_fn(), n_keyframes=n_keyframes, **map_kw)
     frames = f.render(0, n_frames)
     return f, m, frames
