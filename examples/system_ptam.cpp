@@ -43,11 +43,50 @@ int main(int argc, char** argv) {
       vslam_get_init_info(boot.mpMap->sys, 0, info);
       printf("frame %d: stage %d trails %d | %s\n", t, info[0], info[1], boot.mpTracker->GetMessageForUser().c_str());
     }
-    KeyFrame k0, k1; std::vector<std::pair<std::pair<double, double>, std::pair<double, double>>> none; mySE3 T;
-    const bool ok = boot.mpMapMaker->InitFromStereo(k0, k1, none, T);
+    KeyFrame k0, k1; std::vector<std::pair<MapMaker::ImageRef, MapMaker::ImageRef>> none; mySE3 T;
+    const bool ok = boot.mpMapMaker->InitFromStereo(k0, k1, none, T);   // the map exists: reports it
     printf("InitFromStereo: %s, camera at t = (%.3f %.3f %.3f)\n", ok ? "map made" : "no map", T.t[0], T.t[1], T.t[2]);
     vslam_feeder_destroy(f);
     return ok ? 0 : 1;
+  }
+  if (argc > 2 && std::string(argv[2]) == "stereo") {             // a caller that owns the keyframes and the matches: MapMaker::InitFromStereo itself
+    // the matches: the trails of a first system after 12 frames (any matcher would do)
+    std::vector<std::pair<MapMaker::ImageRef, MapMaker::ImageRef>> matches;
+    cv::Mat first(H, W, CV_8UC1), second(H, W, CV_8UC1), rgb(H, W, CV_8UC4);
+    {
+      SystemPTAM a(W, H, true);
+      cv::Mat bw(H, W, CV_8UC1);
+      for (int t = 0; t < 12; t++) {
+        double p[12];
+        vslam_feeder_pose(f, t, p);
+        vslam_feeder_render_pose(f, p, 100 + t, bw.data, bw.step);
+        if (t == 0) { a.onTouchScreen(); bw.copyTo(first); }
+        if (t == 11) bw.copyTo(second);
+        a.update(bw, rgb);
+      }
+      std::vector<int> tr(4 * 1000); int nt = 0;
+      vslam_get_trails(a.mpMap->sys, 0, tr.data(), 1000, &nt);
+      for (int i = 0; i < nt; i++) matches.push_back({{tr[4 * i], tr[4 * i + 1]}, {tr[4 * i + 2], tr[4 * i + 3]}});
+    }
+    SystemPTAM b(W, H, true);
+    KeyFrame kF, kS; kF.sys = kS.sys = b.mpMap->sys;
+    first.copyTo(kF.im0); second.copyTo(kS.im0);
+    mySE3 T;
+    const bool ok = b.mpMapMaker->InitFromStereo(kF, kS, matches, T);
+    printf("InitFromStereo(kFirst, kSecond, %d matches): %s, camera at t = (%.3f %.3f %.3f)\n", (int)matches.size(), ok ? "map made" : "no map", T.t[0], T.t[1], T.t[2]);
+    int good = 0;
+    cv::Mat bw(H, W, CV_8UC1);
+    for (int t = 12; t < 12 + n; t++) {                             // and the tracker follows the map it was handed
+      double p[12];
+      vslam_feeder_pose(f, t, p);
+      vslam_feeder_render_pose(f, p, 100 + t, bw.data, bw.step);
+      b.update(bw, rgb);
+      const std::string msg = b.mpTracker->GetMessageForUser();
+      if (msg.find("quality good") != std::string::npos) good++;
+      if (t == 12 + n - 1) printf("frame %d: %s\n", t, msg.c_str());
+    }
+    vslam_feeder_destroy(f);
+    return ok && good == n ? 0 : 1;
   }
   SystemPTAM sys(W, H);
   vslam_system* dev = sys.mpMap->sys;

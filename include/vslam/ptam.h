@@ -71,7 +71,9 @@ struct Map {
 struct KeyFrame {
   vslam_system* sys = nullptr;
   mySE3 se3CfromW;
+  cv::Mat im0;                                                      // aLevels[0].im: the host copy MapMaker::InitFromStereo hands to the device
   void MakeKeyFrame_Lite(cv::Mat& im, cv::Mat& /*imColor*/) {     // jni/KeyFrame.cc:5-51
+    im.copyTo(im0);                                                 // :12
     vslam_detail::check(vslam_make_keyframe_lite(sys, im.data, im.step, 0, 0));
     vslam_detail::check(vslam_synchronize(sys));
   }
@@ -108,12 +110,23 @@ class MapMaker {
   int QueueSize() { return 0; }
   bool NeedNewKeyFrame(KeyFrame&) { int v = 0; vslam_detail::check(vslam_need_new_keyframe(mMap.sys, 0, &v)); return v != 0; }              // :761-773 (the tracker's current frame)
   bool IsDistanceToNearestKeyFrameExcessive(KeyFrame&) { int v = 0; vslam_detail::check(vslam_distance_to_nearest_keyframe_excessive(mMap.sys, 0, &v)); return v != 0; }   // :1098-1101
-  // :204-376.  The two-view bootstrap runs on the device inside the frame that consumes the second spacebar press (a Tracker built
-  // with bBootstrap, vslam_params.bootstrap): the trails, the two keyframes and the matches never leave it.  This entry point
-  // reports what that frame did -- true and the tracker's pose once the map is good -- instead of taking host-side keyframes.
-  bool InitFromStereo(KeyFrame&, KeyFrame&, std::vector<std::pair<std::pair<double, double>, std::pair<double, double>>>&, mySE3& se3TrackerPose) {
+  // :204-376, the reference's signature (ImageRef = a pair of ints): the two keyframes' images (KeyFrame::im0, kept by MakeKeyFrame_Lite)
+  // and the matches go to the device, which makes the map from them (vslam_init_from_stereo); se3TrackerPose as there.  A Tracker
+  // built with bBootstrap makes the same call by itself on the second spacebar press (the trails never leave the device); once the
+  // map exists this reports it (true and the tracker's pose) without touching it.
+  typedef std::pair<int, int> ImageRef;
+  bool InitFromStereo(KeyFrame& kFirst, KeyFrame& kSecond, std::vector<std::pair<ImageRef, ImageRef>>& vMatches, mySE3& se3TrackerPose) {
     int info[6];
-    if (vslam_get_init_info(mMap.sys, 0, info) != VSLAM_OK || !info[5]) return false;
+    vslam_detail::check(vslam_get_init_info(mMap.sys, 0, info));
+    if (!info[5]) {
+      if (!kFirst.im0.data || !kSecond.im0.data) return false;
+      std::vector<int> m(4 * vMatches.size());
+      for (size_t i = 0; i < vMatches.size(); i++) { m[4 * i] = vMatches[i].first.first; m[4 * i + 1] = vMatches[i].first.second; m[4 * i + 2] = vMatches[i].second.first; m[4 * i + 3] = vMatches[i].second.second; }
+      double q[12];
+      const int rc = vslam_init_from_stereo(mMap.sys, kFirst.im0.data, kSecond.im0.data, kFirst.im0.step, (int)vMatches.size(), m.data(), q);
+      vslam_detail::check(rc);
+      if (rc != 1) return false;
+    }
     vslam_track_state s; vslam_detail::check(vslam_get_state(mMap.sys, 0, &s));
     memcpy(se3TrackerPose.R, s.pose, sizeof(se3TrackerPose.R)); memcpy(se3TrackerPose.t, s.pose + 9, sizeof(se3TrackerPose.t));
     return true;

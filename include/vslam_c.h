@@ -283,6 +283,13 @@ int vslam_mapmaker_idle_job(vslam_system* sys, int job);
 /* ---- map bootstrap (vslam_params.bootstrap) ----
  * Tracker::mbUserPressedSpacebar (jni/Tracker.h:138) of one stream, or of every stream (stream < 0): consumed by the next frame. */
 int vslam_press_spacebar(vslam_system* sys, int stream);
+/* MapMaker::InitFromStereo(KeyFrame&, KeyFrame&, vector<pair<ImageRef, ImageRef>>&, mySE3&) (jni/MapMaker.h:38, jni/MapMaker.cc:204-376) for a caller that
+ * owns the two frames and the matches: host gray images of the first and the second keyframe, n matches as (x, y in the first, x, y in the second)
+ * at level 0.  The first image becomes the first keyframe, the matches take the place of the trails, the second image is the frame the map is made
+ * in.  Returns 1 and the tracker's pose (pose12_out may be NULL) when the map is good, 0 when InitFromStereo gave up (then a new attempt may
+ * follow), a negative error otherwise.  One-stream systems created with bootstrap = 1 that have no map yet.  Synchronous. */
+int vslam_init_from_stereo(vslam_system* sys, const uint8_t* gray_first, const uint8_t* gray_second, size_t row_stride, int n_matches,
+                           const int* matches_xyxy, double pose12_out[12]);
 /* the seed that stands in for the reference's rand() state in HomographyInit's MLESAC and CalcPlaneAligner's RANSAC (default 1) */
 int vslam_set_boot_seed(vslam_system* sys, int stream, unsigned seed);
 /* out[0..5] = mnInitialStage (0 not started, 1 trails running, 2 complete), trails alive, InitFromStereo succeeded, homography inliers,

@@ -56,6 +56,24 @@ void orc_sys_idle_job(void* s, int job) { ((System*)s)->IdleJob(job); }
 void orc_sys_set_last_keyframe_dropped(void* s, int frame) { ((System*)s)->last_kf_dropped = frame; }   // Tracker::mnLastKeyFrameDropped
 void orc_sys_press_spacebar(void* s) { ((System*)s)->spacebar = true; }
 void orc_sys_set_boot_seed(void* s, unsigned seed) { ((System*)s)->boot_seed = seed; }
+// MapMaker::InitFromStereo(kFirst, kSecond, vMatches, se3) with the caller's frames and matches (jni/MapMaker.cc:204-376): the keyframes are
+// made from the two images the way the tracker makes its current frame (MakeKeyFrame_Lite); the second is the tracker's current frame
+int orc_sys_init_from_stereo(void* sv, const uint8_t* first, const uint8_t* second, int stride, const int* matches4, int n, double pose12[12]) {
+  System* s = (System*)sv;
+  if (s->map_good || s->init_stage != 0) return -1;
+  KeyFrame kF, kS;
+  make_keyframe_lite(kF, first, s->p.width, s->p.height, stride, s->p.thr);
+  make_keyframe_lite(kS, second, s->p.width, s->p.height, stride, s->p.thr);
+  std::vector<std::array<int, 4>> m((size_t)n);
+  for (int i = 0; i < n; i++) m[(size_t)i] = {matches4[4 * i], matches4[4 * i + 1], matches4[4 * i + 2], matches4[4 * i + 3]};
+  s->cur = kS;
+  s->frame += 2;                                                     // the two frames the device path spends on it
+  s->n_hom_inliers = 0; s->n_init_points = 0;
+  s->init_ok = s->InitFromStereo(kF, kS, m);
+  s->init_stage = 2;
+  if (pose12) pose_to12(s->pose, pose12);
+  return s->init_ok ? 1 : 0;
+}
 void orc_sys_get_init_info(void* sv, int out[6]) {
   System* s = (System*)sv;
   out[0] = s->init_stage; out[1] = (int)s->trails.size(); out[2] = s->init_ok ? 1 : 0; out[3] = s->n_hom_inliers; out[4] = s->n_init_points; out[5] = s->map_good ? 1 : 0;

@@ -272,6 +272,13 @@ class OracleSystem:
     def set_last_keyframe_dropped(self, frame):
         self.L.orc_sys_set_last_keyframe_dropped(self.h, C.c_int(frame))
 
+    def init_from_stereo(self, gray_first, gray_second, matches_xyxy):
+        a = np.ascontiguousarray(gray_first, np.uint8); b = np.ascontiguousarray(gray_second, np.uint8)
+        m = np.ascontiguousarray(matches_xyxy, np.int32).reshape(-1, 4)
+        pose = np.zeros(12)
+        rc = self.L.orc_sys_init_from_stereo(self.h, _p(a), _p(b), a.shape[1], _p(m), len(m), _p(pose))
+        return rc == 1, pose
+
     def press_spacebar(self):
         self.L.orc_sys_press_spacebar(self.h)
 

@@ -128,6 +128,7 @@ void orc_sys_frame_end(void* sys);
 void orc_sys_set_last_keyframe_dropped(void* sys, int frame);   /* Tracker::mnLastKeyFrameDropped (jni/Tracker.h), -20 at start */
 void orc_sys_press_spacebar(void* sys);
 void orc_sys_set_boot_seed(void* sys, unsigned seed);
+int orc_sys_init_from_stereo(void* sys, const uint8_t* first, const uint8_t* second, int stride, const int* matches4, int n, double pose12[12]);   /* MapMaker::InitFromStereo with the caller's frames and matches */
 void orc_sys_get_init_info(void* sys, int out[6]);   /* stage, trails, InitFromStereo succeeded, homography inliers, points after the stereo pass, map good */
 int orc_sys_get_trails(void* sys, int* out4 /* initial x, y, current x, y */, int cap);
 /* HomographyInit::Compute (jni/HomographyInit.cc:43-71) on n matches given as 8 doubles each: first (z = 1 plane), second, d pixel / d plane (2x2 row-major) */

@@ -94,6 +94,47 @@ def test_trails_and_init_from_stereo_match_the_oracle(patch):
     g.close()
 
 
+def test_init_from_stereo_with_host_keyframes_and_matches():
+    """vslam_init_from_stereo = MapMaker::InitFromStereo(kFirst, kSecond, vMatches, se3) for a caller that owns the frames and the matches
+    (jni/MapMaker.h:38, jni/MapMaker.cc:204-376) against the oracle's InitFromStereo on the same two images and matches.  The matches
+    are the oracle's own trails after 12 frames.  Integers exactly (inlier count, which matches become points, their sub-pixel
+    positions); the map in alignment-invariant quantities to the tolerance of the two sides' independent homography mathematics; then
+    both sides track the following frames of the sequence."""
+    w, h = 640, 480
+    f = feeder.Feeder(w, h, seed=1234, noise=2)
+    frames = f.render(0, 20)
+    kw = dict(patch_size=8, grow_map=3)
+    t_o = orc.OracleSystem(orc.params_from_vslam(capi.default_params(w, h, 1, **kw)))
+    t_o.press_spacebar()
+    for t in range(12):
+        t_o.track_frame(frames[t])
+    matches = t_o.trails()                                             # (x0, y0, x1, y1): frame 0 -> frame 11
+    assert len(matches) > 150
+    g = capi.System(capi.default_params(w, h, 1, bootstrap=1, **kw))
+    o = orc.OracleSystem(orc.params_from_vslam(capi.default_params(w, h, 1, **kw)))
+    ok_g, pose_g = g.init_from_stereo(frames[0], frames[11], matches)
+    ok_o, pose_o = o.init_from_stereo(frames[0], frames[11], matches)
+    assert ok_g and ok_o
+    io, ig = o.init_info(), g.init_info(0)
+    assert (io["stage"], io["init_ok"], io["map_good"], io["hom_inliers"], io["stereo_points"]) == (ig["stage"], ig["init_ok"], ig["map_good"], ig["hom_inliers"], ig["stereo_points"]), (io, ig)
+    assert io["stereo_points"] > 100
+    mo, mg = o.keyframe_meas(1), g.keyframe_meas(0, 1)
+    tr_o, tr_g = mo["source"] == 3, mg["source"] == 3
+    assert np.array_equal(mo["pt"][tr_o], mg["pt"][tr_g]) and np.array_equal(mo["root"][tr_o], mg["root"][tr_g])      # sub-pixel positions of the stereo points
+    rel_o = _mat(o.keyframe_pose(1)) @ np.linalg.inv(_mat(o.keyframe_pose(0)))
+    rel_g = _mat(g.keyframe_pose(0, 1)) @ np.linalg.inv(_mat(g.keyframe_pose(0, 0)))
+    bo, bg = np.linalg.norm(rel_o[:3, 3]), np.linalg.norm(rel_g[:3, 3])
+    assert np.abs(rel_o[:3, :3] - rel_g[:3, :3]).max() < 5e-3 and np.abs(rel_o[:3, 3] / bo - rel_g[:3, 3] / bg).max() < 2e-2
+    assert pose_err(pose_g, g.state(0).pose) == 0.0
+    with pytest.raises(capi.VslamError):
+        g.init_from_stereo(frames[0], frames[11], matches)             # the stream has a map now
+    for t in range(12, 20):
+        g.track_frame(frames[t][None]); o.track_frame(frames[t])
+        so, sg = o.state(), g.state(0)
+        assert so.quality == sg.quality == 2 and sum(sg.found) > 100, (t, list(so.found), list(sg.found))
+    g.close()
+
+
 def test_bootstrap_edge_cases_and_map_dump_round_trip(tmp_path):
     """A press with too few trails left resets the stage (jni/Tracker.cc:266-269); a stream with a map ignores the key; the
     map InitFromStereo made survives vslam_save_map -> vslam_read_map_dump to the 6 digits the format keeps."""

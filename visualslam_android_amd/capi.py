@@ -104,6 +104,7 @@ SYMBOLS = {
     "vslam_get_idle_stats": (_i, [_sys, _i, _vp]),
     "vslam_mapmaker_idle_job": (_i, [_sys, _i]),
     "vslam_press_spacebar": (_i, [_sys, _i]),
+    "vslam_init_from_stereo": (_i, [_sys, _vp, _vp, _sz, _i, _vp, _vp]),
     "vslam_set_boot_seed": (_i, [_sys, _i, C.c_uint]),
     "vslam_get_init_info": (_i, [_sys, _i, _vp]),
     "vslam_get_trails": (_i, [_sys, _i, _vp, _i, _vp]),
@@ -464,6 +465,14 @@ class System:
 
     def load_map_dump(self, stream, directory):
         _check(self.lib.vslam_load_map(self.h, stream, str(directory).encode()))
+
+    def init_from_stereo(self, gray_first, gray_second, matches_xyxy):
+        """MapMaker::InitFromStereo with the caller's frames and matches (vslam_init_from_stereo) -> (ok, pose12)"""
+        a = np.ascontiguousarray(gray_first, np.uint8); b = np.ascontiguousarray(gray_second, np.uint8)
+        m = np.ascontiguousarray(matches_xyxy, np.int32).reshape(-1, 4)
+        pose = np.zeros(12)
+        rc = _check(self.lib.vslam_init_from_stereo(self.h, a.ctypes.data, b.ctypes.data, a.shape[1], len(m), m.ctypes.data, pose.ctypes.data))
+        return bool(rc), pose
 
     def press_spacebar(self, stream=-1):
         _check(self.lib.vslam_press_spacebar(self.h, stream))

@@ -155,6 +155,13 @@ __global__ __launch_bounds__(BOOT_THREADS) void k_trail_advance(MapDev m, BootAr
   const int s = blockIdx.x;
   TrackerState* st = &m.st[s];
   if (st->boot_action != 2) return;
+  __shared__ int sh_host;
+  if (threadIdx.x == 0) sh_host = st->boot_host_matches;
+  __syncthreads();
+  if (sh_host) {                                                     // vslam_init_from_stereo: the matches are the caller's, nothing to search
+    if (threadIdx.x == 0) { st->boot_host_matches = 0; if (st->spacebar) { st->spacebar = 0; st->boot_run = 1; st->boot_ok = 0; } }
+    return;
+  }
   __shared__ uint8_t sh_tmpl[BOOT_WAVES][MPP + 3];
   __shared__ int sh_cand[BOOT_WAVES][64];
   __shared__ int keep[BOOT_MAX_TRAILS + 1];
@@ -594,6 +601,41 @@ extern "C" int vslam_press_spacebar(vslam_system* sys, int stream) {
   HIPCHK(hipGetLastError());
   sys->boot_key_pressed = true;
   return VSLAM_OK;
+}
+
+__global__ void k_boot_host_matches(MapDev m, int stream, int n) {
+  TrackerState* st = &m.st[stream];
+  st->n_trails = n; st->trail_buf = 0; st->boot_host_matches = 1;
+}
+
+// MapMaker::InitFromStereo(KeyFrame &kFirst, KeyFrame &kSecond, vector<pair<ImageRef, ImageRef>> &vMatches, mySE3 &se3CameraPos)
+// (jni/MapMaker.h:38, jni/MapMaker.cc:204-376) for a caller that owns the two frames and the matches: the first image becomes the first
+// keyframe exactly as a first spacebar press makes it (jni/Tracker.cc:290-318), the matches replace the trails, and the second image
+// is the frame that consumes the second press -- HomographyInit, the stereo points, the five + until-converged BundleAdjustAll,
+// AddSomeMapPoints, CalcPlaneAligner -- without TrailTracking_Advance's search.  One-stream systems (the reference's shape).
+extern "C" int vslam_init_from_stereo(vslam_system* sys, const uint8_t* gray_first, const uint8_t* gray_second, size_t row_stride, int n_matches,
+                                      const int* matches_xyxy, double pose12_out[12]) {
+  if (!sys || !gray_first || !gray_second || n_matches < 0 || (n_matches > 0 && !matches_xyxy)) { vslam_set_error("init_from_stereo: bad argument"); return VSLAM_E_INVALID; }
+  if (!sys->p.bootstrap || sys->S != 1) { vslam_set_error("init_from_stereo: needs a one-stream system created with bootstrap = 1"); return VSLAM_E_STATE; }
+  if (n_matches > BOOT_MAX_TRAILS) { vslam_set_error("init_from_stereo: at most %d matches (MaxInitialTrails, jni/Tracker.cc:305)", BOOT_MAX_TRAILS); return VSLAM_E_CAPACITY; }
+  int info[6];
+  int r = vslam_get_init_info(sys, 0, info); if (r) return r;
+  if (info[5] || info[0] != 0) { vslam_set_error("init_from_stereo: the stream has a map or an initialisation in progress"); return VSLAM_E_STATE; }
+  r = vslam_press_spacebar(sys, 0); if (r) return r;
+  r = vslam_update(sys, gray_first, row_stride, 0); if (r) return r;                 // TrailTracking_Start: the first keyframe
+  r = vslam_get_init_info(sys, 0, info); if (r) return r;
+  if (info[0] != 1) { vslam_set_error("init_from_stereo: the first frame did not start the initialisation"); return VSLAM_E_STATE; }
+  if (n_matches > 0) HIPCHK(hipMemcpy(sys->map.trail_pos, matches_xyxy, sizeof(int) * 4 * (size_t)n_matches, hipMemcpyHostToDevice));   // stream 0, trail buffer 0
+  hipLaunchKernelGGL(k_boot_host_matches, dim3(1), dim3(1), 0, sys->stream, sys->map, 0, n_matches);
+  r = vslam_press_spacebar(sys, 0); if (r) return r;
+  r = vslam_update(sys, gray_second, row_stride, 0); if (r) return r;                // the frame of the second press: InitFromStereo
+  r = vslam_get_init_info(sys, 0, info); if (r) return r;
+  if (pose12_out && info[5]) {
+    vslam_track_state st;
+    r = vslam_get_state(sys, 0, &st); if (r) return r;
+    for (int i = 0; i < 12; i++) pose12_out[i] = st.pose[i];
+  }
+  return info[2] && info[5] ? 1 : 0;                                                  // InitFromStereo's bool
 }
 
 extern "C" int vslam_set_boot_seed(vslam_system* sys, int stream, unsigned seed) {

@@ -114,6 +114,7 @@ struct TrackerState {       // Tracker members, jni/Tracker.h:77-150 (+ MapMaker
   int boot_run;             // InitFromStereo is running for this stream (gates its kernels)
   int boot_ok, n_hom_inliers, n_init_points;
   unsigned boot_seed;       // stands in for the reference's rand() state
+  int boot_host_matches;    // vslam_init_from_stereo: the trails are the caller's matches; this frame's TrailTracking_Advance does not search
 };
 
 struct TrackParams {        // device copy of the tunables the kernels read
