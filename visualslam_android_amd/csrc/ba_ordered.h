@@ -303,7 +303,7 @@ DEVFN void ba_compute_ordered(const BaView& v_, const BaConfig& cfg, const BaOrd
   __shared__ double sh_lambda, sh_factor, sh_sigma2, sh_cur_err, sh_new_err, sh_ssq;
   constexpr int LDS_SOLVE = BA_LDS_N * (BA_LDS_N + 1), LDS_LAYOUT = (2 * 4097 * (int)sizeof(int) + 7) / 8;
   __shared__ double lds_buf[LDS_SOLVE > LDS_LAYOUT ? LDS_SOLVE : LDS_LAYOUT];
-  __shared__ double camL[12 * BA_MAX_CAMS_LDS];
+  __shared__ double camL[12 * 128];                                 // every camera of a problem (at most 128 keyframes per map)
   __shared__ int sh_converged, sh_hitmax, sh_counter, sh_accepted, sh_error, sh_nout, sh_cache_valid, sh_next_nvalid;
   static_assert(sizeof(lds_buf) >= (65536 / 32) * sizeof(unsigned), "the LDS buffer also serves the erase's bit map");
   BaResult AS1* R = v.res;
