@@ -261,7 +261,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("VSLAM_BENCH_STREAMS", 2048)), help="sequences per GPU")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("VSLAM_BENCH_STREAMS", 3072)),
+                    help="sequences per GPU (3072: three full rounds of k_pose's 1024 resident workgroups; measured 343 k frames/s at 2048, 365 k at 3072, 366 k at 4096)")
     ap.add_argument("--systems", type=int, default=int(os.environ.get("VSLAM_BENCH_SYSTEMS", 1)),
                     help="split the streams over this many vslam_system handles (one HIP stream each) so their kernels overlap")
     ap.add_argument("--width", type=int, default=640)
@@ -392,9 +393,9 @@ def main():
     ba_batch = args.ba_batch
     if args.ba_delay <= 0:
         ba_batch = 1
-    elif ba_batch <= 0:                        # about four problems per compute unit per launch, and done well inside the delay window
-        per_frame = Sk / float(stagger) if stagger else float(Sk)
-        ba_batch = int(max(1, min(args.ba_delay - 6, (4 * ncu) // max(1.0, per_frame))))
+    elif ba_batch <= 0:                        # about six problems per compute unit per launch, and done well inside the delay window
+        per_frame = Sk / float(stagger) if stagger else float(Sk)    # (3072 streams: 7 frames per batch 359 k frames/s, 10 frames 365 k)
+        ba_batch = int(max(1, min(args.ba_delay - 6, (6 * ncu) // max(1.0, per_frame))))
     vp_kw = dict(patch_size=args.patch, ba_delay_frames=args.ba_delay, use_sbi=args.use_sbi, grow_map=args.grow_map, ba_window=args.ba_window,
                  max_keyframes=args.max_keyframes, max_patches_per_frame=args.max_patches, ba_sum_order=args.ba_sum_order)
     vpk = capi.default_params(W, H, Sk, device=local_rank, ba_batch_frames=ba_batch, **vp_kw)
