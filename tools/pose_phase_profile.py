@@ -3,7 +3,7 @@ import os, sys, ctypes as C
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
 import numpy as np
 from visualslam_android_amd import capi
-capi.load_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'visualslam_android_amd', 'libvslam_hip_baprof.so'))
+capi.load_library(os.environ.get('VSLAM_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'visualslam_android_amd', 'libvslam_hip_baprof.so'))
 from helpers import *
 W, H = 640, 480
 f, m, frames = make_scene(W, H, n_frames=6)
@@ -25,3 +25,4 @@ st = g.state(0)
 print('S', S, 'found', sum(st.found), 'total kcycles per k_pose launch %.1f' % (tot / 1e3 / 8))
 for i in range(0, 10):
     print('%-26s %8.1f kcyc/launch %5.1f%%' % (names[i], out[i] / 1e3 / 8, 100.0 * out[i] / tot))
+print('chain loop, wavefront 0 (chain): working %.1f, at the barrier %.1f kcyc/launch; wavefront 1 (producer): working %.1f, at the barrier %.1f' % tuple(out[i] / 1e3 / 8 for i in (10, 11, 12, 13)))

@@ -644,21 +644,164 @@ DEVFN void item_store(const PoseItem& it, const PoseWs& w, int e, bool all) {   
 // tree reduction would not do.  The workgroup is two wavefronts: wavefront 1 PRODUCES -- one lane per add_mJ call (two
 // lanes per measurement): weight, its row of the Jacobian and the call's 27 products (w J[r]) * J[c] and m * (w J[k]) --
 // a chunk ahead into LDS (the median's sort buffer is free by then); lane q of wavefront 0 walks sum q through the
-// chunk: one LDS read per two calls (immediate offsets) and one dependent addition per call.  Four such workgroups share
-// a CU (one chain per SIMD).
+// chunk: one LDS read per two calls (immediate offsets), two groups of eight calls read ahead, and one dependent addition
+// per call (8 cycles on gfx950, tools/probes/dep_add.hip).  Four such workgroups share a CU (one chain per SIMD).  A single
+// wavefront issues an fp64 instruction every 8 cycles at best, a SIMD one every ~4.3 from two wavefronts (same probe): the
+// producer's ~130 fp64 instructions per chunk of 64 calls are the pace (1650 cycles per chunk measured, 23 per call).
 #define POSE_CHUNK 32                 // measurements per chunk: two producer lanes each
 #define POSE_ENT 27                   // doubles per add_mJ call in LDS: its 27 products (odd stride: bank spread of the producer's stores)
-#define POSE_GRP 8                    // add_mJ calls per register set of the chain (two sets alternate)
-static_assert(2 * 2 * POSE_CHUNK * POSE_ENT + POSE_GRP * POSE_ENT + 64 <= SORT_CAP, "two record buffers (and the chain's one group of read-ahead) in the sort buffer");
+#define POSE_GRP 8                    // add_mJ calls per register set of the chain (three sets in rotation)
+static_assert(2 * 2 * POSE_CHUNK * POSE_ENT + 2 * POSE_GRP * POSE_ENT + 64 <= SORT_CAP, "two record buffers (and the chain's two groups of read-ahead) in the sort buffer");
 static_assert(POSE_THREADS == 128 && POSE_CHUNK == 32 && POSE_GRP % 2 == 0, "wavefront 0 chains, wavefront 1 produces");
 
-DEVFN void pose_chain_load(double (&v)[POSE_GRP], const double* p) {
+DEVFN void pose_chain_load(double (&v)[POSE_GRP], const double __attribute__((address_space(3)))* p) {
 #pragma unroll
   for (int u = 0; u < POSE_GRP; u++) v[u] = p[u * POSE_ENT];
 }
 DEVFN void pose_chain_add(double& acc, const double (&v)[POSE_GRP]) {
 #pragma unroll
   for (int u = 0; u < POSE_GRP; u++) acc += v[u];
+}
+
+#ifdef VSLAM_BA_PROF   // the chain loop's two wavefronts apart: slots 10 / 11 = wavefront 0 working / at the barrier, 12 / 13 = wavefront 1
+#define POSE_ACC_PROF_DECL unsigned long long tw_ = 0, tb_ = 0, tl_ = clock64()
+#define POSE_ACC_BARRIER() do { const unsigned long long a_ = clock64(); tw_ += a_ - tl_; __syncthreads(); tl_ = clock64(); tb_ += tl_ - a_; } while (0)
+#define POSE_ACC_PROF_END() do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { g_pose_prof[10 + 2 * (threadIdx.x >> 6)] += tw_; g_pose_prof[11 + 2 * (threadIdx.x >> 6)] += tb_; } } while (0)
+#else
+#define POSE_ACC_PROF_DECL do { } while (0)
+#define POSE_ACC_BARRIER() __syncthreads()
+#define POSE_ACC_PROF_END() do { } while (0)
+#endif
+#define PAS1 __attribute__((address_space(1)))
+#define PAS3 __attribute__((address_space(3)))
+// The accumulation itself is its own function (not inlined): it gets its own register allocation -- three register sets of
+// tracker data in flight, three of chain operands -- instead of sharing k_pose's, which is full.
+// Each wavefront runs its OWN loop (the branch is scalar: readfirstlane), with the same count of workgroup barriers on
+// both sides: in one shared loop the compiler's wait-count bookkeeping merges the two roles at every join and ends up
+// waiting for ALL outstanding loads before the producer's first use, a global-memory round trip in every chunk.
+// The producer's tracker data comes from the working set in global memory THREE chunks ahead (three register sets in
+// rotation, the loop unrolled by three so that no set is copied): a load has two chunk periods to land.
+// (The outlier marks of the last iteration, :749-756, are a pass of their own in calc_pose_update: a global STORE anywhere in this
+// loop makes loads and stores share the wait counter, and the compiler then waits for zero before every use.)
+__device__ __attribute__((noinline)) double pose_accumulate(const double PAS1* wd, int P, int nf, double wls_prior, bool qint, double sigma2, double PAS3* sortbuf) {
+  const int lane = threadIdx.x & 63;
+  nf = __builtin_amdgcn_readfirstlane(nf); P = __builtin_amdgcn_readfirstlane(P);   // (arguments arrive in vector registers: make the loops scalar again)
+  const int nchunks = (nf + POSE_CHUNK - 1) / POSE_CHUNK;
+  constexpr int BUF = 2 * POSE_CHUNK * POSE_ENT;
+  // sum q of the chain: upper triangle of C row by row (0..20), then v (21..26); the diagonal starts at the prior
+  POSE_ACC_PROF_DECL;
+  double acc = 0.0;
+  if (lane == 0 || lane == 6 || lane == 11 || lane == 15 || lane == 18 || lane == 20) acc = 0.0 + wls_prior;   // add_prior, :734
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 1) {
+    // producer lane = (measurement, row): the products of one add_mJ call; a measurement past the end, or one the reference
+    // skips (weight 0), is a record of zeros: x + 0 = x
+    const int row = lane & 1, pm = lane >> 1;
+    struct Item { double cam[3], image[2], vfound[2], da, db, sqrt_inv_noise; };
+    // The loads are issued by hand and waited for by hand (POSE_ITEM_LOADS per set, in-order return): the compiler's own
+    // bookkeeping puts a wait for ALL outstanding loads in front of the first use of the oldest set.
+#define POSE_ITEM_LOADS 10
+    auto gld = [&](double& dst, int comp, int e) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(wd + (size_t)comp * P + e)); };
+    auto load_chunk = [&](Item& t, int k) {
+      int e = k * POSE_CHUNK + pm;
+      e = e < nf ? e : nf - 1;
+#pragma unroll
+      for (int i = 0; i < 3; i++) gld(t.cam[i], i, e);
+#pragma unroll
+      for (int i = 0; i < 2; i++) { gld(t.image[i], 3 + i, e); gld(t.vfound[i], 9 + i, e); }
+      gld(t.da, 5 + 2 * row, e); gld(t.db, 6 + 2 * row, e);         // this row of m2CamDerivs
+      gld(t.sqrt_inv_noise, 11, e);
+    };
+    // the set is usable once at most `newer` later loads are outstanding; its registers are operands so that no use moves above the wait
+#define POSE_WAIT_SET(t, N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(t.cam[0]), "+v"(t.cam[1]), "+v"(t.cam[2]), "+v"(t.image[0]), "+v"(t.image[1]), \
+                                         "+v"(t.vfound[0]), "+v"(t.vfound[1]), "+v"(t.da), "+v"(t.db), "+v"(t.sqrt_inv_noise))
+    auto produce = [&](const Item& t, int e, double PAS3* buf) {
+      double PAS3* dst = buf + lane * POSE_ENT;
+      double w = 0.0, err[2] = {0.0, 0.0};
+      if (e < nf) {
+        err[0] = (t.vfound[0] - t.image[0]) * t.sqrt_inv_noise; err[1] = (t.vfound[1] - t.image[1]) * t.sqrt_inv_noise;
+        const double es = err[0] * err[0] + err[1] * err[1];
+        w = tukey_weight(es, sigma2);
+      }
+      if (w == 0.0) {
+#pragma unroll
+        for (int k = 0; k < POSE_ENT; k++) dst[k] = 0.0;
+        return;
+      }
+      // this row of CalcJacobian (jni/TrackerData.h:107-122), then wls.add_mJ(v2(row), sqrt_inv_noise * J.row(row), w), :760-767
+      const double ooz = 1.0 / t.cam[2];
+      const double c[3] = {t.cam[0], t.cam[1], t.cam[2]};
+      double J[6], wJ[6];
+#pragma unroll
+      for (int m = 0; m < 6; m++) {
+        double f0, f1;
+        se3_generator_motion(m, c, ooz, f0, f1);
+        J[m] = t.sqrt_inv_noise * (t.da * f0 + t.db * f1);
+        wJ[m] = w * J[m];
+      }
+      const double e_ = row ? err[1] : err[0];
+      const double mm = qint ? (double)(int)e_ : e_;
+      int q = 0;
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int cc = r; cc < 6; cc++) dst[q++] = wJ[r] * J[cc];
+#pragma unroll
+      for (int k = 0; k < 6; k++) dst[21 + k] = mm * wJ[k];
+    };
+    Item it0, it1, it2;
+    load_chunk(it0, 0); load_chunk(it1, 1); load_chunk(it2, 2);
+    POSE_ACC_BARRIER();                                                // the median has left the sort buffer
+    POSE_WAIT_SET(it0, 20);
+    produce(it0, pm, sortbuf);
+    POSE_ACC_BARRIER();
+    auto prod_step = [&](int k, Item& tprod, Item& tload) {         // chunk k + 1 while the chain walks chunk k; then the load of chunk k + 3
+      if (k + 1 < nchunks) {
+        load_chunk(tload, k + 3);                                   // (set k mod 3: chunk k was produced a step ago)
+        POSE_WAIT_SET(tprod, 20);                                   // (two newer sets in flight: 2 * POSE_ITEM_LOADS)
+        produce(tprod, (k + 1) * POSE_CHUNK + pm, sortbuf + ((k + 1) & 1) * BUF);
+      }
+      POSE_ACC_BARRIER();
+    };
+    for (int k = 0; k < nchunks; k += 3) {                          // chunk j's data is in set j mod 3
+      prod_step(k, it1, it0);
+      if (k + 1 < nchunks) prod_step(k + 1, it2, it1);
+      if (k + 2 < nchunks) prod_step(k + 2, it0, it2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the clamped loads past the last chunk
+  } else {
+    POSE_ACC_BARRIER();
+    POSE_ACC_BARRIER();
+    for (int k = 0; k < nchunks; k++) {
+      const int left = nf - k * POSE_CHUNK;
+      const int ng = (2 * (left < POSE_CHUNK ? left : POSE_CHUNK) + POSE_GRP - 1) / POSE_GRP;    // groups of calls in this chunk (the tail is zero records)
+      constexpr int GSTR = POSE_GRP * POSE_ENT;
+      const double PAS3* rp = sortbuf + (k & 1) * BUF + lane;
+      // three register sets in rotation, two groups of read-ahead: an LDS read has sixteen additions to land (the
+      // scheduling barriers keep the compiler from sinking the reads down to their use, which exposes the latency)
+      double x0[POSE_GRP], x1[POSE_GRP], x2[POSE_GRP];
+      pose_chain_load(x0, rp);
+      pose_chain_load(x1, rp + GSTR);
+      for (int g = 0; g < ng; g += 3) {                              // the read-ahead past the last group stays inside the sort buffer
+        pose_chain_load(x2, rp + (g + 2) * GSTR);
+        __builtin_amdgcn_sched_barrier(0);
+        pose_chain_add(acc, x0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 >= ng) break;
+        pose_chain_load(x0, rp + (g + 3) * GSTR);
+        __builtin_amdgcn_sched_barrier(0);
+        pose_chain_add(acc, x1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 2 >= ng) break;
+        pose_chain_load(x1, rp + (g + 4) * GSTR);
+        __builtin_amdgcn_sched_barrier(0);
+        pose_chain_add(acc, x2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      POSE_ACC_BARRIER();
+    }
+  }
+  POSE_ACC_PROF_END();
+  return acc;
 }
 
 DEVFN void calc_pose_update(const PoseWs& ws, MapPointDev* pts, int nf, const TrackParams& tp,
@@ -678,83 +821,14 @@ DEVFN void calc_pose_update(const PoseWs& ws, MapPointDev* pts, int nf, const Tr
     sigma2 = tukey_sigma_squared(med, (unsigned long)nf);
   }
   POSE_STAMP(3);
-  const bool qint = (tp.quirks & VSLAM_Q_POSE_INT_RESIDUAL) != 0;
-  const int nchunks = (nf + POSE_CHUNK - 1) / POSE_CHUNK;
-  constexpr int BUF = 2 * POSE_CHUNK * POSE_ENT;
-  const bool producer = wave == 1;
-  // sum q of the chain: upper triangle of C row by row (0..20), then v (21..26); the diagonal starts at the prior
-  double acc = 0.0;
-  if (lane == 0 || lane == 6 || lane == 11 || lane == 15 || lane == 18 || lane == 20) acc = 0.0 + tp.wls_prior;   // add_prior, :734
-  // producer lane = (measurement, row): the products of one add_mJ call; a measurement past the end, or one the reference
-  // skips (weight 0), is a record of zeros: x + 0 = x
-  const int row = lane & 1, pm = lane >> 1;
-  auto produce = [&](const PoseItem& t, int e, double* buf) {
-    double* dst = buf + lane * POSE_ENT;
-    double w = 0.0, err[2] = {0.0, 0.0};
-    if (e < nf) {
-      err[0] = (t.vfound[0] - t.image[0]) * t.sqrt_inv_noise; err[1] = (t.vfound[1] - t.image[1]) * t.sqrt_inv_noise;
-      const double es = err[0] * err[0] + err[1] * err[1];
-      w = tukey_weight(es, sigma2);
-      if (bMarkOutliers && row == 0) { if (w == 0.0) pts[t.idx].n_out++; else pts[t.idx].n_in++; }   // :749-756
+  const double acc = pose_accumulate((const double PAS1*)ws.d, ws.P, nf, tp.wls_prior, (tp.quirks & VSLAM_Q_POSE_INT_RESIDUAL) != 0, sigma2, (double PAS3*)sortbuf);
+  if (bMarkOutliers) {                                              // :749-756: a measurement the M-estimator gave no weight counts against its point
+    for (int e = threadIdx.x; e < nf; e += POSE_THREADS) {
+      const double sn = ws.d[11 * ws.P + e];
+      const double e0 = (ws.d[9 * ws.P + e] - ws.d[3 * ws.P + e]) * sn, e1 = (ws.d[10 * ws.P + e] - ws.d[4 * ws.P + e]) * sn;
+      MapPointDev* mp = pts + ws.i[ws.P + e];
+      if (tukey_weight(e0 * e0 + e1 * e1, sigma2) == 0.0) mp->n_out++; else mp->n_in++;
     }
-    if (w == 0.0) {
-#pragma unroll
-      for (int k = 0; k < POSE_ENT; k++) dst[k] = 0.0;
-      return;
-    }
-    // this row of CalcJacobian (jni/TrackerData.h:107-122), then wls.add_mJ(v2(row), sqrt_inv_noise * J.row(row), w), :760-767
-    const double ooz = 1.0 / t.cam[2];
-    const double c[3] = {t.cam[0], t.cam[1], t.cam[2]};
-    const double da = row ? t.derivs[2] : t.derivs[0], db = row ? t.derivs[3] : t.derivs[1];
-    double J[6], wJ[6];
-#pragma unroll
-    for (int m = 0; m < 6; m++) {
-      double f0, f1;
-      se3_generator_motion(m, c, ooz, f0, f1);
-      J[m] = t.sqrt_inv_noise * (da * f0 + db * f1);
-      wJ[m] = w * J[m];
-    }
-    const double e_ = row ? err[1] : err[0];
-    const double mm = qint ? (double)(int)e_ : e_;
-    int q = 0;
-#pragma unroll
-    for (int r = 0; r < 6; r++)
-#pragma unroll
-      for (int cc = r; cc < 6; cc++) dst[q++] = wJ[r] * J[cc];
-#pragma unroll
-    for (int k = 0; k < 6; k++) dst[21 + k] = mm * wJ[k];
-  };
-  PoseItem cur, nx;
-  if (producer) {
-    item_load(cur, ws, pm < nf ? pm : nf - 1);
-    item_load(nx, ws, POSE_CHUNK + pm < nf ? POSE_CHUNK + pm : nf - 1);
-  }
-  __syncthreads();                                                  // the median has left the sort buffer
-  if (producer) produce(cur, pm, sortbuf);
-  __syncthreads();
-  for (int k = 0; k < nchunks; k++) {
-    if (producer) {
-      if (k + 1 < nchunks) {
-        cur = nx;
-        const int e2 = (k + 2) * POSE_CHUNK + pm;
-        item_load(nx, ws, e2 < nf ? e2 : nf - 1);
-        produce(cur, (k + 1) * POSE_CHUNK + pm, sortbuf + ((k + 1) & 1) * BUF);
-      }
-    } else {
-      const int left = nf - k * POSE_CHUNK;
-      const int ng = (2 * (left < POSE_CHUNK ? left : POSE_CHUNK) + POSE_GRP - 1) / POSE_GRP;    // groups of calls in this chunk (the tail is zero records)
-      constexpr int GSTR = POSE_GRP * POSE_ENT;
-      const double* rp = sortbuf + (k & 1) * BUF + lane;
-      double x0[POSE_GRP], x1[POSE_GRP];
-      pose_chain_load(x0, rp);
-      for (int g = 0; g < ng; g += 2) {                              // the read-ahead past the last group stays inside the sort buffer
-        pose_chain_load(x1, rp + (g + 1) * GSTR);
-        pose_chain_add(acc, x0);
-        pose_chain_load(x0, rp + (g + 2) * GSTR);
-        if (g + 1 < ng) pose_chain_add(acc, x1);
-      }
-    }
-    __syncthreads();
   }
   POSE_STAMP(4);
   if (wave == 0 && lane < 27) red[lane] = acc;
