@@ -65,8 +65,9 @@ def aggregate(elapsed_s, stats, world):
     """max-over-ranks time and gathered per-rank stats (RCCL all_gather of a small fp64 vector; gloo in CPU tests)."""
     import torch
     import torch.distributed as dist
-    if world == 1 or not dist.is_initialized():
+    if not dist.is_initialized():                      # one rank started without a process group
         return elapsed_s, [list(stats)]
+    world = dist.get_world_size()
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
