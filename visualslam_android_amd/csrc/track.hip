@@ -70,11 +70,29 @@ DEVFN void td_calc_jacobian(const T& td, double* jac) {
 #else
 #define VSLAM_PVS_ATTR
 #endif
+// Map points (104-byte structures) and TrackData (168-byte structures) are arrays of structures: a lane-per-point access is
+// 64 separate 8-byte requests per instruction, and it was the REQUEST rate of L2 that set k_pvs's pace, not the bytes.  Both
+// directions go through LDS: the workgroup's 256 points come in as consecutive 8-byte words (26 KB), and the 13 doubles a
+// point writes (cam, image, derivs, warp_inv -- or only the first 3 / 5 of them, exactly as far as the reference's early
+// returns get) leave with consecutive lanes on consecutive words of a structure, which the memory pipeline merges.
+#define PVS_OUT 13                                                 // doubles of a TrackData that k_pvs writes: [0, 9) and [12, 16)
+struct PvsOut { double cam[3], image[2], derivs[4], warp_inv[4]; };
+static_assert(sizeof(PvsOut) == PVS_OUT * 8 && sizeof(MapPointDev) == PVS_OUT * 8 && sizeof(MapPointDev) % 8 == 0, "one LDS buffer serves both directions");
+static_assert(offsetof(TrackData, derivs) == 40 && offsetof(TrackData, warp_inv) == 96, "k_pvs's write-out indexes TrackData as doubles");
 __global__ __launch_bounds__(TRK_THREADS) VSLAM_PVS_ATTR void k_pvs(MapDev m, TrackParams tp, const double* sbi_rot /* [S][8] or null */) {
   const int s = blockIdx.y;
   TrackerState* st = &m.st[s];
   const bool tracking = st->map_good && st->lost_frames < 3;       // jni/Tracker.cc:103-104
+  const int n_points = st->n_points, i0 = blockIdx.x * TRK_THREADS;
+  if (blockIdx.x != 0 && (!tracking || i0 >= n_points)) return;    // (workgroup 0 also keeps the stream's frame state)
   __shared__ Pose pred;
+  __shared__ __align__(16) double pbuf[TRK_THREADS * PVS_OUT];
+  __shared__ int wn[TRK_THREADS];
+  const int nhere = tracking ? min(TRK_THREADS, n_points - i0) : 0;
+  if (nhere > 0) {
+    const double* src = (const double*)(m.pts + (size_t)s * tp.max_points + i0);
+    for (int k = threadIdx.x; k < nhere * PVS_OUT; k += TRK_THREADS) pbuf[k] = src[k];
+  }
   if (threadIdx.x == 0 && tracking) {                              // ApplyMotionModel, jni/Tracker.cc:781-798
     double v[6];
     for (int i = 0; i < 6; i++) v[i] = st->velocity[i];
@@ -91,36 +109,54 @@ __global__ __launch_bounds__(TRK_THREADS) VSLAM_PVS_ATTR void k_pvs(MapDev m, Tr
       st->n_search = 0; st->n_coarse = 0; st->n_iter = 0; st->n_l3 = 0; st->coarse_found = 0;
     }
   }
-  if (!tracking) return;
-  const int i = blockIdx.x * TRK_THREADS + threadIdx.x;
-  if (i >= st->n_points) return;
-  const MapPointDev& p = m.pts[(size_t)s * tp.max_points + i];
-  TrackData& td = m.td[(size_t)s * tp.max_points + i];
-  int& tdlevel = m.pt_level[(size_t)s * tp.max_points + i];
-  tdlevel = -1;
-  if (p.bad) return;
-  int flags = m.pt_flags[(size_t)s * tp.max_points + i];
-  int& tdflags = flags;
-  CamProj pr;
-  td_project(td, flags, p.pos, pred, tp.cam, pr);                      // :379-381
-  if (!(flags & TDF_IN_IMAGE)) { m.pt_flags[(size_t)s * tp.max_points + i] = flags; return; }
-  cam_derivs(tp.cam, pr, td.derivs);                               // :384 GetDerivsUnsafe
-  // CalcSearchLevelAndWarpMatrix, jni/PatchFinder.cc:31-68
-  const double ooz = 1.0 / td.cam[2];
-  double mr[3], md[3];
-  pose_rot(pred, p.right, mr);
-  pose_rot(pred, p.down, md);
-  const double r0 = mr[0] - td.cam[0] * mr[2] * ooz, r1 = mr[1] - td.cam[1] * mr[2] * ooz;
-  const double d0 = md[0] - td.cam[0] * md[2] * ooz, d1 = md[1] - td.cam[1] * md[2] * ooz;
-  const double* d = td.derivs;
-  td.warp_inv[0] = (d[0] * r0 + d[1] * r1) * ooz; td.warp_inv[2] = (d[2] * r0 + d[3] * r1) * ooz;
-  td.warp_inv[1] = (d[0] * d0 + d[1] * d1) * ooz; td.warp_inv[3] = (d[2] * d0 + d[3] * d1) * ooz;
-  double det = td.warp_inv[0] * td.warp_inv[3] - td.warp_inv[1] * td.warp_inv[2];
-  int level = 0;
-  while (det > 3 && level < NLEV - 1) { level++; det *= 0.25; }
-  if (det > 3 || det < 0.25) { m.pt_flags[(size_t)s * tp.max_points + i] = tdflags | TDF_TMPL_BAD; return; }   // mbTemplateBad = true; return -1
-  m.pt_flags[(size_t)s * tp.max_points + i] = tdflags & ~(TDF_SEARCHED | TDF_FOUND);   // :389-390
-  tdlevel = level;
+  if (nhere <= 0) return;
+  const int i = i0 + threadIdx.x;
+  PvsOut td;
+  int nwr = 0;                                                     // doubles of td this point writes
+  if (i < n_points) {
+    const MapPointDev p = *(const MapPointDev*)(pbuf + (size_t)threadIdx.x * PVS_OUT);
+    const size_t gi = (size_t)s * tp.max_points + i;
+    int level = -1;
+    if (!p.bad) {
+      int flags = m.pt_flags[gi];
+      CamProj pr;
+      const bool projected = td_project(td, flags, p.pos, pred, tp.cam, pr);     // :379-381
+      nwr = projected ? 5 : 3;
+      if (flags & TDF_IN_IMAGE) {
+        nwr = PVS_OUT;
+        cam_derivs(tp.cam, pr, td.derivs);                         // :384 GetDerivsUnsafe
+        // CalcSearchLevelAndWarpMatrix, jni/PatchFinder.cc:31-68
+        const double ooz = 1.0 / td.cam[2];
+        double mr[3], md[3];
+        pose_rot(pred, p.right, mr);
+        pose_rot(pred, p.down, md);
+        const double r0 = mr[0] - td.cam[0] * mr[2] * ooz, r1 = mr[1] - td.cam[1] * mr[2] * ooz;
+        const double d0 = md[0] - td.cam[0] * md[2] * ooz, d1 = md[1] - td.cam[1] * md[2] * ooz;
+        const double* d = td.derivs;
+        td.warp_inv[0] = (d[0] * r0 + d[1] * r1) * ooz; td.warp_inv[2] = (d[2] * r0 + d[3] * r1) * ooz;
+        td.warp_inv[1] = (d[0] * d0 + d[1] * d1) * ooz; td.warp_inv[3] = (d[2] * d0 + d[3] * d1) * ooz;
+        double det = td.warp_inv[0] * td.warp_inv[3] - td.warp_inv[1] * td.warp_inv[2];
+        int lv = 0;
+        while (det > 3 && lv < NLEV - 1) { lv++; det *= 0.25; }
+        if (det > 3 || det < 0.25) flags |= TDF_TMPL_BAD;          // mbTemplateBad = true; return -1
+        else { flags &= ~(TDF_SEARCHED | TDF_FOUND); level = lv; } // :389-390
+      }
+      m.pt_flags[gi] = flags;
+    }
+    m.pt_level[gi] = level;
+  }
+  __syncthreads();                                                 // every lane has its map point out of the buffer
+  wn[threadIdx.x] = nwr;
+  {
+    const double* t = (const double*)&td;
+    for (int f = 0; f < PVS_OUT; f++) if (f < nwr) pbuf[threadIdx.x * PVS_OUT + f] = t[f];
+  }
+  __syncthreads();
+  double* dst = (double*)(m.td + (size_t)s * tp.max_points + i0);
+  for (int k = threadIdx.x; k < nhere * PVS_OUT; k += TRK_THREADS) {
+    const int j = k / PVS_OUT, f = k - j * PVS_OUT;
+    if (f < wn[j]) dst[(size_t)j * (sizeof(TrackData) / 8) + (f < 9 ? f : f + 3)] = pbuf[k];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
