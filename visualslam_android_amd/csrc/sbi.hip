@@ -3,7 +3,7 @@
 //   SmallBlurryImage::MakeFromKF (jni/SmallBlurryImage.cc:20-55)  level 3 -> half size, zero mean, 9x9 Gaussian sigma 0.75
 //   MakeJacs (:58-79)                                              central differences of the template
 //   IteratePosRelToTarget (:98-222)                                6 ESM iterations aligning this frame's SBI to the last one's
-//   SE3fromSE2 (:249-333) + Tracker::CalcSBIRotation (jni/Tracker.cc:885-893)   -> mv6SBIRot, read by k_pvs (ApplyMotionModel)
+//   SE3fromSE2 (:249-333) + Tracker::CalcSBIRotation (jni/Tracker.cc:885-893)   -> mv6SBIRot, read by k_motion (ApplyMotionModel)
 // cv::resize / cv::GaussianBlur / Eigen's 4x4 inverse are third-party arithmetic, restated exactly as in oracle/sbi.cpp
 // (same float expressions in the same order).  The whole stage is bit-exact with the oracle: the sample positions of
 // transform_image are accumulated pixel by pixel by two lanes, and the fifteen ESM sums are taken in the reference's

@@ -1,7 +1,8 @@
 // Tracker::TrackMap (jni/Tracker.cc:358-626) for all streams of a system, fully device resident:
 // no host round-trip inside a frame.  One launch per dependent stage, each batched over the streams:
 //
-//   k_pvs      ApplyMotionModel (:781-798) + per map point TrackerData::Project / GetDerivsUnsafe
+//   k_motion   ApplyMotionModel (:781-798), one lane per stream
+//   k_pvs      per map point TrackerData::Project / GetDerivsUnsafe
 //              (jni/TrackerData.h:69-95) + PatchFinder::CalcSearchLevelAndWarpMatrix (jni/PatchFinder.cc:31-68)
 //   k_plan     potentially-visible-set lists per level in map order (the reference's random_shuffle is the
 //              identity permutation here), coarse-stage selection (:399-461) / fine-stage selection (:493-535)
@@ -79,37 +80,40 @@ DEVFN void td_calc_jacobian(const T& td, double* jac) {
 struct PvsOut { double cam[3], image[2], derivs[4], warp_inv[4]; };
 static_assert(sizeof(PvsOut) == PVS_OUT * 8 && sizeof(MapPointDev) == PVS_OUT * 8 && sizeof(MapPointDev) % 8 == 0, "one LDS buffer serves both directions");
 static_assert(offsetof(TrackData, derivs) == 40 && offsetof(TrackData, warp_inv) == 96, "k_pvs's write-out indexes TrackData as doubles");
-__global__ __launch_bounds__(TRK_THREADS) VSLAM_PVS_ATTR void k_pvs(MapDev m, TrackParams tp, const double* sbi_rot /* [S][8] or null */) {
+// ApplyMotionModel (jni/Tracker.cc:781-798) and the per-frame reset of the tracker's counters, one lane per stream: in k_pvs every
+// workgroup of a stream repeated the prediction on one lane (a serial se3_exp behind two dependent loads) while its other 255 waited.
+__global__ __launch_bounds__(64) void k_motion(MapDev m, int S, const double* sbi_rot /* [S][8] or null */) {
+  const int s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= S) return;
+  TrackerState* st = &m.st[s];
+  const bool tracking = st->map_good && st->lost_frames < 3;       // jni/Tracker.cc:103-104
+  st->frame++;                                                     // :100
+  st->kf_pending = 0; st->kf_added = 0;
+  if (!tracking) return;
+  double v[6];
+  for (int i = 0; i < 6; i++) v[i] = st->velocity[i];
+  if (sbi_rot) { v[0] = 0.0; v[1] = 0.0; for (int i = 3; i < 6; i++) v[i] = sbi_rot[(size_t)s * 8 + i]; }   // mbUseSBIInit :788-794
+  const Pose pred = pose_mul(se3_exp(v), st->pose_final);
+  st->start_pose = st->pose_final; st->pose_cur = pred;
+  for (int l = 0; l < NLEV; l++) { st->attempted[l] = 0; st->found[l] = 0; }   // :360-361
+  st->n_search = 0; st->n_coarse = 0; st->n_iter = 0; st->n_l3 = 0; st->coarse_found = 0;
+}
+
+__global__ __launch_bounds__(TRK_THREADS) VSLAM_PVS_ATTR void k_pvs(MapDev m, TrackParams tp) {
   const int s = blockIdx.y;
   TrackerState* st = &m.st[s];
   const bool tracking = st->map_good && st->lost_frames < 3;       // jni/Tracker.cc:103-104
   const int n_points = st->n_points, i0 = blockIdx.x * TRK_THREADS;
-  if (blockIdx.x != 0 && (!tracking || i0 >= n_points)) return;    // (workgroup 0 also keeps the stream's frame state)
-  __shared__ Pose pred;
+  if (!tracking || i0 >= n_points) return;
   __shared__ __align__(16) double pbuf[TRK_THREADS * PVS_OUT];
   __shared__ int wn[TRK_THREADS];
-  const int nhere = tracking ? min(TRK_THREADS, n_points - i0) : 0;
-  if (nhere > 0) {
+  const int nhere = min(TRK_THREADS, n_points - i0);
+  {
     const double* src = (const double*)(m.pts + (size_t)s * tp.max_points + i0);
     for (int k = threadIdx.x; k < nhere * PVS_OUT; k += TRK_THREADS) pbuf[k] = src[k];
   }
-  if (threadIdx.x == 0 && tracking) {                              // ApplyMotionModel, jni/Tracker.cc:781-798
-    double v[6];
-    for (int i = 0; i < 6; i++) v[i] = st->velocity[i];
-    if (sbi_rot) { v[0] = 0.0; v[1] = 0.0; for (int i = 3; i < 6; i++) v[i] = sbi_rot[(size_t)s * 8 + i]; }   // mbUseSBIInit :788-794
-    pred = pose_mul(se3_exp(v), st->pose_final);
-  }
+  const Pose pred = st->pose_cur;                                  // k_motion's prediction (a uniform load)
   __syncthreads();
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    st->frame++;                                                   // :100
-    st->kf_pending = 0; st->kf_added = 0;
-    if (tracking) {
-      st->start_pose = st->pose_final; st->pose_cur = pred;
-      for (int l = 0; l < NLEV; l++) { st->attempted[l] = 0; st->found[l] = 0; }   // :360-361
-      st->n_search = 0; st->n_coarse = 0; st->n_iter = 0; st->n_l3 = 0; st->coarse_found = 0;
-    }
-  }
-  if (nhere <= 0) return;
   const int i = i0 + threadIdx.x;
   PvsOut td;
   int nwr = 0;                                                     // doubles of td this point writes
@@ -1226,8 +1230,8 @@ int trk_search_stage(vslam_system* sys, int stage) {
   trk_search_args(sys, a);
   if (stage == 0) {
     prof_mark(sys, 3);
-    hipLaunchKernelGGL(k_pvs, dim3((P + TRK_THREADS - 1) / TRK_THREADS, S), dim3(TRK_THREADS), 0, sys->stream, m, tp,
-                       sys->p.use_sbi ? (const double*)sys->fr.sbi_rot : (const double*)nullptr);
+    hipLaunchKernelGGL(k_motion, dim3((S + 63) / 64), dim3(64), 0, sys->stream, m, S, sys->p.use_sbi ? (const double*)sys->fr.sbi_rot : (const double*)nullptr);
+    hipLaunchKernelGGL(k_pvs, dim3((P + TRK_THREADS - 1) / TRK_THREADS, S), dim3(TRK_THREADS), 0, sys->stream, m, tp);
     prof_mark(sys, 4);
     hipLaunchKernelGGL(k_plan, dim3(S), dim3(TRK_THREADS), 0, sys->stream, m, tp, 0);
     prof_mark(sys, 5);
