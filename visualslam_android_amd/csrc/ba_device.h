@@ -417,14 +417,20 @@ DEVFN int ba_block_excl_scan(int AS1* a, int n, int* ired) {
   return total;
 }
 
+#define BA_LAYOUT_CB 12   // cameras whose LUT entries of a point are loaded together (one memory round trip instead of one per camera)
 BA_PHASE_FN void ba_build_layout(const BaView& v_, int nc, int np, int* ired, int* lds_i /* LDS, 2 * (max_pts + 1) ints */) {
   const BaViewG v = ba_g(v_);
   // 1. per point: how many adjustable / fixed cameras measure it, which adjustable ones; V and epsilon_b start at zero
   for (int p = threadIdx.x; p < np; p += BA_THREADS) {
     int nF = 0, nX = 0; unsigned long long mk = 0;
-    for (int c = 0; c < nc; c++) {
-      if (v.lut[(size_t)c * v.max_pts + p] < 0) continue;
-      if (v.cam_fixed[c]) nX++; else { nF++; mk |= 1ull << (v.cam_row[c] / 6); }
+    for (int c0 = 0; c0 < nc; c0 += BA_LAYOUT_CB) {
+      int li[BA_LAYOUT_CB];
+      _Pragma("unroll") for (int u = 0; u < BA_LAYOUT_CB; u++) li[u] = c0 + u < nc ? v.lut[(size_t)(c0 + u) * v.max_pts + p] : -1;
+      _Pragma("unroll") for (int u = 0; u < BA_LAYOUT_CB; u++) {
+        if (li[u] < 0) continue;
+        const int c = c0 + u;
+        if (v.cam_fixed[c]) nX++; else { nF++; mk |= 1ull << (v.cam_row[c] / 6); }
+      }
     }
     v.pt_offF[p] = nF; v.pt_offX[p] = nX; v.pt_maskF[p] = mk;
     _Pragma("unroll") for (int k = 0; k < 6; k++) PT(pt_V, k, p) = 0.0;
@@ -436,32 +442,59 @@ BA_PHASE_FN void ba_build_layout(const BaView& v_, int nc, int np, int* ired, in
   // 2. the slots: adjustable cameras in ordinal order, then (region X) fixed cameras in index order
   for (int p = threadIdx.x; p < np; p += BA_THREADS) {
     int kf = v.pt_offF[p], kx = MF + v.pt_offX[p];
-    for (int c = 0; c < nc; c++) {
-      const int i = v.lut[(size_t)c * v.max_pts + p];
-      if (i < 0) continue;
-      const bool fx = v.cam_fixed[c] != 0;
-      const int s = fx ? kx++ : kf++;
-      v.sl_info[s] = SL_MAKE(c, MS_OK, fx ? 255 : v.cam_row[c] / 6) | (fx && v.pt_offF[p + 1] - v.pt_offF[p] > 0 ? SL_HASF : 0);
-      v.sl_pt[s] = p; v.sl_logical[s] = i;
-      SL(sl_found, 0, s) = MS(ms_found, 0, i); SL(sl_found, 1, s) = MS(ms_found, 1, i);
-      v.sl_sin[s] = v.ms_sin[i];
+    const bool hasF = v.pt_offF[p + 1] - kf > 0;
+    for (int c0 = 0; c0 < nc; c0 += BA_LAYOUT_CB) {
+      int li[BA_LAYOUT_CB];
+      _Pragma("unroll") for (int u = 0; u < BA_LAYOUT_CB; u++) li[u] = c0 + u < nc ? v.lut[(size_t)(c0 + u) * v.max_pts + p] : -1;
+      double f0[BA_LAYOUT_CB], f1[BA_LAYOUT_CB], sn[BA_LAYOUT_CB];       // the measurements' static data, all requested before the first is stored
+      _Pragma("unroll") for (int u = 0; u < BA_LAYOUT_CB; u++) {
+        const int i = li[u] < 0 ? 0 : li[u];
+        f0[u] = MS(ms_found, 0, i); f1[u] = MS(ms_found, 1, i); sn[u] = v.ms_sin[i];
+      }
+      _Pragma("unroll") for (int u = 0; u < BA_LAYOUT_CB; u++) {
+        const int i = li[u];
+        if (i < 0) continue;
+        const int c = c0 + u;
+        const bool fx = v.cam_fixed[c] != 0;
+        const int s = fx ? kx++ : kf++;
+        v.sl_info[s] = SL_MAKE(c, MS_OK, fx ? 255 : v.cam_row[c] / 6) | (fx && hasF ? SL_HASF : 0);
+        v.sl_pt[s] = p; v.sl_logical[s] = i;
+        SL(sl_found, 0, s) = f0[u]; SL(sl_found, 1, s) = f1[u];
+        v.sl_sin[s] = sn[u];
+      }
     }
   }
-  // 3. chunk tables of the step sweep: consecutive whole points, at most 64 slots (one lane each)
+  // 3. chunk tables of the step sweep: consecutive whole points, at most 64 slots (one lane each).  Wavefront 0 cuts region F,
+  //    wavefront 1 region X: 64 lanes look at the next 64 points at once, the first whose end leaves the chunk's 64 slots is the cut.
   int* oF = lds_i; int* oX = lds_i + (np + 1);
   for (int p = threadIdx.x; p <= np; p += BA_THREADS) { oF[p] = v.pt_offF[p]; oX[p] = v.pt_offX[p]; }
   __syncthreads();
-  if (threadIdx.x == 0 || threadIdx.x == 64) {
-    const int* o = threadIdx.x == 0 ? oF : oX;
-    int AS1* ch = threadIdx.x == 0 ? v.chF : v.chX;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave < 2) {
+    const int* o = wave == 0 ? oF : oX;
+    int AS1* ch = wave == 0 ? v.chF : v.chX;
     int k = 0, start = 0;
-    if (np > 0) ch[0] = o[0];
-    for (int p = 0; p < np; p++) {
-      if (o[p + 1] - o[start] > 64 && p > start) { ch[++k] = o[p]; start = p; }   // a point with more than 64 slots stands alone
+    if (np > 0 && lane == 0) ch[0] = o[0];
+    while (start < np) {
+      // the cut is the first point p > start with o[p + 1] - o[start] > 64 (a point with more than 64 slots stands alone)
+      const int ostart = o[start];
+      int cut = -1;
+      for (int base = start + 1; base < np && cut < 0; base += 64) {
+        const int pp = base + lane;
+        const bool over = pp < np && o[pp + 1] - ostart > 64;
+        const unsigned long long bm = __ballot(over);
+        if (bm) cut = base + (int)__ffsll((long long)bm) - 1;
+      }
+      if (cut < 0) break;
+      k++;
+      if (lane == 0) ch[k] = o[cut];
+      start = cut;
     }
-    if (np > 0) ch[++k] = o[np];
-    v.ch_n[threadIdx.x == 0 ? 0 : 1] = k;
-    if (threadIdx.x == 0) { v.ch_n[2] = MF; v.ch_n[3] = MF + MX; }
+    if (np > 0) { k++; if (lane == 0) ch[k] = o[np]; }
+    if (lane == 0) {
+      v.ch_n[wave] = k;
+      if (wave == 0) { v.ch_n[2] = MF; v.ch_n[3] = MF + MX; }
+    }
   }
   __syncthreads();
 }
