@@ -1153,15 +1153,20 @@ BA_PHASE_FN int ba_erase_outliers(const BaView& v_, int M, int nm, int nout, uns
   for (int t = threadIdx.x; t < nwords; t += BA_THREADS) bits[t] = 0u;
   __syncthreads();
   int mine = 0;
-  for (int s = threadIdx.x; s < M; s += BA_THREADS) {
-    const int info = v.sl_info[s];
-    if (SL_STATE(info) != MS_BAD) continue;
-    v.sl_info[s] = SL_WITH_STATE(info, MS_ERASED);
-    v.scratch[s] = __builtin_huge_val();
-    const int i = v.sl_logical[s];
-    atomicOr(&bits[i >> 5], 1u << (i & 31));
-    atomicAdd((int*)&v.pt_nout[v.sl_pt[s]], 1);
-    mine++;
+  constexpr int EI = 8;                                               // slots whose state words are requested together: few slots are bad, the loop is all latency
+  for (int s0 = threadIdx.x; s0 < M; s0 += EI * BA_THREADS) {
+    int info[EI];
+    _Pragma("unroll") for (int u = 0; u < EI; u++) { const int s = s0 + u * BA_THREADS; info[u] = s < M ? v.sl_info[s] : 0; }
+    _Pragma("unroll") for (int u = 0; u < EI; u++) {
+      const int s = s0 + u * BA_THREADS;
+      if (s >= M || SL_STATE(info[u]) != MS_BAD) continue;
+      v.sl_info[s] = SL_WITH_STATE(info[u], MS_ERASED);
+      v.scratch[s] = __builtin_huge_val();
+      const int i = v.sl_logical[s];
+      atomicOr(&bits[i >> 5], 1u << (i & 31));
+      atomicAdd((int*)&v.pt_nout[v.sl_pt[s]], 1);
+      mine++;
+    }
   }
   const int total = ba_block_sum_i(mine, ired);                     // (barriers inside: the bit map is complete)
   if (total == 0) return nout;
