@@ -1058,6 +1058,11 @@ BA_PHASE_FN double ba_map_update(const BaView& v_, int nfree, int np, double lam
       SIn nin = cin;
       const bool act = lane < n;
       const int pt = cin.pt;
+      // the point's V and epsilon_b for its first lane: requested by every lane of the point (one broadcast access) at the top of
+      // the trip, so that they are under way while the slot's W^T * update is formed
+      double eb[3], vq[6];
+      _Pragma("unroll") for (int q = 0; q < 3; q++) eb[q] = PT(pt_eb, q, pt);
+      _Pragma("unroll") for (int q = 0; q < 6; q++) vq[q] = PT(pt_V, q, pt);
       double t[3] = {0, 0, 0};
       if (act && SL_STATE(cin.info) == MS_OK) {
         MeasState ms;
@@ -1078,10 +1083,6 @@ BA_PHASE_FN double ba_map_update(const BaView& v_, int nfree, int np, double lam
       const int ptprev = __shfl_up(pt, 1);
       const bool leader = act && (lane == 0 || ptprev != pt);
       const unsigned long long lm = __ballot(leader);
-      // the point's V and epsilon_b for its first lane: requested by every lane of the point (one broadcast access) before the sums
-      double eb[3], vq[6];
-      _Pragma("unroll") for (int q = 0; q < 3; q++) eb[q] = PT(pt_eb, q, pt);
-      _Pragma("unroll") for (int q = 0; q < 6; q++) vq[q] = PT(pt_V, q, pt);
       if (leader) {
         const unsigned long long above = lane < 63 ? lm >> (lane + 1) : 0ull;
         const int cnt = above ? (int)__ffsll((long long)above) : n - lane;
