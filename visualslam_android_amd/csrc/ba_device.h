@@ -520,34 +520,45 @@ BA_PHASE_FN BaNewError ba_find_new_error(const BaView& v_, const BaConfig& cfg_,
   const double AS1* pts = trial ? v.pt_new : v.pt_pos;
   double ne = 0.0;
   int nv = 0;
-  for (int i0 = threadIdx.x; i0 < M; i0 += BA_ILP_PROJ * BA_THREADS) {
-    int info[BA_ILP_PROJ], mp[BA_ILP_PROJ]; double f0[BA_ILP_PROJ], f1[BA_ILP_PROJ], sn[BA_ILP_PROJ];
+  // The slot fields of the NEXT batch are requested together with this batch's points (which hang on this batch's slot fields):
+  // one exposed memory round trip per batch instead of two.  (Deeper pipelining does not survive the compiler: with the stores to
+  // `scratch` in the loop, loads and stores share vmcnt and every first use waits for zero.)
+  struct SlotBatch { int info[BA_ILP_PROJ], mp[BA_ILP_PROJ]; double f0[BA_ILP_PROJ], f1[BA_ILP_PROJ], sn[BA_ILP_PROJ]; };
+  auto load_batch = [&](int i0, SlotBatch& b) {
     _Pragma("unroll") for (int u = 0; u < BA_ILP_PROJ; u++) {
       const int i = i0 + u * BA_THREADS, ic = i < M ? i : M - 1;
-      info[u] = v.sl_info[ic]; mp[u] = v.sl_pt[ic];
-      if (i >= M) info[u] = SL_WITH_STATE(info[u], MS_ERASED);
-      f0[u] = SL(sl_found, 0, ic); f1[u] = SL(sl_found, 1, ic); sn[u] = v.sl_sin[ic];
+      b.info[u] = v.sl_info[ic]; b.mp[u] = v.sl_pt[ic];
+      if (i >= M) b.info[u] = SL_WITH_STATE(b.info[u], MS_ERASED);
+      b.f0[u] = SL(sl_found, 0, ic); b.f1[u] = SL(sl_found, 1, ic); b.sn[u] = v.sl_sin[ic];
     }
+  };
+  SlotBatch cb;
+  if ((int)threadIdx.x < M) load_batch(threadIdx.x, cb);
+  for (int i0 = threadIdx.x; i0 < M; i0 += BA_ILP_PROJ * BA_THREADS) {
     Pose T[BA_ILP_PROJ]; double X[BA_ILP_PROJ][3];
     _Pragma("unroll") for (int u = 0; u < BA_ILP_PROJ; u++) {
-      { const int cj = SL_CAM(info[u]); _Pragma("unroll") for (int q = 0; q < 9; q++) T[u].R[q] = camL[cj * 12 + q]; _Pragma("unroll") for (int q = 0; q < 3; q++) T[u].t[q] = camL[cj * 12 + 9 + q]; }
-      _Pragma("unroll") for (int k = 0; k < 3; k++) X[u][k] = pts[3 * mp[u] + k];
+      { const int cj = SL_CAM(cb.info[u]); _Pragma("unroll") for (int q = 0; q < 9; q++) T[u].R[q] = camL[cj * 12 + q]; _Pragma("unroll") for (int q = 0; q < 3; q++) T[u].t[q] = camL[cj * 12 + 9 + q]; }
+      _Pragma("unroll") for (int k = 0; k < 3; k++) X[u][k] = pts[3 * cb.mp[u] + k];
     }
+    SlotBatch nb = cb;
+    const int in = i0 + BA_ILP_PROJ * BA_THREADS;
+    if (in < M) load_batch(in, nb);
     _Pragma("unroll") for (int u = 0; u < BA_ILP_PROJ; u++) {
-      const int st = SL_STATE(info[u]);
+      const int st = SL_STATE(cb.info[u]);
       if (st == MS_ERASED) continue;
       const int i = i0 + u * BA_THREADS;
       double c[3];
       pose_xform(T[u], X[u], c);
       if (c[2] <= 0) { ne += 1.0; v.scratch[i] = __builtin_huge_val(); continue; }
       const CamProj pr = cam_project(cfg.cam, c[0] / c[2], c[1] / c[2]);
-      const double e0 = (f0[u] - pr.im[0]) * sn[u], e1 = (f1[u] - pr.im[1]) * sn[u];
+      const double e0 = (cb.f0[u] - pr.im[0]) * cb.sn[u], e1 = (cb.f1[u] - pr.im[1]) * cb.sn[u];
       const double e2 = e0 * e0 + e1 * e1;
       ne += tukey_objective(e2, sigma2);
       const bool stays = st == MS_OK;                                 // MS_BAD ones are erased at the end of this step
       v.scratch[i] = stays ? e2 : __builtin_huge_val();
       nv += stays ? 1 : 0;
     }
+    cb = nb;
   }
   BaNewError r; r.ne = ne; r.nvalid = nv;
   return r;
