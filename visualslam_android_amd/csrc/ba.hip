@@ -773,7 +773,11 @@ int ba_alloc(vslam_system* sys) {
   // k_ba_compute needs scratch memory, and the runtime sizes that lazily, at the first launch of a grid this large: paid here,
   // at creation, not by the first BundleAdjustRecent / BundleAdjustAll a caller times.
   ba_launch_compute(ws->pool, make_cfg(sys->tp), sys->S, sys->stream, -1, -1);
+  // ... and on every stream of the asynchronous map-maker's ring: scratch belongs to the hardware queue a stream maps to, and the
+  // first batch on a queue that has not seen the kernel stalled the host for ~5 ms in the middle of the timed frames.
+  for (hipStream_t st : sys->ba_streams) ba_launch_compute(ws->pool, make_cfg(sys->tp), sys->S, st, -1, -1);
   HIPCHK(hipGetLastError());
+  HIPCHK(hipDeviceSynchronize());
   return VSLAM_OK;
 }
 
