@@ -361,31 +361,14 @@ def main():
         map_kw["per_level"] = tuple(int(x) for x in args.corners_per_level.split(","))
 
     # ---- synthetic scenes: one seeded feeder, trajectory and ground-truth map per stream -----------------------------
+    # Built CHUNK streams at a time (a feeder holds a 16.8 MB texture: all 3072 at once were 67 GB of host memory per rank, 530 GB for
+    # eight ranks of a node; now ~6 GB): feeders -> source keyframe images (host threads) -> their maximal FAST corners from the device
+    # front end in batches of FB images per call (3 + 2 launches per batch: a per-image front end was ~16,000 set-up launches for 2048
+    # streams, which a profiler pass with counters serialises one by one -- VERDICT r2 weak #11) -> maps (host threads) -> load_map, the
+    # start pose -> the stream's T frames rendered and uploaded as one contiguous piece -> the feeders closed (stream 0's is kept for
+    # the parity check).
     t_setup = time.time()
-    seeds = [1234 + rank * S + s for s in range(S)]
-    with ThreadPoolExecutor(nthreads) as ex:
-        feeders = list(ex.map(lambda sd: feeder.Feeder(W, H, seed=sd), seeds))
-    # The maps' source keyframes: rendered per stream (host threads), their maximal FAST corners from the device front end in batches of
-    # FB images per call (3 + 2 launches per batch: a per-image front end was ~16,000 set-up launches for 2048 streams, which a
-    # profiler pass with counters serialises one by one -- VERDICT r2 weak #11), the maps built from them on the host.
     NKF = 8
-    with ThreadPoolExecutor(nthreads) as ex:
-        kf_images = list(ex.map(lambda f: feeder.keyframe_images(f, n_keyframes=NKF), feeders))
-    FB = min(256, S * NKF)
-    fe = capi.System(capi.default_params(W, H, FB, patch_size=args.patch, device=local_rank))
-    flat_imgs = [im for ims in kf_images for im in ims]
-    kf_corners = []
-    for b0 in range(0, len(flat_imgs), FB):
-        chunk = flat_imgs[b0:b0 + FB]
-        batch = np.stack(chunk + [chunk[-1]] * (FB - len(chunk)))
-        fe.make_keyframe_lite(batch)
-        fe.fast_nonmax()
-        for i in range(len(chunk)):
-            kf_corners.append([fe.read_max_corners(i, l)[0] for l in range(4)])
-    fe.close()
-    with ThreadPoolExecutor(nthreads) as ex:
-        maps = list(ex.map(lambda s_: feeder.build_map(feeders[s_], None, n_keyframes=NKF, images=kf_images[s_], corners=kf_corners[s_ * NKF:(s_ + 1) * NKF], **map_kw), range(S)))
-    del flat_imgs, kf_corners
     NS = max(1, min(args.systems, S))
     assert S % NS == 0, "--streams must be a multiple of --systems"
     Sk = S // NS
@@ -407,21 +390,48 @@ def main():
     def sys_of(s):
         return systems[s // Sk], s % Sk
 
-    for s in range(S):
-        sy, ls = sys_of(s)
-        sy.load_map(ls, maps[s])
-        sy.set_pose(ls, feeders[s].pose(-1))
-        if stagger:                            # Tracker::mnLastKeyFrameDropped: stream s asks for its first keyframe in frame 1 + phase
-            sy.set_last_keyframe_dropped(ls, -20 + (s * stagger) // S)
     host_mode = bool(args.host_frames)
     # frame ring, stream-major ([S][T][H][W]: a stream's T frames are one contiguous upload, not T strided pieces)
     frames_dev = torch.empty((S, T, H, W), dtype=torch.uint8, device="cpu" if host_mode else "cuda", pin_memory=host_mode)
     host_frames0 = None
-    with ThreadPoolExecutor(max(1, nthreads // 4)) as ex:
-        for s, fr in enumerate(ex.map(lambda f: f.render(0, T, threads=4), feeders)):
-            frames_dev[s].copy_(torch.from_numpy(fr))
-            if s == 0:
-                host_frames0 = fr
+    feeder0 = map0 = None
+    CHUNK = 256
+    FB = min(256, S * NKF)
+    fe = capi.System(capi.default_params(W, H, FB, patch_size=args.patch, device=local_rank))
+    for c0 in range(0, S, CHUNK):
+        cs = list(range(c0, min(S, c0 + CHUNK)))
+        with ThreadPoolExecutor(nthreads) as ex:
+            feeders = list(ex.map(lambda s_: feeder.Feeder(W, H, seed=1234 + rank * S + s_), cs))
+            kf_images = list(ex.map(lambda f: feeder.keyframe_images(f, n_keyframes=NKF), feeders))
+        flat_imgs = [im for ims in kf_images for im in ims]
+        kf_corners = []
+        for b0 in range(0, len(flat_imgs), FB):
+            chunk = flat_imgs[b0:b0 + FB]
+            batch = np.stack(chunk + [chunk[-1]] * (FB - len(chunk)))
+            fe.make_keyframe_lite(batch)
+            fe.fast_nonmax()
+            for i in range(len(chunk)):
+                kf_corners.append([fe.read_max_corners(i, l)[0] for l in range(4)])
+        with ThreadPoolExecutor(nthreads) as ex:
+            maps = list(ex.map(lambda j: feeder.build_map(feeders[j], None, n_keyframes=NKF, images=kf_images[j], corners=kf_corners[j * NKF:(j + 1) * NKF], **map_kw), range(len(cs))))
+        for j, s_ in enumerate(cs):
+            sy, ls = sys_of(s_)
+            sy.load_map(ls, maps[j])
+            sy.set_pose(ls, feeders[j].pose(-1))
+            if stagger:                        # Tracker::mnLastKeyFrameDropped: stream s asks for its first keyframe in frame 1 + phase
+                sy.set_last_keyframe_dropped(ls, -20 + (s_ * stagger) // S)
+        with ThreadPoolExecutor(max(1, nthreads // 4)) as ex:
+            for j, fr in enumerate(ex.map(lambda f: f.render(0, T, threads=4), feeders)):
+                frames_dev[cs[j]].copy_(torch.from_numpy(fr))
+                if cs[j] == 0:
+                    host_frames0 = fr
+        if c0 == 0:
+            feeder0, map0 = feeders[0], maps[0]
+        for j, f in enumerate(feeders):
+            if f is not feeder0:
+                f.close()
+        del feeders, kf_images, flat_imgs, kf_corners, maps
+    fe.close()
     torch.cuda.synchronize()
     setup_s = time.time() - t_setup
     base = frames_dev.data_ptr()
@@ -622,8 +632,8 @@ def main():
             # stream 0 keeps the reference's own keyframe schedule (phase 0): the same frames through the oracle end at the same pose
             vp1 = capi.default_params(W, H, 1, **vp_kw)
             o = orc.OracleSystem(orc.params_from_vslam(vp1))
-            o.load_map(maps[0])
-            o.set_pose(feeders[0].pose(-1))
+            o.load_map(map0)
+            o.set_pose(feeder0.pose(-1))
             for t in range(T):
                 o.track_frame(host_frames0[t])
             pose_diff = float(np.abs(np.array(o.state().pose[:]) - np.array(st1[0].pose[:])).max())
