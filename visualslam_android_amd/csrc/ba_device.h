@@ -938,11 +938,26 @@ BA_PHASE_FN void ba_schur_mfma(const BaView& v_, int np, int nS, double lambda, 
   const int STRIDE = BA_WAVES * PPC;
   const int pfirst = wave * PPC;
   const int ksteps = diag ? BA_MFMA_K / 4 : (3 * PPC + 3) / 4;
-  auto slot_at = [&](int p0) -> int { const int p = p0 + pl; return (active && p < np) ? ba_slot_of(v, p, f) : -1; };
+  // A slot's index hangs on two words of its point (mask and offset of its F slots), its state on the index: two dependent round
+  // trips.  The pipeline is two deep accordingly: the point words of trip t+2 and the slot state of trip t+1 are requested in trip t
+  // (the index of t+1 is formed from the words requested a trip earlier), so that no request waits for one issued in the same trip.
+  auto slot_words = [&](int p0, unsigned long long& mk, int& off) {
+    const int p = p0 + pl, pc = p < np ? p : np - 1;
+    mk = v.pt_maskF[pc]; off = v.pt_offF[pc];
+  };
+  auto slot_from = [&](int p0, unsigned long long mk, int off) -> int {
+    const int p = p0 + pl;
+    if (!(active && p < np) || !((mk >> f) & 1ull)) return -1;
+    return off + __popcll(mk & ((1ull << f) - 1ull));                  // ba_slot_of
+  };
   MeasState ms_n; double V_n[6], eb_n[3];
+  unsigned long long mk_nn; int off_nn;
   {
     const int pc = pfirst + pl < np ? pfirst + pl : np - 1;
-    load_state_x(slot_at(pfirst), pc, ms_n);
+    unsigned long long mk0; int off0;
+    slot_words(pfirst, mk0, off0);
+    slot_words(pfirst + STRIDE, mk_nn, off_nn);
+    load_state_x(slot_from(pfirst, mk0, off0), pc, ms_n);
     _Pragma("unroll") for (int k = 0; k < 6; k++) V_n[k] = PT(pt_V, k, pc);
     _Pragma("unroll") for (int k = 0; k < 3; k++) eb_n[k] = PT(pt_eb, k, pc);
   }
@@ -954,9 +969,11 @@ BA_PHASE_FN void ba_schur_mfma(const BaView& v_, int np, int nS, double lambda, 
     _Pragma("unroll") for (int k = 0; k < 3; k++) eb[k] = eb_n[k];
     {
       const int pn = p0 + STRIDE + pl, pc = pn < np ? pn : np - 1;
-      load_state_x(slot_at(p0 + STRIDE), pc, ms_n);
+      const int slot_n = slot_from(p0 + STRIDE, mk_nn, off_nn);
+      load_state_x(slot_n, pc, ms_n);
       _Pragma("unroll") for (int k = 0; k < 6; k++) V_n[k] = PT(pt_V, k, pc);
       _Pragma("unroll") for (int k = 0; k < 3; k++) eb_n[k] = PT(pt_eb, k, pc);
+      slot_words(p0 + 2 * STRIDE, mk_nn, off_nn);
     }
     double Vi[9];                                                       // V*^-1 (:329-347)
     if (Vl[0] * Vl[2] * Vl[5] == 0) { _Pragma("unroll") for (int k = 0; k < 9; k++) Vi[k] = 0.0; }
