@@ -1273,7 +1273,8 @@ DEVFN void ba_compute(const BaView& v_, const BaConfig& cfg) {
     BA_STAMP(1);
     if (nvalid == 0) { if (threadIdx.x == 0) sh_error = 1; __syncthreads(); break; }
     {                                                              // :220-227 Tukey sigma, clamped
-      const double med = block_radix_select(v.scratch, M, nvalid / 2, hist, sel);
+      const double med = M > 4096 ? block_radix_select<16>(v.scratch, M, nvalid / 2, hist, sel)   // (big problems: 16 values per lane in flight, 64 per lane and sweep)
+                                  : block_radix_select<8>(v.scratch, M, nvalid / 2, hist, sel);
       double s2 = tukey_sigma_squared(med, (unsigned long)nvalid);
       if (s2 < cfg.min_sigma2) s2 = cfg.min_sigma2;
       if (threadIdx.x == 0) sh_sigma2 = s2;

@@ -312,7 +312,7 @@ template <int N> DEVFN int wave_multi_index(int lane) { return N == 64 ? lane : 
 // The values are read RS_BATCH at a time per thread before any histogram update, so the round trips of a batch overlap
 // (the pointer type is a template parameter: an address_space(1) pointer keeps the loads global instead of flat).
 #define RS_BATCH 8
-template <class VP>
+template <int BATCH = RS_BATCH, class VP>
 DEVFN double block_radix_select(VP v, int n, int k, int* hist, unsigned long long* sel) {
   for (int i = threadIdx.x; i < 768; i += blockDim.x) hist[i] = 0;
   __syncthreads();
@@ -322,12 +322,12 @@ DEVFN double block_radix_select(VP v, int n, int k, int* hist, unsigned long lon
   for (int pass = 0; pass < 8; pass++) {
     const int shift = 56 - 8 * pass;
     int* H = hist + 256 * (pass % 3);
-    for (int i0 = threadIdx.x; i0 < n; i0 += RS_BATCH * blockDim.x) {
-      unsigned long long b[RS_BATCH];
+    for (int i0 = threadIdx.x; i0 < n; i0 += BATCH * blockDim.x) {
+      unsigned long long b[BATCH];
 #pragma unroll
-      for (int u = 0; u < RS_BATCH; u++) { const int i = i0 + u * blockDim.x; b[u] = (unsigned long long)__double_as_longlong(v[i < n ? i : n - 1]); }
+      for (int u = 0; u < BATCH; u++) { const int i = i0 + u * blockDim.x; b[u] = (unsigned long long)__double_as_longlong(v[i < n ? i : n - 1]); }
 #pragma unroll
-      for (int u = 0; u < RS_BATCH; u++) if (i0 + u * (int)blockDim.x < n && (b[u] & mask) == prefix) atomicAdd(&H[(b[u] >> shift) & 255], 1);
+      for (int u = 0; u < BATCH; u++) if (i0 + u * (int)blockDim.x < n && (b[u] & mask) == prefix) atomicAdd(&H[(b[u] >> shift) & 255], 1);
     }
     __syncthreads();
     const int h0 = H[4 * l], h1 = H[4 * l + 1], h2 = H[4 * l + 2], h3 = H[4 * l + 3];   // 4 bins per lane, shuffle prefix sum
@@ -348,12 +348,12 @@ DEVFN double block_radix_select(VP v, int n, int k, int* hist, unsigned long lon
     int* Z = hist + 256 * ((pass + 2) % 3);
     for (int i = threadIdx.x; i < 256; i += blockDim.x) Z[i] = 0;
     if (cnt == 1 && pass < 7) {                                    // one value left under the prefix: fetch it whole
-      for (int i0 = threadIdx.x; i0 < n; i0 += RS_BATCH * blockDim.x) {
-        unsigned long long b[RS_BATCH];
+      for (int i0 = threadIdx.x; i0 < n; i0 += BATCH * blockDim.x) {
+        unsigned long long b[BATCH];
 #pragma unroll
-        for (int u = 0; u < RS_BATCH; u++) { const int i = i0 + u * blockDim.x; b[u] = (unsigned long long)__double_as_longlong(v[i < n ? i : n - 1]); }
+        for (int u = 0; u < BATCH; u++) { const int i = i0 + u * blockDim.x; b[u] = (unsigned long long)__double_as_longlong(v[i < n ? i : n - 1]); }
 #pragma unroll
-        for (int u = 0; u < RS_BATCH; u++) if (i0 + u * (int)blockDim.x < n && (b[u] & mask) == prefix) sel[0] = b[u];
+        for (int u = 0; u < BATCH; u++) if (i0 + u * (int)blockDim.x < n && (b[u] & mask) == prefix) sel[0] = b[u];
       }
       __syncthreads();
       prefix = sel[0];
