@@ -293,6 +293,7 @@ struct SearchArgs {
   int w[NLEV], h[NLEV], cap[NLEV];
   size_t kf_stride[NLEV];       // bytes per keyframe image at level l
   int kf_pitch[NLEV];
+  int nblk, S;                  // the launch's workgroups per stream and streams (xcd_stream_block)
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -313,17 +314,32 @@ template <int G> DEVFN int grp_sum_i(int v) { for (int d = 1; d < G; d <<= 1) v 
 template <int G> DEVFN double grp_sum_d(double v) { for (int d = 1; d < G; d <<= 1) v += __shfl_xor(v, d); return v; }
 DEVFN unsigned udot4(unsigned a, unsigned b, unsigned c) { return __builtin_amdgcn_udot4(a, b, c, false); }
 
+// Workgroups go to the eight XCDs of the device round-robin by their linear index, and every XCD has its own L2.  The search kernels
+// gather from one stream's frame pyramid and keyframes: with (patch block, stream) as (x, y) of the grid the ~140 workgroups of a stream
+// were dealt over all eight L2s, each of which fetched the stream's images for itself.  The grid is one-dimensional instead and the linear
+// index i is read as (xcd = i % 8, then patch block, then group of eight streams): all workgroups of a stream share i % 8, i.e. one L2.
+#define TRK_XCDS 8
+DEVFN void xcd_stream_block(int nblk, int S, int& s, int& blk) {
+  const int i = blockIdx.x, x = i % TRK_XCDS, j = i / TRK_XCDS;
+  blk = j % nblk;
+  s = (j / nblk) * TRK_XCDS + x;
+  if (s >= S) s = -1;
+}
+static int xcd_grid(int nblk, int S) { return nblk * ((S + TRK_XCDS - 1) / TRK_XCDS) * TRK_XCDS; }
+
 template <int PS, int G>
 __global__ __launch_bounds__(64) void k_searchN(MapDev m, TrackParams tp, SearchArgs a, int stage) {
   constexpr int NPIX = PS * PS, HALF = PS / 2, PPW = 64 / G, NW = (PS + 3) / 4;
-  const int s = blockIdx.y;
+  int s, bx;
+  xcd_stream_block(a.nblk, a.S, s, bx);
+  if (s < 0) return;
   TrackerState* st = &m.st[s];
   if (!(st->map_good && st->lost_frames < 3)) return;
   const int nsearch = st->n_search;
-  if ((int)blockIdx.x * PPW >= nsearch) return;
+  if (bx * PPW >= nsearch) return;
   const int lane = threadIdx.x, grp = lane / G, sub = lane % G;
   const bool rowact = sub < PS;                                      // this lane owns a template row
-  const int e = blockIdx.x * PPW + grp;
+  const int e = bx * PPW + grp;
   bool act = e < nsearch;                                            // this lane group has a patch
   const bool lead = sub == 0;
   const int2 ent = act ? m.search_list[(size_t)s * tp.max_points + e] : make_int2(0, 0);
@@ -623,11 +639,13 @@ DEVFN void subpix_block(const MapDev& m, const TrackParams& tp, const SearchArgs
 #define SUBPIX_GRID 16     // the entries with a sub-pixel budget are few (level-3 points / the coarse set): a short grid that strides
 template <int PS, int G>
 __global__ __launch_bounds__(64) void k_subpixN(MapDev m, TrackParams tp, SearchArgs a, int stage) {
-  const int s = blockIdx.y;
+  int s, bx;
+  xcd_stream_block(a.nblk, a.S, s, bx);
+  if (s < 0) return;
   TrackerState* st = &m.st[s];
   if (!(st->map_good && st->lost_frames < 3)) return;
   const int nsub = stage == 0 ? st->n_search : st->n_l3;             // entries that carry a sub-pixel budget
-  for (int blk = blockIdx.x; blk * (64 / G) < nsub; blk += gridDim.x) subpix_block<PS, G>(m, tp, a, st, s, nsub, blk);
+  for (int blk = bx; blk * (64 / G) < nsub; blk += a.nblk) subpix_block<PS, G>(m, tp, a, st, s, nsub, blk);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1228,6 +1246,7 @@ int trk_search_stage(vslam_system* sys, int stage) {
   const TrackParams& tp = sys->tp;
   SearchArgs a;
   trk_search_args(sys, a);
+  a.S = S; a.nblk = 1;
   if (stage == 0) {
     prof_mark(sys, 3);
     hipLaunchKernelGGL(k_motion, dim3((S + 63) / 64), dim3(64), 0, sys->stream, m, S, sys->p.use_sbi ? (const double*)sys->fr.sbi_rot : (const double*)nullptr);
@@ -1238,11 +1257,11 @@ int trk_search_stage(vslam_system* sys, int stage) {
     if (!tp.coarse_disabled) {
       const int nc = 2 * tp.coarse_max;
       if (tp.P == 8) {
-        hipLaunchKernelGGL((k_searchN<8, 8>), dim3((nc + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 0);
-        if (tp.coarse_subpix_its > 0) hipLaunchKernelGGL((k_subpixN<8, 8>), dim3(SUBPIX_GRID, S), dim3(64), 0, sys->stream, m, tp, a, 0);
+        a.nblk = (nc + 7) / 8; hipLaunchKernelGGL((k_searchN<8, 8>), dim3(xcd_grid(a.nblk, S)), dim3(64), 0, sys->stream, m, tp, a, 0);
+        if (tp.coarse_subpix_its > 0) { a.nblk = SUBPIX_GRID; hipLaunchKernelGGL((k_subpixN<8, 8>), dim3(xcd_grid(a.nblk, S)), dim3(64), 0, sys->stream, m, tp, a, 0); }
       } else {
-        hipLaunchKernelGGL((k_searchN<11, 16>), dim3((nc + 3) / 4, S), dim3(64), 0, sys->stream, m, tp, a, 0);
-        if (tp.coarse_subpix_its > 0) hipLaunchKernelGGL((k_subpixN<11, 16>), dim3(SUBPIX_GRID, S), dim3(64), 0, sys->stream, m, tp, a, 0);
+        a.nblk = (nc + 3) / 4; hipLaunchKernelGGL((k_searchN<11, 16>), dim3(xcd_grid(a.nblk, S)), dim3(64), 0, sys->stream, m, tp, a, 0);
+        if (tp.coarse_subpix_its > 0) { a.nblk = SUBPIX_GRID; hipLaunchKernelGGL((k_subpixN<11, 16>), dim3(xcd_grid(a.nblk, S)), dim3(64), 0, sys->stream, m, tp, a, 0); }
       }
     }
     prof_mark(sys, 6);
@@ -1252,11 +1271,11 @@ int trk_search_stage(vslam_system* sys, int stage) {
     hipLaunchKernelGGL(k_plan, dim3(S), dim3(TRK_THREADS), 0, sys->stream, m, tp, 1);
     prof_mark(sys, 8);
     if (tp.P == 8) {
-      hipLaunchKernelGGL((k_searchN<8, 8>), dim3((maxSearch + 7) / 8, S), dim3(64), 0, sys->stream, m, tp, a, 1);
-      if (tp.fine_subpix_its > 0) hipLaunchKernelGGL((k_subpixN<8, 8>), dim3(SUBPIX_GRID, S), dim3(64), 0, sys->stream, m, tp, a, 1);
+      a.nblk = (maxSearch + 7) / 8; hipLaunchKernelGGL((k_searchN<8, 8>), dim3(xcd_grid(a.nblk, S)), dim3(64), 0, sys->stream, m, tp, a, 1);
+      if (tp.fine_subpix_its > 0) { a.nblk = SUBPIX_GRID; hipLaunchKernelGGL((k_subpixN<8, 8>), dim3(xcd_grid(a.nblk, S)), dim3(64), 0, sys->stream, m, tp, a, 1); }
     } else {
-      hipLaunchKernelGGL((k_searchN<11, 16>), dim3((maxSearch + 3) / 4, S), dim3(64), 0, sys->stream, m, tp, a, 1);
-      if (tp.fine_subpix_its > 0) hipLaunchKernelGGL((k_subpixN<11, 16>), dim3(SUBPIX_GRID, S), dim3(64), 0, sys->stream, m, tp, a, 1);
+      a.nblk = (maxSearch + 3) / 4; hipLaunchKernelGGL((k_searchN<11, 16>), dim3(xcd_grid(a.nblk, S)), dim3(64), 0, sys->stream, m, tp, a, 1);
+      if (tp.fine_subpix_its > 0) { a.nblk = SUBPIX_GRID; hipLaunchKernelGGL((k_subpixN<11, 16>), dim3(xcd_grid(a.nblk, S)), dim3(64), 0, sys->stream, m, tp, a, 1); }
     }
     prof_mark(sys, 9);
   }
