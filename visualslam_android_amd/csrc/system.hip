@@ -91,6 +91,8 @@ extern "C" int vslam_create(const vslam_params* p, vslam_system** out) {
   sys->S = p->n_streams;
   sys->have_frame = false;
   sys->stream = nullptr;
+  // (default priorities: the tracker's stream at the highest priority, with or without the front end's at the lowest, was measured at
+  // 3072 streams: 376 k against 398-400 k frames/s -- the front end of frame t+1 then finishes late and the tracker waits for it)
   if (hipStreamCreateWithFlags(&sys->stream, hipStreamNonBlocking) != hipSuccess) {
     vslam_set_error("create: hipStreamCreate failed"); delete sys; return VSLAM_E_HIP;
   }
